@@ -1,0 +1,135 @@
+/*
+ * reface_hip.h -- C-ABI of the MI355X (gfx950) REFace inference kernels.
+ *
+ * The reference (Sanoojan/REFace) is 100 % Python: its "operator API" for the hot path is the
+ * set of ATen calls issued by ldm/modules/diffusionmodules/openaimodel.py, ldm/modules/attention.py,
+ * ldm/modules/diffusionmodules/model.py and ldm/models/diffusion/ddim.py.
+ * Each entry point below replaces one family of those calls; the reference line it stands in for
+ * is cited next to it.  The Python host layer (reface_amd/*.py) binds these with ctypes; the
+ * binding a reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers + sizes; no torch types.  All pointers are DEVICE pointers, 16-byte aligned.
+ *   - the caller owns every buffer; kernels never allocate.
+ *   - `stream` is a hipStream_t passed as void* (the caller's current PyTorch HIP stream).
+ *   - every function returns 0 on success, non-zero on error; rf_last_error() gives the message.
+ *   - activations are channels-last: a tensor [B, H, W, C] is a row-major matrix [B*H*W, C].
+ *   - dtype codes: RF_F32 = 0 (fp32 storage, exact-fp32 MFMA), RF_BF16 = 1 (bf16 storage, fp32 accumulate).
+ */
+#ifndef REFACE_HIP_H
+#define REFACE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { RF_F32 = 0, RF_BF16 = 1 };
+
+/* epilogue activations of rf_conv_gemm */
+enum { RF_ACT_NONE = 0, RF_ACT_GEGLU = 1, RF_ACT_SILU = 2, RF_ACT_QUICK_GELU = 3, RF_ACT_GELU = 4 };
+
+const char* rf_last_error(void);
+int rf_version(void);
+
+/*
+ * rf_conv_gemm -- implicit-GEMM convolution / linear layer on the matrix cores:
+ *
+ *     out[m, n] = act( alpha * sum_k A[m, k] * W[n, k] + bias[n] + rowvec[sample(m), n] ) + residual[m, n]
+ *
+ * A is never materialised: row m is output pixel (b, oy, ox); k = (ky*KW + kx) * (C0 + C1) + c
+ * addresses input pixel (oy*stride - pad_t + ky, ox*stride - pad_l + kx) of a channels-last source,
+ * optionally nearest-upsampled x2 on the fly (`ups`) and optionally the channel concatenation of two
+ * sources [src0 | src1] (UNet skip connections).  KH = KW = 1 with B*Hin*Win = M gives a plain GEMM
+ * (nn.Linear / 1x1 conv); `batch` > 1 runs independent problems (strides in elements).
+ *
+ * Replaces: F.conv2d 3x3 / 1x1 in ResBlock, Downsample, Upsample, UNet in/out convs
+ * (openaimodel.py:107,116,151-153,204,230,241,669,835), nn.Linear in attention / GEGLU / time-embed
+ * (attention.py:40,60,159-170; openaimodel.py:218-224,632-636), torch.cat([h, hs.pop()])
+ * (openaimodel.py:898), F.interpolate nearest (openaimodel.py:116), the VAE convs
+ * (model.py:60-79,97-121,155-174) and bmm in the VAE AttnBlock (model.py:186-198).
+ */
+typedef struct rf_conv_gemm_desc {
+    int32_t dtype;        /* RF_F32 | RF_BF16: element type of src0/src1/W */
+    int32_t out_dtype;    /* element type of out and residual */
+    int32_t M, N, K;      /* GEMM view; K = KH*KW*(C0+C1) (may be padded up to a multiple of 8) */
+    const void* src0;
+    const void* src1;     /* optional second source (channel concat), NULL if unused */
+    int32_t C0, C1;       /* channels taken from src0 / src1 */
+    int32_t ld0, ld1;     /* pixel pitch (elements) of src0 / src1 */
+    int32_t Hin, Win;     /* spatial size of the stored source (before `ups`) */
+    int32_t Hout, Wout;   /* spatial size of the output; M = B*Hout*Wout */
+    int32_t KH, KW, stride, pad_t, pad_l, ups;
+    const void* W;        /* [N][K] row-major */
+    const float* bias;    /* [N] fp32 or NULL */
+    const float* rowvec;  /* [M / rows_per_sample][ldv] fp32 or NULL */
+    int32_t rows_per_sample, ldv;
+    const void* residual; /* [M][ldr] (out_dtype) or NULL */
+    int32_t ldr;
+    int32_t act;          /* RF_ACT_* ; GEGLU: W rows interleaved in blocks of 32 (value|gate), out has N/2 columns */
+    void* out;
+    int32_t ldo;
+    float alpha;
+    int32_t batch;        /* >= 1 */
+    int64_t sA, sW, sO, sR;   /* batch strides (elements) of src0, W, out, residual */
+} rf_conv_gemm_desc;
+
+int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream);
+
+/*
+ * GroupNorm(32 groups) over channels-last [B, HW, C]  (+ optional SiLU), two launches:
+ *   rf_groupnorm_stats : per (b, chunk, group) partial (sum, sumsq) in fp64 -> `partial`
+ *                        partial must hold B * nchunks * 32 * 2 doubles.
+ *   rf_groupnorm_apply : y = (x - mean) * rstd * gamma + beta, optional SiLU.
+ * Replaces nn.GroupNorm / GroupNorm32 + nn.SiLU (util.py:214-216, attention.py:76-77,
+ * model.py:33-39; openaimodel.py:201-203,225-227,832-834).
+ */
+int rf_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, int ldx, int nchunks, double* partial, void* stream);
+int rf_groupnorm_apply(int dtype, const void* x, int B, int HW, int C, int ldx, int nchunks, const double* partial,
+                       const float* gamma, const float* beta, float eps, int silu, int out_dtype, void* out, int ldo, void* stream);
+
+/* LayerNorm over the last dim of [M, C] (eps, affine).  Replaces nn.LayerNorm (attention.py:231-233,
+ * xf.py:22-28, HF CLIP layer norms). */
+int rf_layernorm(int dtype, const void* x, int M, int C, int ldx, const float* gamma, const float* beta, float eps,
+                 int out_dtype, void* out, int ldo, void* stream);
+
+/*
+ * Fused multi-head attention  out = softmax(scale * q k^T) v  without materialising the scores.
+ * q/k/v/out are [B, N, heads*d] views with pixel pitches ldq/ldk/ldv/ldo (so q, k, v may live in
+ * one fused [B, N, 3*heads*d] buffer).  Nq query tokens, Nk key tokens per batch element.
+ * Replaces attention.py:206-220 (einsum + softmax + einsum) and HF CLIPAttention.
+ */
+int rf_attention(int dtype, const void* q, const void* k, const void* v, void* out,
+                 int B, int heads, int d, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo,
+                 int64_t sq, int64_t sk, int64_t sv, int64_t so, float scale, void* stream);
+
+/* Row softmax over the last dim of [rows, cols] fp32, in place allowed (VAE AttnBlock, model.py:188). */
+int rf_softmax_rows(float* x, int rows, int cols, int ld, void* stream);
+
+/*
+ * DDIM step glue (ddim.py:330-374):
+ *   rf_ddim_pack_input : x_in[2B or B, h, w, Cpad] = [img | z_inpaint | mask | 0-pad], duplicated for CFG.
+ *   rf_ddim_update     : e = e_u + s (e_c - e_u); pred_x0 = (x - sqrt(1-a_t) e) / sqrt(a_t);
+ *                        x_prev = sqrt(a_prev) pred_x0 + sqrt(1 - a_prev - sigma^2) e + sigma * noise.
+ *   All latent tensors are fp32 NCHW [B, 4, h, w] (the sampler's external layout); eps is the UNet
+ *   output in channels-last fp32 [2B or B, h*w, ld_eps].
+ */
+int rf_ddim_pack_input(const float* img, const float* z_inpaint, const float* mask, int B, int hw, int dup,
+                       int out_dtype, void* x_in, int Cpad, void* stream);
+int rf_ddim_update(const float* eps, int ld_eps, int cfg, float scale, float* img, float* pred_x0, const float* noise,
+                   int B, int hw, float sqrt_at, float sqrt_1m_at, float sqrt_aprev, float dir_coef, float sigma, void* stream);
+
+/* Layout / dtype helpers. */
+int rf_nchw_to_nhwc(const float* x, int B, int C, int HW, int out_dtype, void* out, int Cpad, void* stream);
+int rf_nhwc_to_nchw(int dtype, const void* x, int B, int C, int HW, int ldx, float* out, void* stream);
+int rf_cast(int in_dtype, const void* x, int out_dtype, void* out, int64_t n, void* stream);
+/* sinusoidal timestep embedding [n, dim] = [cos(t f) | sin(t f)] (util.py:151-166); freqs [dim/2] fp32 */
+int rf_timestep_embedding(const float* t, int n, int dim, const float* freqs, float* out, void* stream);
+/* elementwise y = silu(x) on fp32 (emb path, openaimodel.py:219) */
+int rf_silu_f32(const float* x, float* y, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REFACE_HIP_H */

@@ -1,0 +1,86 @@
+"""ctypes binding of the C-ABI in include/reface_hip.h (libreface_hip.so, built by reface_amd/build.py).
+
+There is NO fallback: if the shared library is missing or fails to load, importing any compute
+path raises (the product never routes through PyTorch eager ops or the CPU oracle).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libreface_hip.so")
+
+RF_F32, RF_BF16 = 0, 1
+ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU, ACT_GELU = 0, 1, 2, 3, 4
+
+
+class ConvGemmDesc(C.Structure):
+    """Mirror of ``rf_conv_gemm_desc`` (include/reface_hip.h)."""
+    _fields_ = [
+        ("dtype", C.c_int32), ("out_dtype", C.c_int32),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("src0", C.c_void_p), ("src1", C.c_void_p),
+        ("C0", C.c_int32), ("C1", C.c_int32), ("ld0", C.c_int32), ("ld1", C.c_int32),
+        ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
+        ("ups", C.c_int32),
+        ("W", C.c_void_p), ("bias", C.c_void_p), ("rowvec", C.c_void_p),
+        ("rows_per_sample", C.c_int32), ("ldv", C.c_int32),
+        ("residual", C.c_void_p), ("ldr", C.c_int32), ("act", C.c_int32),
+        ("out", C.c_void_p), ("ldo", C.c_int32), ("alpha", C.c_float),
+        ("batch", C.c_int32),
+        ("sA", C.c_int64), ("sW", C.c_int64), ("sO", C.c_int64), ("sR", C.c_int64),
+    ]
+
+
+_SIGS = {
+    "rf_last_error": (C.c_char_p, []),
+    "rf_version": (C.c_int, []),
+    "rf_conv_gemm": (C.c_int, [C.POINTER(ConvGemmDesc), C.c_void_p]),
+    "rf_groupnorm_stats": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "rf_groupnorm_apply": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "rf_layernorm": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
+                               C.c_void_p, C.c_int, C.c_void_p]),
+    "rf_attention": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_void_p]),
+    "rf_softmax_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "rf_ddim_pack_input": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "rf_ddim_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "rf_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "rf_nhwc_to_nchw": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "rf_cast": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "rf_timestep_embedding": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rf_silu_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+class RefaceHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libreface_hip.so (once) and attach the prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RefaceHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m reface_amd.build` "
+            "(or __graft_entry__.build()). There is no CPU / eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)       # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().rf_last_error()
+        raise RefaceHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,52 @@
+"""Build the gfx950 shared library  reface_amd/lib/libreface_hip.so  with hipcc (in-tree).
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so
+travels to the GPU box with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libreface_hip.so")
+SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+
+
+def _stale(obj, deps):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "reface_hip.h")]
+    objs, procs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((s, subprocess.Popen(cmd)))
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {s}")
+    if force or procs or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,115 @@
+// Shared device/host helpers for the gfx950 REFace kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/reface_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+typedef uint16_t bf16_t;   // storage type of bf16 values
+
+namespace rf {
+
+void set_error(const char* fmt, ...);
+
+#define RF_CHECK(cond, ...)                                     \
+    do {                                                        \
+        if (!(cond)) {                                          \
+            rf::set_error(__VA_ARGS__);                         \
+            return 1;                                           \
+        }                                                       \
+    } while (0)
+
+#define RF_LAUNCH_CHECK(name)                                               \
+    do {                                                                    \
+        hipError_t e_ = hipGetLastError();                                  \
+        if (e_ != hipSuccess) {                                             \
+            rf::set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return 2;                                                       \
+        }                                                                   \
+    } while (0)
+
+// Bit casts BY VALUE.  hipcc (ROCm 7.2) miscompiles __builtin_bit_cast applied directly to an element
+// lvalue of an ext_vector_type (v[q] in an unrolled loop collapses to v[0]); copying the element into a
+// by-value parameter first is safe.
+__device__ __forceinline__ float as_f32(uint32_t x) { return __builtin_bit_cast(float, x); }
+__device__ __forceinline__ uint32_t as_u32(float x) { return __builtin_bit_cast(uint32_t, x); }
+
+// round-to-nearest-even fp32 -> bf16 (NaN preserved), same rule as torch .to(bfloat16)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = as_u32( f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return as_f32( ((uint32_t)h) << 16); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+template <typename T> struct elem;
+template <> struct elem<float> {
+    static constexpr int VEC = 4;   // elements per 16-byte vector
+    __device__ static __forceinline__ float load(const float* p) { return *p; }
+    __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct elem<bf16_t> {
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ float load(const bf16_t* p) { return bf2f(*p); }
+    __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// unpack a 16-byte vector of T into floats
+template <typename T> __device__ __forceinline__ void unpack16(const u32x4_t& v, float* f);
+template <> __device__ __forceinline__ void unpack16<float>(const u32x4_t& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = as_f32( v[i]);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const u32x4_t& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = as_f32( v[i] << 16);
+        f[2 * i + 1] = as_f32( v[i] & 0xffff0000u);
+    }
+}
+template <typename T> __device__ __forceinline__ u32x4_t pack16(const float* f);
+template <> __device__ __forceinline__ u32x4_t pack16<float>(const float* f) {
+    u32x4_t v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = as_u32( f[i]);
+    return v;
+}
+template <> __device__ __forceinline__ u32x4_t pack16<bf16_t>(const float* f) {
+    u32x4_t v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + expf(-1.702f * x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace rf

@@ -1,0 +1,168 @@
+// Small HBM-bound glue kernels: DDIM step arithmetic, layout changes, casts, timestep embedding.
+#include "common.h"
+
+namespace rf {
+
+template <typename TO> __device__ __forceinline__ void st(TO* p, float v);
+template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// x_in[(dup*B), hw, Cpad] = [img(4) | z_inpaint(4) | mask(1) | 0...]   (ddim.py:330, 338)
+template <typename TO>
+__global__ void ddim_pack_kernel(const float* __restrict__ img, const float* __restrict__ z, const float* __restrict__ mask,
+                                 int B, int hw, int dup, TO* __restrict__ out, int Cpad) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*hw pixels
+    if (i >= (long long)B * hw) return;
+    const int b = (int)(i / hw), p = (int)(i - (long long)b * hw);
+    float v[9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        v[c] = img[((long long)b * 4 + c) * hw + p];
+        v[4 + c] = z[((long long)b * 4 + c) * hw + p];
+    }
+    v[8] = mask[(long long)b * hw + p];
+    for (int r = 0; r < dup; ++r) {
+        TO* o = out + ((long long)(r * B + b) * hw + p) * Cpad;
+        for (int c = 0; c < Cpad; ++c) st<TO>(o + c, c < 9 ? v[c] : 0.f);
+    }
+}
+
+// ddim.py:346, 364-374 on NCHW fp32 latents; eps is channels-last [(2B|B), hw, ld]
+__global__ void ddim_update_kernel(const float* __restrict__ eps, int ld, int cfg, float scale, float* __restrict__ img,
+                                   float* __restrict__ pred_x0, const float* __restrict__ noise, int B, int hw,
+                                   float sqrt_at, float sqrt_1m_at, float sqrt_aprev, float dir_coef, float sigma) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*4*hw
+    if (i >= (long long)B * 4 * hw) return;
+    const int p = (int)(i % hw);
+    const int c = (int)((i / hw) % 4);
+    const int b = (int)(i / ((long long)4 * hw));
+    float e;
+    if (cfg) {
+        const float eu = eps[((long long)b * hw + p) * ld + c];
+        const float ec = eps[((long long)(B + b) * hw + p) * ld + c];
+        e = eu + scale * (ec - eu);
+    } else {
+        e = eps[((long long)b * hw + p) * ld + c];
+    }
+    const float x = img[i];
+    const float px0 = (x - sqrt_1m_at * e) / sqrt_at;
+    float xp = sqrt_aprev * px0 + dir_coef * e;
+    if (noise) xp += sigma * noise[i];
+    img[i] = xp;
+    if (pred_x0) pred_x0[i] = px0;
+}
+
+template <typename TO>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int B, int C, int HW, TO* __restrict__ out, int Cpad) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*HW*Cpad (output order)
+    if (i >= (long long)B * HW * Cpad) return;
+    const int c = (int)(i % Cpad);
+    const long long bp = i / Cpad;
+    const int p = (int)(bp % HW), b = (int)(bp / HW);
+    st<TO>(out + i, c < C ? x[((long long)b * C + c) * HW + p] : 0.f);
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, int B, int C, int HW, int ldx, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*C*HW (output order)
+    if (i >= (long long)B * C * HW) return;
+    const int p = (int)(i % HW);
+    const int c = (int)((i / HW) % C);
+    const int b = (int)(i / ((long long)C * HW));
+    out[i] = elem<T>::load(x + ((long long)b * HW + p) * ldx + c);
+}
+
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) st<TO>(y + i, elem<TI>::load(x + i));
+}
+
+// util.py:151-166; `freqs` [dim/2] = exp(-ln(max_period) * k / half) is a host-built fp32 table
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int n, int dim, const float* __restrict__ freqs, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim / 2;
+    if (i >= n * half) return;
+    const int r = i / half, k = i - r * half;
+    const float a = t[r] * freqs[k];
+    out[(long long)r * dim + k] = cosf(a);
+    out[(long long)r * dim + half + k] = sinf(a);
+    if ((dim & 1) && k == 0) out[(long long)r * dim + dim - 1] = 0.f;
+}
+
+__global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = silu_exact(x[i]);
+}
+
+static inline dim3 grid1d(long long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+}  // namespace rf
+
+using namespace rf;
+
+extern "C" int rf_ddim_pack_input(const float* img, const float* z_inpaint, const float* mask, int B, int hw, int dup,
+                                  int out_dtype, void* x_in, int Cpad, void* stream) {
+    RF_CHECK(img && z_inpaint && mask && x_in && B > 0 && hw > 0 && (dup == 1 || dup == 2) && Cpad >= 9, "rf_ddim_pack_input: bad arguments");
+    hipStream_t st_ = (hipStream_t)stream;
+    if (out_dtype == RF_F32) hipLaunchKernelGGL(ddim_pack_kernel<float>, grid1d((long long)B * hw), dim3(256), 0, st_, img, z_inpaint, mask, B, hw, dup, (float*)x_in, Cpad);
+    else if (out_dtype == RF_BF16) hipLaunchKernelGGL(ddim_pack_kernel<bf16_t>, grid1d((long long)B * hw), dim3(256), 0, st_, img, z_inpaint, mask, B, hw, dup, (bf16_t*)x_in, Cpad);
+    else RF_CHECK(false, "rf_ddim_pack_input: bad out_dtype %d", out_dtype);
+    RF_LAUNCH_CHECK("rf_ddim_pack_input");
+    return 0;
+}
+
+extern "C" int rf_ddim_update(const float* eps, int ld_eps, int cfg, float scale, float* img, float* pred_x0, const float* noise,
+                              int B, int hw, float sqrt_at, float sqrt_1m_at, float sqrt_aprev, float dir_coef, float sigma, void* stream) {
+    RF_CHECK(eps && img && B > 0 && hw > 0 && ld_eps >= 4, "rf_ddim_update: bad arguments");
+    hipLaunchKernelGGL(ddim_update_kernel, grid1d((long long)B * 4 * hw), dim3(256), 0, (hipStream_t)stream, eps, ld_eps, cfg, scale, img,
+                       pred_x0, noise, B, hw, sqrt_at, sqrt_1m_at, sqrt_aprev, dir_coef, sigma);
+    RF_LAUNCH_CHECK("rf_ddim_update");
+    return 0;
+}
+
+extern "C" int rf_nchw_to_nhwc(const float* x, int B, int C, int HW, int out_dtype, void* out, int Cpad, void* stream) {
+    RF_CHECK(x && out && B > 0 && C > 0 && HW > 0 && Cpad >= C, "rf_nchw_to_nhwc: bad arguments");
+    const long long n = (long long)B * HW * Cpad;
+    if (out_dtype == RF_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid1d(n), dim3(256), 0, (hipStream_t)stream, x, B, C, HW, (float*)out, Cpad);
+    else if (out_dtype == RF_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid1d(n), dim3(256), 0, (hipStream_t)stream, x, B, C, HW, (bf16_t*)out, Cpad);
+    else RF_CHECK(false, "rf_nchw_to_nhwc: bad out_dtype %d", out_dtype);
+    RF_LAUNCH_CHECK("rf_nchw_to_nhwc");
+    return 0;
+}
+
+extern "C" int rf_nhwc_to_nchw(int dtype, const void* x, int B, int C, int HW, int ldx, float* out, void* stream) {
+    RF_CHECK(x && out && B > 0 && C > 0 && HW > 0 && ldx >= C, "rf_nhwc_to_nchw: bad arguments");
+    const long long n = (long long)B * C * HW;
+    if (dtype == RF_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid1d(n), dim3(256), 0, (hipStream_t)stream, (const float*)x, B, C, HW, ldx, out);
+    else if (dtype == RF_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid1d(n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, B, C, HW, ldx, out);
+    else RF_CHECK(false, "rf_nhwc_to_nchw: bad dtype %d", dtype);
+    RF_LAUNCH_CHECK("rf_nhwc_to_nchw");
+    return 0;
+}
+
+extern "C" int rf_cast(int in_dtype, const void* x, int out_dtype, void* out, int64_t n, void* stream) {
+    RF_CHECK(x && out && n > 0, "rf_cast: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (in_dtype == RF_F32 && out_dtype == RF_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), grid1d(n), dim3(256), 0, s, (const float*)x, (bf16_t*)out, (long long)n);
+    else if (in_dtype == RF_BF16 && out_dtype == RF_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid1d(n), dim3(256), 0, s, (const bf16_t*)x, (float*)out, (long long)n);
+    else if (in_dtype == RF_F32 && out_dtype == RF_F32) hipLaunchKernelGGL((cast_kernel<float, float>), grid1d(n), dim3(256), 0, s, (const float*)x, (float*)out, (long long)n);
+    else if (in_dtype == RF_BF16 && out_dtype == RF_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), grid1d(n), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, (long long)n);
+    else RF_CHECK(false, "rf_cast: bad dtypes %d -> %d", in_dtype, out_dtype);
+    RF_LAUNCH_CHECK("rf_cast");
+    return 0;
+}
+
+extern "C" int rf_timestep_embedding(const float* t, int n, int dim, const float* freqs, float* out, void* stream) {
+    RF_CHECK(t && out && freqs && n > 0 && dim >= 2, "rf_timestep_embedding: bad arguments");
+    hipLaunchKernelGGL(timestep_embedding_kernel, grid1d((long long)n * (dim / 2)), dim3(256), 0, (hipStream_t)stream, t, n, dim, freqs, out);
+    RF_LAUNCH_CHECK("rf_timestep_embedding");
+    return 0;
+}
+
+extern "C" int rf_silu_f32(const float* x, float* y, int64_t n, void* stream) {
+    RF_CHECK(x && y && n > 0, "rf_silu_f32: bad arguments");
+    hipLaunchKernelGGL(silu_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, x, y, (long long)n);
+    RF_LAUNCH_CHECK("rf_silu_f32");
+    return 0;
+}

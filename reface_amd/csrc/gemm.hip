@@ -1,0 +1,329 @@
+// Implicit-GEMM convolution / linear layer on the gfx950 matrix cores.
+//
+//   out[m, n] = act(alpha * sum_k A[m, k] W[n, k] + bias[n] + rowvec[sample(m), n]) + residual[m, n]
+//
+// One kernel template serves both storage types through a common *byte* geometry: a K-tile is
+// 128 bytes of K per row (64 bf16 or 32 fp32), LDS rows are 128 B with a 16-B-slot XOR swizzle,
+// every lane feeds the MFMA from one 16-B fragment (lane l: row l&31, slot 2*kk + (l>>5)):
+//   bf16 : 1 x v_mfma_f32_32x32x16_bf16 per fragment pair (8 k per lane-half)
+//   fp32 : 4 x v_mfma_f32_32x32x2_f32   per fragment pair (exact fp32 FMA chain, 157 TF peak)
+// The A operand is gathered on the fly from channels-last source tensors (3x3 / 1x1, stride,
+// asymmetric padding, nearest x2 upsample folded into the addressing, 2-source channel concat),
+// staged global -> registers -> LDS with the next tile's loads issued before the current tile's
+// MFMAs (one barrier per K-tile, double-buffered LDS).
+#include "common.h"
+
+namespace rf {
+
+struct GemmParams {
+    int M, N, K;
+    const void* src0;
+    const void* src1;
+    int C0, Ctot, ld0, ld1;
+    int Hin, Win, Hout, Wout, KH, KW, stride, pad_t, pad_l, ups;
+    const void* W;
+    const float* bias;
+    const float* rowvec;
+    int rows_per_sample, ldv;
+    const void* residual;
+    int ldr, act;
+    void* out;
+    int ldo;
+    float alpha;
+    long long sA, sW, sO, sR;
+    int tiles_m, tiles_n;
+};
+
+template <typename T> struct MmaFrag;
+template <> struct MmaFrag<bf16_t> {
+    __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+};
+template <> struct MmaFrag<float> {
+    __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as_f32( a[q]), as_f32( b[q]), acc, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+template <typename TO> __device__ __forceinline__ void store_out(TO* p, float v);
+template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+template <typename TO> __device__ __forceinline__ float load_out(const TO* p);
+template <> __device__ __forceinline__ float load_out<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float load_out<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+
+template <typename T, typename TO, int WM, int WN, int TM, int TN, bool CONV>
+__global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BM = 32 * TM * WM;
+    constexpr int BN = 32 * TN * WN;
+    constexpr int VEC = elem<T>::VEC;
+    constexpr int BK = 8 * VEC;          // elements of K per tile (128 bytes)
+    constexpr int RPP = NT / 8;          // rows covered per staging pass
+    constexpr int AV = BM / RPP;         // A vectors per thread
+    constexpr int BV = BN / RPP;         // B vectors per thread
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/threads mismatch");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsA = smem;                       // [2][BM][128]
+    char* const ldsB = smem + 2 * BM * 128;        // [2][BN][128]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware tile order: XCD x (= block id mod 8 as dispatched) owns a contiguous run of tiles,
+    // N-fastest inside the run, so the N-tiles that share an A panel hit the same L2.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const long long zb = blockIdx.y;
+    const T* src0 = (const T*)p.src0 + zb * p.sA;
+    const T* src1 = (const T*)p.src1;
+    const T* Wp = (const T*)p.W + zb * p.sW;
+
+    const int slot = tid & 7;
+    const int r0 = tid >> 3;
+
+    // ---- per-thread A row descriptors
+    int a_pix[AV];     // CONV: b*Hin*Win ; plain: row index (or -1 invalid)
+    int a_iy[AV], a_ix[AV];
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+        const int m = m0 + r0 + i * RPP;
+        if (CONV) {
+            const int hw = p.Hout * p.Wout;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            a_pix[i] = (m < p.M) ? b * p.Hin * p.Win : -1;
+            a_iy[i] = oy * p.stride - p.pad_t;
+            a_ix[i] = ox * p.stride - p.pad_l;
+        } else {
+            a_pix[i] = (m < p.M) ? m : -1;
+            a_iy[i] = a_ix[i] = 0;
+        }
+    }
+    // running K position of this thread's vector slot
+    int kvec = slot * VEC;       // element index along K
+    int cv = kvec, ky = 0, kx = 0;   // CONV: channel within tap, tap coords
+    if (CONV) {
+        while (cv >= p.Ctot) {
+            cv -= p.Ctot;
+            if (++kx == p.KW) { kx = 0; ++ky; }
+        }
+    }
+    const int Hv = p.ups ? p.Hin * 2 : p.Hin, Wv = p.ups ? p.Win * 2 : p.Win;
+
+    u32x4_t ra[AV], rb[BV];
+
+    auto load_tiles = [&]() {
+        const bool kval = kvec < p.K;
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (CONV) {
+                int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+                const bool ok = kval && a_pix[i] >= 0 && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+                if (ok) {
+                    if (p.ups) { iy >>= 1; ix >>= 1; }
+                    const long long pix = (long long)a_pix[i] + iy * p.Win + ix;
+                    const T* ptr = (cv < p.C0) ? src0 + pix * p.ld0 + cv : src1 + pix * p.ld1 + (cv - p.C0);
+                    v = *(const u32x4_t*)ptr;
+                }
+            } else {
+                if (kval && a_pix[i] >= 0) v = *(const u32x4_t*)(src0 + (long long)a_pix[i] * p.ld0 + kvec);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BV; ++j) {
+            const int n = n0 + r0 + j * RPP;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (kval && n < p.N) v = *(const u32x4_t*)(Wp + (long long)n * p.K + kvec);
+            rb[j] = v;
+        }
+        // advance to the next K tile
+        kvec += BK;
+        if (CONV) {
+            cv += BK;
+            while (cv >= p.Ctot) {
+                cv -= p.Ctot;
+                if (++kx == p.KW) { kx = 0; ++ky; }
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        char* a = ldsA + buf * BM * 128;
+        char* b = ldsB + buf * BN * 128;
+#pragma unroll
+        for (int i = 0; i < AV; ++i) *(u32x4_t*)(a + lds_off(r0 + i * RPP, slot)) = ra[i];
+#pragma unroll
+        for (int j = 0; j < BV; ++j) *(u32x4_t*)(b + lds_off(r0 + j * RPP, slot)) = rb[j];
+    };
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tiles();
+    store_tiles(0);
+    __syncthreads();
+
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles();
+        const char* a = ldsA + buf * BM * 128;
+        const char* b = ldsB + buf * BN * 128;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int s = kk * 2 + lhalf;
+            u32x4_t fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4_t*)(a + lds_off((wm * TM + i) * 32 + lrow, s));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *(const u32x4_t*)(b + lds_off((wn * TN + j) * 32 + lrow, s));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) MmaFrag<T>::mma(acc[i][j], fa[i], fb[j]);
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    TO* outp = (TO*)p.out + zb * p.sO;
+    const TO* resp = p.residual ? (const TO*)p.residual + zb * p.sR : nullptr;
+    const bool geglu = p.act == RF_ACT_GEGLU;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+            if (row >= p.M) continue;
+            const float* rv = p.rowvec ? p.rowvec + (long long)(row / p.rows_per_sample) * p.ldv : nullptr;
+            if (geglu) {
+                if constexpr (TN % 2 == 0) {
+#pragma unroll
+                    for (int j = 0; j < TN; j += 2) {
+                        const int cv_ = n0 + (wn * TN + j) * 32 + lrow;      // packed column of the value half
+                        const int cg_ = cv_ + 32;
+                        if (cg_ >= p.N) continue;
+                        float a_ = acc[i][j][r] * p.alpha, g_ = acc[i][j + 1][r] * p.alpha;
+                        if (p.bias) { a_ += p.bias[cv_]; g_ += p.bias[cg_]; }
+                        const int oc = ((n0 + (wn * TN + j) * 32) >> 1) + lrow;
+                        float v = a_ * gelu_erf(g_);
+                        if (resp) v += load_out<TO>(resp + (long long)row * p.ldr + oc);
+                        store_out<TO>(outp + (long long)row * p.ldo + oc, v);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = n0 + (wn * TN + j) * 32 + lrow;
+                    if (col >= p.N) continue;
+                    float v = acc[i][j][r] * p.alpha;
+                    if (p.bias) v += p.bias[col];
+                    if (rv) v += rv[col];
+                    if (p.act == RF_ACT_SILU) v = silu_exact(v);
+                    else if (p.act == RF_ACT_QUICK_GELU) v = quick_gelu(v);
+                    else if (p.act == RF_ACT_GELU) v = gelu_erf(v);
+                    if (resp) v += load_out<TO>(resp + (long long)row * p.ldr + col);
+                    store_out<TO>(outp + (long long)row * p.ldo + col, v);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, typename TO, int WM, int WN, int TM, int TN>
+static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipStream_t st) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int smem = 2 * (BM + BN) * 128;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    dim3 grid(p.tiles_m * p.tiles_n, d->batch, 1), block(WM * WN * 64);
+    if (conv) {
+        auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, true>;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+        hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    } else {
+        auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, false>;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+        hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    }
+    RF_LAUNCH_CHECK("rf_conv_gemm");
+    return 0;
+}
+
+template <typename T, typename TO>
+static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipStream_t st) {
+    const int N = p.N;
+    if (d->act == RF_ACT_GEGLU) return launch_cfg<T, TO, 2, 2, 2, 2>(d, p, conv, st);
+    if (N <= 64) return launch_cfg<T, TO, 4, 1, 1, 2>(d, p, conv, st);
+    const int pad128 = ((N + 127) / 128) * 128, pad160 = ((N + 159) / 160) * 160;
+    if (pad160 < pad128) return launch_cfg<T, TO, 4, 1, 1, 5>(d, p, conv, st);
+    return launch_cfg<T, TO, 2, 2, 2, 2>(d, p, conv, st);
+}
+
+}  // namespace rf
+
+extern "C" int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream) {
+    using namespace rf;
+    RF_CHECK(d != nullptr, "rf_conv_gemm: null descriptor");
+    RF_CHECK(d->dtype == RF_F32 || d->dtype == RF_BF16, "rf_conv_gemm: bad dtype %d", d->dtype);
+    RF_CHECK(d->out_dtype == RF_F32 || d->out_dtype == RF_BF16, "rf_conv_gemm: bad out_dtype %d", d->out_dtype);
+    const int vec = d->dtype == RF_F32 ? 4 : 8;
+    const int ctot = d->C0 + d->C1;
+    RF_CHECK(d->M > 0 && d->N > 0 && d->K > 0 && d->batch >= 1, "rf_conv_gemm: bad sizes M=%d N=%d K=%d batch=%d", d->M, d->N, d->K, d->batch);
+    RF_CHECK(d->src0 && d->W && d->out, "rf_conv_gemm: null operand");
+    RF_CHECK(d->K % vec == 0 && ctot % vec == 0 && d->C0 % vec == 0 && d->ld0 % vec == 0,
+             "rf_conv_gemm: K=%d C0=%d C1=%d ld0=%d must be multiples of %d", d->K, d->C0, d->C1, d->ld0, vec);
+    RF_CHECK(d->C1 == 0 || (d->src1 && d->ld1 % vec == 0), "rf_conv_gemm: bad second source");
+    RF_CHECK(d->KH >= 1 && d->KW >= 1 && d->stride >= 1, "rf_conv_gemm: bad window");
+    RF_CHECK(d->KH * d->KW * ctot <= d->K && d->K < d->KH * d->KW * ctot + 8 * vec,
+             "rf_conv_gemm: K=%d inconsistent with KH*KW*(C0+C1)=%d", d->K, d->KH * d->KW * ctot);
+    RF_CHECK(((uintptr_t)d->src0 | (uintptr_t)d->src1 | (uintptr_t)d->W) % 16 == 0, "rf_conv_gemm: operands must be 16-byte aligned");
+    RF_CHECK(d->act != RF_ACT_GEGLU || (d->N % 64 == 0 && !d->rowvec), "rf_conv_gemm: GEGLU needs N %% 64 == 0 and no rowvec");
+    RF_CHECK(!d->rowvec || d->rows_per_sample > 0, "rf_conv_gemm: rowvec needs rows_per_sample");
+    const bool conv = !(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->ups == 0 &&
+                        d->C1 == 0 && d->Hin == d->Hout && d->Win == d->Wout);
+    RF_CHECK(!conv || d->batch == 1, "rf_conv_gemm: batch > 1 only for plain GEMM");
+    RF_CHECK(!conv || (d->Hout > 0 && d->Wout > 0 && d->M % (d->Hout * d->Wout) == 0), "rf_conv_gemm: M not a multiple of Hout*Wout");
+    GemmParams p;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.src0 = d->src0; p.src1 = d->src1;
+    p.C0 = d->C0; p.Ctot = ctot; p.ld0 = d->ld0; p.ld1 = d->ld1;
+    p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout;
+    p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.ups = d->ups;
+    p.W = d->W; p.bias = d->bias; p.rowvec = d->rowvec; p.rows_per_sample = d->rows_per_sample; p.ldv = d->ldv;
+    p.residual = d->residual; p.ldr = d->ldr; p.act = d->act; p.out = d->out; p.ldo = d->ldo; p.alpha = d->alpha;
+    p.sA = d->sA; p.sW = d->sW; p.sO = d->sO; p.sR = d->sR;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == RF_F32) {
+        if (d->out_dtype == RF_F32) return launch_typed<float, float>(d, p, conv, st);
+        return launch_typed<float, bf16_t>(d, p, conv, st);
+    }
+    if (d->out_dtype == RF_F32) return launch_typed<bf16_t, float>(d, p, conv, st);
+    return launch_typed<bf16_t, bf16_t>(d, p, conv, st);
+}

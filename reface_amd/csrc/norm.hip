@@ -1,0 +1,354 @@
+// GroupNorm(32) (+SiLU), LayerNorm and row softmax for channels-last activations (HBM-bound
+// side kernels: 16-byte vector loads, wavefront reductions, fp64 cross-block sums).
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace rf {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+constexpr int GN_SLOTS = 4;     // channel vectors per thread (C <= 4 * 256 * VEC)
+constexpr int GN_THREADS = 256;
+
+template <typename T> struct gn_acc { typedef float type; };
+template <> struct gn_acc<float> { typedef double type; };   // fp32 (parity) path: fp64 partial sums throughout
+
+// thread t owns channel vectors {tv + q*TV}; pixel lanes stride over the chunk's pixels
+template <typename T>
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restrict__ x, int HW, int C, int ldx, int nchunks,
+                                                              double* __restrict__ partial) {
+    typedef typename gn_acc<T>::type acc_t;
+    constexpr int VEC = elem<T>::VEC;
+    const int nvec = C / VEC;
+    const int TV = nvec < GN_THREADS ? nvec : GN_THREADS;
+    const int PL = GN_THREADS / TV;                 // pixel lanes
+    const int tv = threadIdx.x % TV, pl = threadIdx.x / TV;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int ppc = (HW + nchunks - 1) / nchunks;
+    const int p0 = chunk * ppc, p1 = min(HW, p0 + ppc);
+    const int cpg = C / 32;
+
+    acc_t s[GN_SLOTS][VEC], ss[GN_SLOTS][VEC];
+#pragma unroll
+    for (int q = 0; q < GN_SLOTS; ++q)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[q][e] = ss[q][e] = 0;
+
+    if (pl < PL) {
+        for (int p = p0 + pl; p < p1; p += PL) {
+            const T* row = x + ((long long)b * HW + p) * ldx;
+#pragma unroll
+            for (int q = 0; q < GN_SLOTS; ++q) {
+                const int v = tv + q * TV;
+                if (v < nvec) {
+                    float f[VEC];
+                    unpack16<T>(*(const u32x4_t*)(row + v * VEC), f);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { s[q][e] += f[e]; ss[q][e] += (acc_t)f[e] * f[e]; }
+                }
+            }
+        }
+    }
+    // deterministic two-stage reduction through LDS (no atomics): per-(pixel lane, channel) sums,
+    // then per group over (pixel lanes x channels-per-group)
+    extern __shared__ __attribute__((aligned(16))) char gn_smem[];
+    double* chs = (double*)gn_smem;             // [PL][C]
+    double* chq = chs + (size_t)PL * C;         // [PL][C]
+    if (pl < PL) {
+#pragma unroll
+        for (int q = 0; q < GN_SLOTS; ++q) {
+            const int v = tv + q * TV;
+            if (v < nvec) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    chs[pl * C + v * VEC + e] = (double)s[q][e];
+                    chq[pl * C + v * VEC + e] = (double)ss[q][e];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    __shared__ double red[GN_THREADS][2];
+    {
+        const int g = threadIdx.x & 31, part = threadIdx.x >> 5;
+        double a = 0.0, qq = 0.0;
+        const int n = PL * cpg;
+        for (int e = part; e < n; e += GN_THREADS / 32) {
+            const int pp = e / cpg, cc = e - pp * cpg;
+            a += chs[pp * C + g * cpg + cc];
+            qq += chq[pp * C + g * cpg + cc];
+        }
+        red[threadIdx.x][0] = a;
+        red[threadIdx.x][1] = qq;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double sa = 0.0, sq = 0.0;
+        for (int k = 0; k < GN_THREADS / 32; ++k) { sa += red[threadIdx.x + 32 * k][0]; sq += red[threadIdx.x + 32 * k][1]; }
+        double* o = partial + (((long long)b * nchunks + chunk) * 32 + threadIdx.x) * 2;
+        o[0] = sa;
+        o[1] = sq;
+    }
+}
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restrict__ x, int HW, int C, int ldx, int nchunks,
+                                                              const double* __restrict__ partial, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, int do_silu,
+                                                              TO* __restrict__ out, int ldo, int achunks) {
+    constexpr int VEC = elem<T>::VEC;
+    const int nvec = C / VEC;
+    const int TV = nvec < GN_THREADS ? nvec : GN_THREADS;
+    const int PL = GN_THREADS / TV;
+    const int tv = threadIdx.x % TV, pl = threadIdx.x / TV;
+    const int b = blockIdx.y;
+    const int cpg = C / 32;
+
+    __shared__ float mean_s[32], rstd_s[32];
+    __shared__ double red[GN_THREADS][2];
+    {   // reduce the per-chunk partials of sample b: thread -> (group, part)
+        const int g = threadIdx.x & 31, part = threadIdx.x >> 5;
+        double a = 0.0, q = 0.0;
+        for (int c = part; c < nchunks; c += GN_THREADS / 32) {
+            const double* pp = partial + (((long long)b * nchunks + c) * 32 + g) * 2;
+            a += pp[0];
+            q += pp[1];
+        }
+        red[threadIdx.x][0] = a;
+        red[threadIdx.x][1] = q;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            double sa = 0.0, sq = 0.0;
+            for (int k = 0; k < GN_THREADS / 32; ++k) { sa += red[threadIdx.x + 32 * k][0]; sq += red[threadIdx.x + 32 * k][1]; }
+            const double n = (double)HW * cpg;
+            const double mean = sa / n;
+            double var = sq / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            mean_s[threadIdx.x] = (float)mean;
+            rstd_s[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+        __syncthreads();
+    }
+    float sc[GN_SLOTS][VEC], sh[GN_SLOTS][VEC];
+#pragma unroll
+    for (int q = 0; q < GN_SLOTS; ++q) {
+        const int v = tv + q * TV;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            sc[q][e] = sh[q][e] = 0.f;
+            if (v < nvec) {
+                const int c = v * VEC + e, g = c / cpg;
+                const float a = rstd_s[g] * gamma[c];
+                sc[q][e] = a;
+                sh[q][e] = beta[c] - mean_s[g] * a;
+            }
+        }
+    }
+    if (pl >= PL) return;
+    const int ppc = (HW + achunks - 1) / achunks;
+    const int p0 = blockIdx.x * ppc, p1 = min(HW, p0 + ppc);
+    for (int p = p0 + pl; p < p1; p += PL) {
+        const T* row = x + ((long long)b * HW + p) * ldx;
+        TO* orow = out + ((long long)b * HW + p) * ldo;
+#pragma unroll
+        for (int q = 0; q < GN_SLOTS; ++q) {
+            const int v = tv + q * TV;
+            if (v < nvec) {
+                float f[VEC];
+                unpack16<T>(*(const u32x4_t*)(row + v * VEC), f);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float y = f[e] * sc[q][e] + sh[q][e];
+                    f[e] = do_silu ? silu_exact(y) : y;
+                }
+                if constexpr (sizeof(TO) == sizeof(T)) {
+                    *(u32x4_t*)(orow + v * VEC) = pack16<TO>(f);
+                } else if constexpr (sizeof(TO) == 4) {      // bf16 in -> fp32 out: two vectors
+                    *(u32x4_t*)(orow + v * VEC) = pack16<float>(f);
+                    *(u32x4_t*)(orow + v * VEC + 4) = pack16<float>(f + 4);
+                } else {                                     // fp32 in -> bf16 out: half vector
+                    u32x2_t h;
+                    h[0] = pack_bf2(f[0], f[1]);
+                    h[1] = pack_bf2(f[2], f[3]);
+                    *(u32x2_t*)(orow + v * VEC) = h;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 6;
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int M, int C, int ldx, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, TO* __restrict__ out, int ldo) {
+    constexpr int VEC = elem<T>::VEC;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int nvec = C / VEC;
+    const T* xr = x + (long long)row * ldx;
+    float f[LN_MAXV][VEC];
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < LN_MAXV; ++q) {
+        const int v = lane + q * 64;
+        if (v < nvec) {
+            unpack16<T>(*(const u32x4_t*)(xr + v * VEC), f[q]);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) sum += f[q][e];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int q = 0; q < LN_MAXV; ++q) {
+        const int v = lane + q * 64;
+        if (v < nvec) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { const float d = f[q][e] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
+    TO* orow = out + (long long)row * ldo;
+#pragma unroll
+    for (int q = 0; q < LN_MAXV; ++q) {
+        const int v = lane + q * 64;
+        if (v < nvec) {
+            float y[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int c = v * VEC + e;
+                y[e] = (f[q][e] - mean) * rstd * gamma[c] + beta[c];
+            }
+            if constexpr (sizeof(TO) == sizeof(T)) {
+                *(u32x4_t*)(orow + v * VEC) = pack16<TO>(y);
+            } else if constexpr (sizeof(TO) == 4) {
+                *(u32x4_t*)(orow + v * VEC) = pack16<float>(y);
+                *(u32x4_t*)(orow + v * VEC + 4) = pack16<float>(y + 4);
+            } else {
+                u32x2_t h;
+                h[0] = pack_bf2(y[0], y[1]);
+                h[1] = pack_bf2(y[2], y[3]);
+                *(u32x2_t*)(orow + v * VEC) = h;
+            }
+        }
+    }
+}
+
+// one block per row; three sweeps (max, sum, write) -- rows are L2-resident between sweeps
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int cols, int ld) {
+    float* r = x + (long long)blockIdx.x * ld;
+    __shared__ float red[4];
+    float m = -INFINITY;
+    for (int c = threadIdx.x * 4; c < cols; c += 1024) {
+        const f32x4_t v = *(const f32x4_t*)(r + c);
+        m = fmaxf(fmaxf(fmaxf(m, v[0]), fmaxf(v[1], v[2])), v[3]);
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = threadIdx.x * 4; c < cols; c += 1024) {
+        const f32x4_t v = *(const f32x4_t*)(r + c);
+        s += expf(v[0] - m) + expf(v[1] - m) + expf(v[2] - m) + expf(v[3] - m);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    for (int c = threadIdx.x * 4; c < cols; c += 1024) {
+        f32x4_t v = *(const f32x4_t*)(r + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = expf(v[e] - m) * inv;
+        *(f32x4_t*)(r + c) = v;
+    }
+}
+
+}  // namespace rf
+
+using namespace rf;
+
+extern "C" const char* rf_last_error(void) { return rf::g_err; }
+extern "C" int rf_version(void) { return 100; }
+
+static int gn_check(const char* name, int dtype, int C, int ldx, int nchunks) {
+    const int vec = dtype == RF_F32 ? 4 : 8;
+    RF_CHECK(dtype == RF_F32 || dtype == RF_BF16, "%s: bad dtype %d", name, dtype);
+    RF_CHECK(C % 32 == 0 && C % vec == 0 && ldx % vec == 0, "%s: C=%d ld=%d must be multiples of 32 and %d", name, C, ldx, vec);
+    RF_CHECK(C / vec <= GN_SLOTS * GN_THREADS, "%s: C=%d too large", name, C);
+    RF_CHECK(nchunks >= 1, "%s: nchunks=%d", name, nchunks);
+    return 0;
+}
+
+extern "C" int rf_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, int ldx, int nchunks, double* partial, void* stream) {
+    if (gn_check("rf_groupnorm_stats", dtype, C, ldx, nchunks)) return 1;
+    RF_CHECK(x && partial && B > 0 && HW > 0, "rf_groupnorm_stats: bad arguments");
+    dim3 grid(nchunks, B);
+    const int vec = dtype == RF_F32 ? 4 : 8;
+    const int nvec = C / vec, TV = nvec < GN_THREADS ? nvec : GN_THREADS, PL = GN_THREADS / TV;
+    const size_t smem = (size_t)2 * PL * C * sizeof(double);
+    RF_CHECK(smem <= 64 * 1024, "rf_groupnorm_stats: C=%d needs %zu B of LDS", C, smem);
+    if (dtype == RF_F32) hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(GN_THREADS), smem, (hipStream_t)stream, (const float*)x, HW, C, ldx, nchunks, partial);
+    else hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(GN_THREADS), smem, (hipStream_t)stream, (const bf16_t*)x, HW, C, ldx, nchunks, partial);
+    RF_LAUNCH_CHECK("rf_groupnorm_stats");
+    return 0;
+}
+
+extern "C" int rf_groupnorm_apply(int dtype, const void* x, int B, int HW, int C, int ldx, int nchunks, const double* partial,
+                                  const float* gamma, const float* beta, float eps, int silu, int out_dtype, void* out, int ldo, void* stream) {
+    if (gn_check("rf_groupnorm_apply", dtype, C, ldx, nchunks)) return 1;
+    RF_CHECK(x && partial && gamma && beta && out && B > 0 && HW > 0, "rf_groupnorm_apply: bad arguments");
+    RF_CHECK(out_dtype == RF_F32 || out_dtype == RF_BF16, "rf_groupnorm_apply: bad out_dtype");
+    RF_CHECK(ldo % 8 == 0, "rf_groupnorm_apply: ldo=%d must be a multiple of 8", ldo);
+    // blocks of >= ~64 pixels, about 2 blocks per CU in total
+    int achunks = (512 + B - 1) / B;
+    const int maxc = (HW + 63) / 64;
+    if (achunks > maxc) achunks = maxc;
+    if (achunks < 1) achunks = 1;
+    dim3 grid(achunks, B);
+    hipStream_t st = (hipStream_t)stream;
+#define GN_APPLY(T, TO) hipLaunchKernelGGL((gn_apply_kernel<T, TO>), grid, dim3(GN_THREADS), 0, st, (const T*)x, HW, C, ldx, nchunks, partial, gamma, beta, eps, silu, (TO*)out, ldo, achunks)
+    if (dtype == RF_F32 && out_dtype == RF_F32) GN_APPLY(float, float);
+    else if (dtype == RF_F32) GN_APPLY(float, bf16_t);
+    else if (out_dtype == RF_F32) GN_APPLY(bf16_t, float);
+    else GN_APPLY(bf16_t, bf16_t);
+#undef GN_APPLY
+    RF_LAUNCH_CHECK("rf_groupnorm_apply");
+    return 0;
+}
+
+extern "C" int rf_layernorm(int dtype, const void* x, int M, int C, int ldx, const float* gamma, const float* beta, float eps,
+                            int out_dtype, void* out, int ldo, void* stream) {
+    const int vec = dtype == RF_F32 ? 4 : 8;
+    RF_CHECK(dtype == RF_F32 || dtype == RF_BF16, "rf_layernorm: bad dtype %d", dtype);
+    RF_CHECK(out_dtype == RF_F32 || out_dtype == RF_BF16, "rf_layernorm: bad out_dtype");
+    RF_CHECK(x && gamma && beta && out && M > 0, "rf_layernorm: bad arguments");
+    RF_CHECK(C % vec == 0 && ldx % vec == 0 && ldo % 8 == 0 && C / vec <= 64 * LN_MAXV, "rf_layernorm: C=%d ldx=%d ldo=%d unsupported", C, ldx, ldo);
+    dim3 grid((M + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+#define LN(T, TO) hipLaunchKernelGGL((layernorm_kernel<T, TO>), grid, dim3(256), 0, st, (const T*)x, M, C, ldx, gamma, beta, eps, (TO*)out, ldo)
+    if (dtype == RF_F32 && out_dtype == RF_F32) LN(float, float);
+    else if (dtype == RF_F32) LN(float, bf16_t);
+    else if (out_dtype == RF_F32) LN(bf16_t, float);
+    else LN(bf16_t, bf16_t);
+#undef LN
+    RF_LAUNCH_CHECK("rf_layernorm");
+    return 0;
+}
+
+extern "C" int rf_softmax_rows(float* x, int rows, int cols, int ld, void* stream) {
+    RF_CHECK(x && rows > 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0, "rf_softmax_rows: bad arguments rows=%d cols=%d ld=%d", rows, cols, ld);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, cols, ld);
+    RF_LAUNCH_CHECK("rf_softmax_rows");
+    return 0;
+}

@@ -1,0 +1,252 @@
+"""Thin Python launchers over the C-ABI (reface_amd/_lib.py).
+
+PyTorch is used for device memory and the current HIP stream only; every arithmetic op of the
+hot path is a HIP kernel from libreface_hip.so.  Activations are channels-last torch tensors
+([B, H, W, C] or [M, C]) in fp32 or bf16; biases / norm affine parameters stay fp32.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, RF_BF16, RF_F32, ConvGemmDesc)
+
+
+def code(dt):
+    if dt == torch.float32:
+        return RF_F32
+    if dt == torch.bfloat16:
+        return RF_BF16
+    raise TypeError(f"unsupported dtype {dt}")
+
+
+def vec(dt):
+    return 4 if dt == torch.float32 else 8
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _require_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.RefaceHipError("reface_amd ops need device tensors (no CPU fallback)")
+
+
+# ------------------------------------------------------------------------------------------------
+# weight packing (done once at load time)
+# ------------------------------------------------------------------------------------------------
+def pack_conv_weight(w, dtype, cin_pad=None):
+    """[Cout, Cin, KH, KW] -> [Cout, KH*KW*Cin_pad] with k = (ky*KW + kx)*Cin_pad + c."""
+    co, ci, kh, kw = w.shape
+    cp = ci if cin_pad is None else cin_pad
+    wp = torch.zeros((co, kh, kw, cp), dtype=torch.float32, device=w.device)
+    wp[..., :ci] = w.float().permute(0, 2, 3, 1)
+    return wp.reshape(co, kh * kw * cp).to(dtype).contiguous()
+
+
+def pack_concat_conv_weight(w, c0, dtype):
+    """conv over cat([a(c0 ch), b]) -- same layout as pack_conv_weight (channels already in cat order)."""
+    return pack_conv_weight(w, dtype)
+
+
+def pack_geglu(w, b, dtype):
+    """GEGLU projection [2F, C] (value rows 0..F-1, gate rows F..2F-1) -> rows interleaved in blocks
+    of 32 (value block, gate block) so one MFMA wave tile holds matching value/gate columns."""
+    f2, c = w.shape
+    f = f2 // 2
+    assert f % 32 == 0
+    wv, wg = w[:f].reshape(f // 32, 32, c), w[f:].reshape(f // 32, 32, c)
+    wp = torch.stack([wv, wg], dim=1).reshape(f2, c)
+    bv, bg = b[:f].reshape(f // 32, 32), b[f:].reshape(f // 32, 32)
+    bp = torch.stack([bv, bg], dim=1).reshape(f2)
+    return wp.to(dtype).contiguous(), bp.float().contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# descriptor-based launches.  `Launch` objects are built once per (layer, shape) and replayed.
+# ------------------------------------------------------------------------------------------------
+class Launch:
+    """A prepared kernel launch: ``fn(*args, stream)``.  Keeps the tensors it points at alive."""
+    __slots__ = ("fn", "args", "keep", "name")
+
+    def __init__(self, fn, args, keep, name):
+        self.fn, self.args, self.keep, self.name = fn, args, keep, name
+
+    def __call__(self, stream=None):
+        rc = self.fn(*self.args, stream if stream is not None else stream_ptr())
+        if rc != 0:
+            _lib.check(rc, self.name)
+
+
+def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, Win=1, Hout=1, Wout=1, KH=1, KW=1,
+              stride=1, pad_t=0, pad_l=0, ups=0, bias=None, rowvec=None, rows_per_sample=0, ldv=0, residual=None, ldr=0,
+              act=ACT_NONE, ldo=None, alpha=1.0, batch=1, sA=0, sW=0, sO=0, sR=0, name="rf_conv_gemm"):
+    """Prepare an rf_conv_gemm launch (see include/reface_hip.h)."""
+    lib = _lib.load()
+    _require_gpu(src0, W, out, src1, bias, rowvec, residual)
+    d = ConvGemmDesc()
+    d.dtype, d.out_dtype = code(src0.dtype), code(out.dtype)
+    assert W.dtype == src0.dtype and (src1 is None or src1.dtype == src0.dtype)
+    assert residual is None or residual.dtype == out.dtype
+    assert bias is None or bias.dtype == torch.float32
+    assert rowvec is None or rowvec.dtype == torch.float32
+    d.M, d.N, d.K = M, N, K
+    d.src0, d.src1 = _p(src0), _p(src1)
+    d.C0, d.C1, d.ld0, d.ld1 = C0, C1, ld0, ld1
+    d.Hin, d.Win, d.Hout, d.Wout = Hin, Win, Hout, Wout
+    d.KH, d.KW, d.stride, d.pad_t, d.pad_l, d.ups = KH, KW, stride, pad_t, pad_l, ups
+    d.W, d.bias, d.rowvec = _p(W), _p(bias), _p(rowvec)
+    d.rows_per_sample, d.ldv = rows_per_sample, ldv
+    d.residual, d.ldr, d.act = _p(residual), ldr, act
+    d.out, d.ldo, d.alpha = _p(out), (ldo if ldo is not None else (N // 2 if act == ACT_GEGLU else N)), alpha
+    d.batch, d.sA, d.sW, d.sO, d.sR = batch, sA, sW, sO, sR
+    return Launch(lib.rf_conv_gemm, (C.byref(d),), (d, src0, src1, W, out, bias, rowvec, residual), name)
+
+
+def linear(x, W, out, bias=None, *, act=ACT_NONE, residual=None, rowvec=None, rows_per_sample=0, alpha=1.0, name="linear"):
+    """out[M, N] = act(x[M, K] @ W[N, K]^T + bias) (+ residual).  x / out may be row-strided 2-D views."""
+    M, K = x.shape
+    N = W.shape[0]
+    assert W.shape[1] == K and x.stride(1) == 1 and out.stride(1) == 1
+    return conv_gemm(x, W, out, M=M, N=N, K=K, C0=K, ld0=x.stride(0), Hin=1, Win=M, Hout=1, Wout=M, bias=bias, act=act,
+                     residual=residual, ldr=(residual.stride(0) if residual is not None else 0), rowvec=rowvec,
+                     rows_per_sample=rows_per_sample, ldv=(rowvec.stride(0) if rowvec is not None else 0),
+                     ldo=out.stride(0), alpha=alpha, name=name)
+
+
+def conv2d(x, W, out, bias=None, *, ksize=3, stride=1, pad=(1, 1), ups=0, x2=None, residual=None, rowvec=None,
+           act=ACT_NONE, name="conv2d"):
+    """Channels-last convolution.  x: [B, Hin, Win, C0] (+ optional x2 [B, Hin, Win, C1] concatenated
+    on channels); W: packed [Cout, k*k*(C0+C1)]; out: [B, Hout, Wout, Cout]."""
+    B, Hin, Win, C0 = x.shape
+    C1 = 0 if x2 is None else x2.shape[3]
+    Bo, Hout, Wout, N = out.shape
+    assert Bo == B and x.stride(3) == 1 and out.stride(3) == 1
+    K = W.shape[1]
+    return conv_gemm(x, W, out, M=B * Hout * Wout, N=N, K=K, C0=C0, ld0=x.stride(2), src1=x2, C1=C1,
+                     ld1=(x2.stride(2) if x2 is not None else 0), Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, KH=ksize, KW=ksize,
+                     stride=stride, pad_t=pad[0], pad_l=pad[1], ups=ups, bias=bias, residual=residual,
+                     ldr=(residual.stride(2) if residual is not None else 0), rowvec=rowvec, rows_per_sample=Hout * Wout,
+                     ldv=(rowvec.stride(0) if rowvec is not None else 0), act=act, ldo=out.stride(2), name=name)
+
+
+GN_MAX_CHUNKS = 32
+
+
+def gn_chunks(B, HW):
+    n = max(1, min(GN_MAX_CHUNKS, HW // 32))
+    while B * n > 1024 and n > 1:
+        n //= 2
+    return n
+
+
+def groupnorm(x, gamma, beta, out, partial, *, eps, silu, name="groupnorm"):
+    """GroupNorm(32)(+SiLU) over channels-last x [B, H, W, C] -> out.  ``partial``: fp64 scratch
+    of at least B * GN_MAX_CHUNKS * 64 elements.  Returns the two launches (stats, apply)."""
+    lib = _lib.load()
+    _require_gpu(x, gamma, beta, out, partial)
+    B, H, W_, Cc = x.shape
+    HW = H * W_
+    n = gn_chunks(B, HW)
+    assert partial.dtype == torch.float64 and partial.numel() >= B * n * 64
+    a = Launch(lib.rf_groupnorm_stats, (code(x.dtype), _p(x), B, HW, Cc, x.stride(2), n, _p(partial)), (x, partial), name + ".stats")
+    b = Launch(lib.rf_groupnorm_apply, (code(x.dtype), _p(x), B, HW, Cc, x.stride(2), n, _p(partial), _p(gamma), _p(beta),
+                                        float(eps), int(bool(silu)), code(out.dtype), _p(out), out.stride(2)),
+               (x, partial, gamma, beta, out), name + ".apply")
+    return [a, b]
+
+
+def layernorm(x, gamma, beta, out, *, eps=1e-5, name="layernorm"):
+    lib = _lib.load()
+    _require_gpu(x, gamma, beta, out)
+    M, Cc = x.shape
+    return Launch(lib.rf_layernorm, (code(x.dtype), _p(x), M, Cc, x.stride(0), _p(gamma), _p(beta), float(eps), code(out.dtype),
+                                     _p(out), out.stride(0)), (x, gamma, beta, out), name)
+
+
+def attention(q, k, v, out, *, heads, scale, name="attention"):
+    """q/k/v/out: [B, N, heads*d] views (last dim contiguous; may be slices of a fused qkv buffer)."""
+    lib = _lib.load()
+    _require_gpu(q, k, v, out)
+    B, Nq, Cc = q.shape
+    Nk = k.shape[1]
+    d = Cc // heads
+    assert q.dtype == k.dtype == v.dtype == out.dtype
+    return Launch(lib.rf_attention, (code(q.dtype), _p(q), _p(k), _p(v), _p(out), B, heads, d, Nq, Nk, q.stride(1), k.stride(1),
+                                     v.stride(1), out.stride(1), q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale)),
+                  (q, k, v, out), name)
+
+
+def softmax_rows(x, name="softmax_rows"):
+    lib = _lib.load()
+    _require_gpu(x)
+    rows, cols = x.shape
+    return Launch(lib.rf_softmax_rows, (_p(x), rows, cols, x.stride(0)), (x,), name)
+
+
+def ddim_pack_input(img, z_inpaint, mask, x_in, *, dup, name="ddim_pack"):
+    lib = _lib.load()
+    _require_gpu(img, z_inpaint, mask, x_in)
+    B, _, h, w = img.shape
+    return Launch(lib.rf_ddim_pack_input, (_p(img), _p(z_inpaint), _p(mask), B, h * w, dup, code(x_in.dtype), _p(x_in), x_in.shape[-1]),
+                  (img, z_inpaint, mask, x_in), name)
+
+
+def ddim_update(eps, img, pred_x0, noise, *, cfg, scale, sqrt_at, sqrt_1m_at, sqrt_aprev, dir_coef, sigma, name="ddim_update"):
+    lib = _lib.load()
+    _require_gpu(eps, img, pred_x0, noise)
+    B, _, h, w = img.shape
+    assert eps.dtype == torch.float32
+    return Launch(lib.rf_ddim_update, (_p(eps), eps.shape[-1], int(cfg), float(scale), _p(img), _p(pred_x0), _p(noise), B, h * w,
+                                       float(sqrt_at), float(sqrt_1m_at), float(sqrt_aprev), float(dir_coef), float(sigma)),
+                  (eps, img, pred_x0, noise), name)
+
+
+def nchw_to_nhwc(x, out, name="nchw_to_nhwc"):
+    lib = _lib.load()
+    _require_gpu(x, out)
+    B, Cc, H, W_ = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
+    return Launch(lib.rf_nchw_to_nhwc, (_p(x), B, Cc, H * W_, code(out.dtype), _p(out), out.shape[-1]), (x, out), name)
+
+
+def nhwc_to_nchw(x, out, C_=None, name="nhwc_to_nchw"):
+    lib = _lib.load()
+    _require_gpu(x, out)
+    B, H, W_, ld = x.shape[0], x.shape[1], x.shape[2], x.stride(2)
+    Cc = out.shape[1] if C_ is None else C_
+    assert out.dtype == torch.float32 and out.is_contiguous()
+    return Launch(lib.rf_nhwc_to_nchw, (code(x.dtype), _p(x), B, Cc, H * W_, ld, _p(out)), (x, out), name)
+
+
+def cast(x, out, name="cast"):
+    lib = _lib.load()
+    _require_gpu(x, out)
+    assert x.is_contiguous() and out.is_contiguous() and x.numel() == out.numel()
+    return Launch(lib.rf_cast, (code(x.dtype), _p(x), code(out.dtype), _p(out), x.numel()), (x, out), name)
+
+
+def timestep_embedding(t, freqs, out, name="timestep_embedding"):
+    lib = _lib.load()
+    _require_gpu(t, freqs, out)
+    n, dim = out.shape
+    assert t.dtype == torch.float32 and freqs.dtype == torch.float32 and out.dtype == torch.float32
+    return Launch(lib.rf_timestep_embedding, (_p(t), n, dim, _p(freqs), _p(out)), (t, freqs, out), name)
+
+
+def silu_f32(x, out, name="silu"):
+    lib = _lib.load()
+    _require_gpu(x, out)
+    return Launch(lib.rf_silu_f32, (_p(x), _p(out), x.numel()), (x, out), name)
+
+
+def run(launches, stream=None):
+    s = stream if stream is not None else stream_ptr()
+    for l in launches:
+        l(s)

@@ -1,0 +1,266 @@
+"""GPU parity tests of the individual HIP kernels (through the C-ABI) against plain PyTorch fp32
+CPU references of the same op.  fp32 kernels: round-off-class tolerances; bf16 kernels: compared
+against the fp32 reference evaluated on the bf16-rounded inputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from reface_amd import ops
+from reface_amd.params import seeded_randn as rnd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def tol(dt):
+    return (2e-5, 2e-5) if dt == torch.float32 else (3e-2, 2e-2)
+
+
+def check(got, ref, dt, scale=1.0):
+    got = got.float().cpu()
+    atol, rtol = tol(dt)
+    err = (got - ref).abs()
+    lim = atol * scale + rtol * ref.abs()
+    assert torch.isfinite(got).all()
+    assert (err <= lim).all(), f"max err {err.max():.3e} at ref absmax {ref.abs().max():.3e} (dtype {dt})"
+
+
+def q(x, dt):
+    """round to the storage dtype, return (device tensor in dt, fp32 cpu copy of the rounded values)"""
+    xd = x.to(dt)
+    return xd.to(DEV), xd.float()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 320, 320), (77, 200, 136), (16, 1280, 320), (257, 96, 1024), (1, 768, 512)])
+def test_linear(dt, M, N, K):
+    x, xr = q(rnd((M, K), 1), dt)
+    w, wr = q(rnd((N, K), 2) / math.sqrt(K), dt)
+    b = rnd((N,), 3)
+    res, rr = q(rnd((M, N), 4), dt)
+    out = torch.empty((M, N), dtype=dt, device=DEV)
+    ops.linear(x, w, out, b.to(DEV), residual=res)()
+    torch.cuda.synchronize()
+    check(out, F.linear(xr, wr, b) + rr, dt)
+    # asymmetric identity check (transposition detector): W = I-like with distinct rows
+    out2 = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    ops.linear(x, w, out2, None, act=ops.ACT_SILU)()
+    torch.cuda.synchronize()
+    check(out2, F.silu(F.linear(xr, wr)), dt)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_linear_strided_views_and_rowvec(dt):
+    M, K, N, B = 96, 64, 160, 3
+    buf, bufr = q(rnd((M, 3 * K), 5), dt)
+    w, wr = q(rnd((N, K), 6) / 8, dt)
+    rv = rnd((B, N), 7)
+    outbuf = torch.zeros((M, 2 * N), dtype=dt, device=DEV)
+    ops.linear(buf[:, K:2 * K], w, outbuf[:, N:], None, rowvec=rv.to(DEV), rows_per_sample=M // B)()
+    torch.cuda.synchronize()
+    ref = F.linear(bufr[:, K:2 * K], wr) + rv.repeat_interleave(M // B, 0)
+    check(outbuf[:, N:], ref, dt)
+    assert (outbuf[:, :N] == 0).all()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_geglu(dt):
+    M, Cc, Fh = 200, 64, 128
+    x, xr = q(rnd((M, Cc), 8), dt)
+    w = rnd((2 * Fh, Cc), 9) / 8
+    b = rnd((2 * Fh,), 10)
+    wp, bp = ops.pack_geglu(w, b, dt)
+    out = torch.empty((M, Fh), dtype=dt, device=DEV)
+    ops.linear(x, wp.to(DEV), out, bp.to(DEV), act=ops.ACT_GEGLU)()
+    torch.cuda.synchronize()
+    h = F.linear(xr, w.to(dt).float(), b)
+    a, g = h.chunk(2, -1)
+    check(out, a * F.gelu(g), dt)
+
+
+def _conv_ref(xr, wr, b, stride, pad4, ups):
+    x = xr.permute(0, 3, 1, 2)
+    if ups:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    x = F.pad(x, pad4)
+    return F.conv2d(x, wr, b, stride=stride).permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", ["s1", "s2", "asym", "ups", "cat", "cin16", "k1"])
+def test_conv(dt, case):
+    B, H, W_, Ci, Co = 2, 12, 10, 64, 96
+    stride, pad4, ups, ks, x2 = 1, (1, 1, 1, 1), 0, 3, None
+    if case == "s2":
+        stride = 2
+    elif case == "asym":
+        stride, pad4 = 2, (0, 1, 0, 1)
+    elif case == "ups":
+        ups = 1
+    elif case == "cin16":
+        Ci = 16
+    elif case == "k1":
+        ks, pad4 = 1, (0, 0, 0, 0)
+    x, xr = q(rnd((B, H, W_, Ci), 11), dt)
+    Ct = Ci
+    if case == "cat":
+        x2, x2r = q(rnd((B, H, W_, 32), 12), dt)
+        Ct = Ci + 32
+        xr = torch.cat([xr, x2r], -1)
+    w = rnd((Co, Ct, ks, ks), 13) / math.sqrt(Ct * ks * ks)
+    b = rnd((Co,), 14)
+    wr = w.to(dt).float()
+    ref = _conv_ref(xr, wr, b, stride, pad4, ups)
+    out = torch.empty(ref.shape, dtype=dt, device=DEV)
+    ops.conv2d(x, ops.pack_conv_weight(w, dt).to(DEV), out, b.to(DEV), ksize=ks, stride=stride, pad=(pad4[2], pad4[0]), ups=ups, x2=x2)()
+    torch.cuda.synchronize()
+    check(out, ref, dt)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_conv_padded_cin_and_epilogue(dt):
+    """9 real input channels stored in 16 (UNet conv_in), temb row-vector + residual epilogue."""
+    B, H, W_, Co = 2, 8, 8, 320
+    x9 = rnd((B, H, W_, 9), 15)
+    x = torch.zeros((B, H, W_, 16))
+    x[..., :9] = x9
+    x, xr = q(x, dt)
+    w = rnd((Co, 9, 3, 3), 16) / 9
+    b = rnd((Co,), 17)
+    rv = rnd((B, Co), 18)
+    res, rr = q(rnd((B, H, W_, Co), 19), dt)
+    out = torch.empty((B, H, W_, Co), dtype=dt, device=DEV)
+    ops.conv2d(x, ops.pack_conv_weight(w, dt, cin_pad=16).to(DEV), out, b.to(DEV), rowvec=rv.to(DEV), residual=res)()
+    torch.cuda.synchronize()
+    ref = _conv_ref(xr[..., :9], w.to(dt).float(), b, 1, (1, 1, 1, 1), 0) + rv[:, None, None, :] + rr
+    check(out, ref, dt)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_batched_gemm(dt):
+    Bt, M, N, K = 3, 100, 72, 64
+    a, ar = q(rnd((Bt, M, K), 20), dt)
+    w, wr = q(rnd((Bt, N, K), 21) / 8, dt)
+    out = torch.empty((Bt, M, N), dtype=torch.float32, device=DEV)
+    ops.conv_gemm(a, w, out, M=M, N=N, K=K, C0=K, ld0=K, Hin=1, Win=M, Hout=1, Wout=M, ldo=N, alpha=0.5, batch=Bt,
+                  sA=M * K, sW=N * K, sO=M * N)()
+    torch.cuda.synchronize()
+    check(out, 0.5 * torch.einsum("bmk,bnk->bmn", ar, wr), dt)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Cc,hw,silu,eps", [(320, 16, True, 1e-5), (640, 9, False, 1e-6), (1280, 8, True, 1e-5), (2560, 8, True, 1e-5), (128, 32, True, 1e-6)])
+def test_groupnorm(dt, Cc, hw, silu, eps):
+    B = 3
+    x, xr = q(rnd((B, hw, hw, Cc), 22) * 2 + 0.7, dt)
+    g = rnd((Cc,), 23) * 0.2 + 1
+    be = rnd((Cc,), 24) * 0.2
+    out = torch.empty((B, hw, hw, Cc), dtype=dt, device=DEV)
+    part = torch.empty(B * ops.GN_MAX_CHUNKS * 64, dtype=torch.float64, device=DEV)
+    ops.run(ops.groupnorm(x, g.to(DEV), be.to(DEV), out, part, eps=eps, silu=silu))
+    torch.cuda.synchronize()
+    ref = F.group_norm(xr.permute(0, 3, 1, 2), 32, g, be, eps)
+    if silu:
+        ref = F.silu(ref)
+    check(out, ref.permute(0, 2, 3, 1), dt)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Cc", [320, 768, 1024, 1280])
+def test_layernorm(dt, Cc):
+    M = 131
+    x, xr = q(rnd((M, Cc), 25) * 1.5 - 0.3, dt)
+    g = rnd((Cc,), 26) * 0.2 + 1
+    be = rnd((Cc,), 27) * 0.2
+    out = torch.empty((M, Cc), dtype=dt, device=DEV)
+    ops.layernorm(x, g.to(DEV), be.to(DEV), out, eps=1e-5)()
+    torch.cuda.synchronize()
+    check(out, F.layer_norm(xr, (Cc,), g, be, 1e-5), dt)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("heads,d,N", [(8, 40, 256), (8, 80, 144), (8, 160, 64), (2, 160, 200), (16, 64, 257), (4, 8, 36), (8, 40, 1024)])
+def test_attention(dt, heads, d, N):
+    B = 2
+    Cc = heads * d
+    qkv, qkvr = q(rnd((B, N, 3 * Cc), 28), dt)
+    out = torch.empty((B, N, Cc), dtype=dt, device=DEV)
+    scale = d ** -0.5
+    ops.attention(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], out, heads=heads, scale=scale)()
+    torch.cuda.synchronize()
+    sp = lambda t: t.reshape(B, N, heads, d).transpose(1, 2)
+    qq, kk, vv = sp(qkvr[..., :Cc]), sp(qkvr[..., Cc:2 * Cc]), sp(qkvr[..., 2 * Cc:])
+    att = torch.softmax(qq @ kk.transpose(-1, -2) * scale, -1)
+    ref = (att @ vv).transpose(1, 2).reshape(B, N, Cc)
+    check(out, ref, dt)
+
+
+def test_attention_spike_forces_rescale():
+    """Online-softmax rescale branch: one key dominates from a late tile (guide rule 26)."""
+    B, heads, d, N = 1, 1, 40, 320
+    qkv = rnd((B, N, 3 * d), 29)
+    qkv[0, 5, :d] *= 6.0
+    qkv[0, 300, d:2 * d] = qkv[0, 5, :d] * 2.0          # key 300 aligned with query 5
+    x = qkv.to(DEV)
+    out = torch.empty((B, N, d), dtype=torch.float32, device=DEV)
+    ops.attention(x[..., :d], x[..., d:2 * d], x[..., 2 * d:], out, heads=1, scale=d ** -0.5)()
+    torch.cuda.synchronize()
+    att = torch.softmax((qkv[..., :d] @ qkv[..., d:2 * d].transpose(-1, -2)).double() * d ** -0.5, -1)
+    ref = (att @ qkv[..., 2 * d:].double()).float()
+    check(out, ref, torch.float32)
+
+
+def test_softmax_rows():
+    x = rnd((37, 4096), 30) * 3
+    xd = x.to(DEV)
+    ops.softmax_rows(xd)()
+    torch.cuda.synchronize()
+    check(xd, torch.softmax(x, -1), torch.float32, scale=0.01)
+
+
+def test_ddim_glue():
+    B, h = 2, 8
+    img, z, m = rnd((B, 4, h, h), 31), rnd((B, 4, h, h), 32), (rnd((B, 1, h, h), 33) > 0).float()
+    for dt in (torch.float32, torch.bfloat16):
+        x_in = torch.empty((2 * B, h, h, 16), dtype=dt, device=DEV)
+        ops.ddim_pack_input(img.to(DEV), z.to(DEV), m.to(DEV), x_in, dup=2)()
+        torch.cuda.synchronize()
+        ref = torch.cat([img, z, m], 1).permute(0, 2, 3, 1)
+        got = x_in.float().cpu()
+        assert torch.equal(got[:B, ..., :9], ref.to(dt).float()) and torch.equal(got[B:, ..., :9], ref.to(dt).float())
+        assert (got[..., 9:] == 0).all()
+    eps = rnd((2 * B, h, h, 64), 34)
+    a_t, a_prev, sig = 0.5, 0.6, 0.1
+    noise = rnd((B, 4, h, h), 35)
+    imgd = img.to(DEV).clone()
+    px0 = torch.empty_like(imgd)
+    ops.ddim_update(eps.to(DEV), imgd, px0, noise.to(DEV), cfg=True, scale=3.5, sqrt_at=math.sqrt(a_t),
+                    sqrt_1m_at=math.sqrt(1 - a_t), sqrt_aprev=math.sqrt(a_prev), dir_coef=math.sqrt(1 - a_prev - sig ** 2), sigma=sig)()
+    torch.cuda.synchronize()
+    e = eps[..., :4].permute(0, 3, 1, 2)
+    e = e[:B] + 3.5 * (e[B:] - e[:B])
+    r0 = (img - math.sqrt(1 - a_t) * e) / math.sqrt(a_t)
+    rp = math.sqrt(a_prev) * r0 + math.sqrt(1 - a_prev - sig ** 2) * e + sig * noise
+    check(px0, r0, torch.float32)
+    check(imgd, rp, torch.float32)
+
+
+def test_layout_and_embedding():
+    x = rnd((2, 5, 6, 7), 36)
+    out = torch.empty((2, 6, 7, 8), dtype=torch.float32, device=DEV)
+    ops.nchw_to_nhwc(x.to(DEV), out)()
+    back = torch.empty((2, 5, 6, 7), dtype=torch.float32, device=DEV)
+    ops.nhwc_to_nchw(out, back)()
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu()[..., :5], x.permute(0, 2, 3, 1)) and (out.cpu()[..., 5:] == 0).all()
+    assert torch.equal(back.cpu(), x)
+    t = torch.tensor([981.0, 1.0, 500.0, 21.0])
+    half = 160
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(0, half, dtype=torch.float32) / half)
+    emb = torch.empty((4, 320), dtype=torch.float32, device=DEV)
+    ops.timestep_embedding(t.to(DEV), freqs.to(DEV), emb)()
+    torch.cuda.synchronize()
+    args = t[:, None] * freqs[None]
+    check(emb, torch.cat([torch.cos(args), torch.sin(args)], -1), torch.float32, scale=0.1)
