@@ -61,7 +61,8 @@ typedef struct rf_conv_gemm_desc {
     int32_t Hin, Win;     /* spatial size of the stored source (before `ups`) */
     int32_t Hout, Wout;   /* spatial size of the output; M = B*Hout*Wout */
     int32_t KH, KW, stride, pad_t, pad_l, ups;
-    const void* W;        /* [N][K] row-major */
+    const void* W;        /* [N][K] row-major with row pitch ldw */
+    int32_t ldw;          /* row pitch of W in elements (0 = K) */
     const float* bias;    /* [N] fp32 or NULL */
     const float* rowvec;  /* [M / rows_per_sample][ldv] fp32 or NULL */
     int32_t rows_per_sample, ldv;
@@ -113,12 +114,14 @@ int rf_softmax_rows(float* x, int rows, int cols, int ld, void* stream);
  *   rf_ddim_update     : e = e_u + s (e_c - e_u); pred_x0 = (x - sqrt(1-a_t) e) / sqrt(a_t);
  *                        x_prev = sqrt(a_prev) pred_x0 + sqrt(1 - a_prev - sigma^2) e + sigma * noise.
  *   All latent tensors are fp32 NCHW [B, 4, h, w] (the sampler's external layout); eps is the UNet
- *   output in channels-last fp32 [2B or B, h*w, ld_eps].
+ *   output in channels-last fp32 [2B or B, h*w, ld_eps].  `coefs` is a DEVICE array of 5 fp32 step
+ *   coefficients {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev-sigma^2), sigma}, so one captured
+ *   hipGraph of a step can be replayed for every timestep.
  */
 int rf_ddim_pack_input(const float* img, const float* z_inpaint, const float* mask, int B, int hw, int dup,
                        int out_dtype, void* x_in, int Cpad, void* stream);
 int rf_ddim_update(const float* eps, int ld_eps, int cfg, float scale, float* img, float* pred_x0, const float* noise,
-                   int B, int hw, float sqrt_at, float sqrt_1m_at, float sqrt_aprev, float dir_coef, float sigma, void* stream);
+                   int B, int hw, const float* coefs, void* stream);
 
 /* Layout / dtype helpers. */
 int rf_nchw_to_nhwc(const float* x, int B, int C, int HW, int out_dtype, void* out, int Cpad, void* stream);
@@ -126,6 +129,9 @@ int rf_nhwc_to_nchw(int dtype, const void* x, int B, int C, int HW, int ldx, flo
 int rf_cast(int in_dtype, const void* x, int out_dtype, void* out, int64_t n, void* stream);
 /* sinusoidal timestep embedding [n, dim] = [cos(t f) | sin(t f)] (util.py:151-166); freqs [dim/2] fp32 */
 int rf_timestep_embedding(const float* t, int n, int dim, const float* freqs, float* out, void* stream);
+/* KL-VAE posterior sample (distributions.py:24-37, ddpm.py:857): moments NCHW [B, 2C, HW] = (mean | logvar),
+ * eps NCHW [B, C, HW] or NULL (mode):  out = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * eps) */
+int rf_gaussian_sample(const float* moments, const float* eps, float scale, float* out, int B, int C, int HW, void* stream);
 /* elementwise y = silu(x) on fp32 (emb path, openaimodel.py:219) */
 int rf_silu_f32(const float* x, float* y, int64_t n, void* stream);
 

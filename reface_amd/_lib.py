@@ -23,7 +23,7 @@ class ConvGemmDesc(C.Structure):
         ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32),
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
         ("ups", C.c_int32),
-        ("W", C.c_void_p), ("bias", C.c_void_p), ("rowvec", C.c_void_p),
+        ("W", C.c_void_p), ("ldw", C.c_int32), ("bias", C.c_void_p), ("rowvec", C.c_void_p),
         ("rows_per_sample", C.c_int32), ("ldv", C.c_int32),
         ("residual", C.c_void_p), ("ldr", C.c_int32), ("act", C.c_int32),
         ("out", C.c_void_p), ("ldo", C.c_int32), ("alpha", C.c_float),
@@ -46,12 +46,13 @@ _SIGS = {
     "rf_softmax_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "rf_ddim_pack_input": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "rf_ddim_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+                                 C.c_void_p, C.c_void_p]),
     "rf_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "rf_nhwc_to_nchw": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "rf_cast": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "rf_timestep_embedding": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rf_silu_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "rf_gaussian_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -28,9 +28,11 @@ __global__ void ddim_pack_kernel(const float* __restrict__ img, const float* __r
 }
 
 // ddim.py:346, 364-374 on NCHW fp32 latents; eps is channels-last [(2B|B), hw, ld]
+// coefs (device, fp32): {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev-sigma^2), sigma}
 __global__ void ddim_update_kernel(const float* __restrict__ eps, int ld, int cfg, float scale, float* __restrict__ img,
                                    float* __restrict__ pred_x0, const float* __restrict__ noise, int B, int hw,
-                                   float sqrt_at, float sqrt_1m_at, float sqrt_aprev, float dir_coef, float sigma) {
+                                   const float* __restrict__ coefs) {
+    const float sqrt_at = coefs[0], sqrt_1m_at = coefs[1], sqrt_aprev = coefs[2], dir_coef = coefs[3], sigma = coefs[4];
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*4*hw
     if (i >= (long long)B * 4 * hw) return;
     const int p = (int)(i % hw);
@@ -95,6 +97,21 @@ __global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, 
     if (i < n) y[i] = silu_exact(x[i]);
 }
 
+// distributions.py:24-37 + ddpm.py:857: out = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * eps), NCHW
+__global__ void gaussian_sample_kernel(const float* __restrict__ moments, const float* __restrict__ eps, float scale,
+                                       float* __restrict__ out, int B, int Cc, int HW) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*C*HW
+    if (i >= (long long)B * Cc * HW) return;
+    const int p = (int)(i % HW);
+    const int c = (int)((i / HW) % Cc);
+    const int b = (int)(i / ((long long)Cc * HW));
+    const float mean = moments[((long long)b * 2 * Cc + c) * HW + p];
+    float lv = moments[((long long)b * 2 * Cc + Cc + c) * HW + p];
+    lv = fminf(fmaxf(lv, -30.0f), 20.0f);
+    const float x = mean + expf(0.5f * lv) * (eps ? eps[i] : 0.0f);
+    out[i] = scale * x;
+}
+
 static inline dim3 grid1d(long long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
 }  // namespace rf
@@ -113,10 +130,10 @@ extern "C" int rf_ddim_pack_input(const float* img, const float* z_inpaint, cons
 }
 
 extern "C" int rf_ddim_update(const float* eps, int ld_eps, int cfg, float scale, float* img, float* pred_x0, const float* noise,
-                              int B, int hw, float sqrt_at, float sqrt_1m_at, float sqrt_aprev, float dir_coef, float sigma, void* stream) {
-    RF_CHECK(eps && img && B > 0 && hw > 0 && ld_eps >= 4, "rf_ddim_update: bad arguments");
+                              int B, int hw, const float* coefs, void* stream) {
+    RF_CHECK(eps && img && coefs && B > 0 && hw > 0 && ld_eps >= 4, "rf_ddim_update: bad arguments");
     hipLaunchKernelGGL(ddim_update_kernel, grid1d((long long)B * 4 * hw), dim3(256), 0, (hipStream_t)stream, eps, ld_eps, cfg, scale, img,
-                       pred_x0, noise, B, hw, sqrt_at, sqrt_1m_at, sqrt_aprev, dir_coef, sigma);
+                       pred_x0, noise, B, hw, coefs);
     RF_LAUNCH_CHECK("rf_ddim_update");
     return 0;
 }
@@ -164,5 +181,12 @@ extern "C" int rf_silu_f32(const float* x, float* y, int64_t n, void* stream) {
     RF_CHECK(x && y && n > 0, "rf_silu_f32: bad arguments");
     hipLaunchKernelGGL(silu_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, x, y, (long long)n);
     RF_LAUNCH_CHECK("rf_silu_f32");
+    return 0;
+}
+
+extern "C" int rf_gaussian_sample(const float* moments, const float* eps, float scale, float* out, int B, int C, int HW, void* stream) {
+    RF_CHECK(moments && out && B > 0 && C > 0 && HW > 0, "rf_gaussian_sample: bad arguments");
+    hipLaunchKernelGGL(gaussian_sample_kernel, grid1d((long long)B * C * HW), dim3(256), 0, (hipStream_t)stream, moments, eps, scale, out, B, C, HW);
+    RF_LAUNCH_CHECK("rf_gaussian_sample");
     return 0;
 }

@@ -22,6 +22,7 @@ struct GemmParams {
     int C0, Ctot, ld0, ld1;
     int Hin, Win, Hout, Wout, KH, KW, stride, pad_t, pad_l, ups;
     const void* W;
+    int ldw;
     const float* bias;
     const float* rowvec;
     int rows_per_sample, ldv;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         for (int j = 0; j < BV; ++j) {
             const int n = n0 + r0 + j * RPP;
             u32x4_t v = {0u, 0u, 0u, 0u};
-            if (kval && n < p.N) v = *(const u32x4_t*)(Wp + (long long)n * p.K + kvec);
+            if (kval && n < p.N) v = *(const u32x4_t*)(Wp + (long long)n * p.ldw + kvec);
             rb[j] = v;
         }
         // advance to the next K tile
@@ -300,6 +301,7 @@ extern "C" int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream) {
     RF_CHECK(d->K % vec == 0 && ctot % vec == 0 && d->C0 % vec == 0 && d->ld0 % vec == 0,
              "rf_conv_gemm: K=%d C0=%d C1=%d ld0=%d must be multiples of %d", d->K, d->C0, d->C1, d->ld0, vec);
     RF_CHECK(d->C1 == 0 || (d->src1 && d->ld1 % vec == 0), "rf_conv_gemm: bad second source");
+    RF_CHECK(d->ldw == 0 || (d->ldw >= d->K && d->ldw % vec == 0), "rf_conv_gemm: bad ldw=%d", d->ldw);
     RF_CHECK(d->KH >= 1 && d->KW >= 1 && d->stride >= 1, "rf_conv_gemm: bad window");
     RF_CHECK(d->KH * d->KW * ctot <= d->K && d->K < d->KH * d->KW * ctot + 8 * vec,
              "rf_conv_gemm: K=%d inconsistent with KH*KW*(C0+C1)=%d", d->K, d->KH * d->KW * ctot);
@@ -316,7 +318,7 @@ extern "C" int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream) {
     p.C0 = d->C0; p.Ctot = ctot; p.ld0 = d->ld0; p.ld1 = d->ld1;
     p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout;
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.ups = d->ups;
-    p.W = d->W; p.bias = d->bias; p.rowvec = d->rowvec; p.rows_per_sample = d->rows_per_sample; p.ldv = d->ldv;
+    p.W = d->W; p.ldw = d->ldw > 0 ? d->ldw : d->K; p.bias = d->bias; p.rowvec = d->rowvec; p.rows_per_sample = d->rows_per_sample; p.ldv = d->ldv;
     p.residual = d->residual; p.ldr = d->ldr; p.act = d->act; p.out = d->out; p.ldo = d->ldo; p.alpha = d->alpha;
     p.sA = d->sA; p.sW = d->sW; p.sO = d->sO; p.sR = d->sR;
     hipStream_t st = (hipStream_t)stream;

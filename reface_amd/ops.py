@@ -86,7 +86,7 @@ class Launch:
 
 def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, Win=1, Hout=1, Wout=1, KH=1, KW=1,
               stride=1, pad_t=0, pad_l=0, ups=0, bias=None, rowvec=None, rows_per_sample=0, ldv=0, residual=None, ldr=0,
-              act=ACT_NONE, ldo=None, alpha=1.0, batch=1, sA=0, sW=0, sO=0, sR=0, name="rf_conv_gemm"):
+              act=ACT_NONE, ldo=None, alpha=1.0, batch=1, sA=0, sW=0, sO=0, sR=0, ldw=0, name="rf_conv_gemm"):
     """Prepare an rf_conv_gemm launch (see include/reface_hip.h)."""
     lib = _lib.load()
     _require_gpu(src0, W, out, src1, bias, rowvec, residual)
@@ -101,7 +101,7 @@ def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, 
     d.C0, d.C1, d.ld0, d.ld1 = C0, C1, ld0, ld1
     d.Hin, d.Win, d.Hout, d.Wout = Hin, Win, Hout, Wout
     d.KH, d.KW, d.stride, d.pad_t, d.pad_l, d.ups = KH, KW, stride, pad_t, pad_l, ups
-    d.W, d.bias, d.rowvec = _p(W), _p(bias), _p(rowvec)
+    d.W, d.ldw, d.bias, d.rowvec = _p(W), ldw, _p(bias), _p(rowvec)
     d.rows_per_sample, d.ldv = rows_per_sample, ldv
     d.residual, d.ldr, d.act = _p(residual), ldr, act
     d.out, d.ldo, d.alpha = _p(out), (ldo if ldo is not None else (N // 2 if act == ACT_GEGLU else N)), alpha
@@ -198,14 +198,14 @@ def ddim_pack_input(img, z_inpaint, mask, x_in, *, dup, name="ddim_pack"):
                   (img, z_inpaint, mask, x_in), name)
 
 
-def ddim_update(eps, img, pred_x0, noise, *, cfg, scale, sqrt_at, sqrt_1m_at, sqrt_aprev, dir_coef, sigma, name="ddim_update"):
+def ddim_update(eps, img, pred_x0, noise, coefs, *, cfg, scale, name="ddim_update"):
+    """coefs: device fp32 [5] = {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev-sigma^2), sigma}."""
     lib = _lib.load()
-    _require_gpu(eps, img, pred_x0, noise)
+    _require_gpu(eps, img, pred_x0, noise, coefs)
     B, _, h, w = img.shape
-    assert eps.dtype == torch.float32
+    assert eps.dtype == torch.float32 and coefs.dtype == torch.float32
     return Launch(lib.rf_ddim_update, (_p(eps), eps.shape[-1], int(cfg), float(scale), _p(img), _p(pred_x0), _p(noise), B, h * w,
-                                       float(sqrt_at), float(sqrt_1m_at), float(sqrt_aprev), float(dir_coef), float(sigma)),
-                  (eps, img, pred_x0, noise), name)
+                                       _p(coefs)), (eps, img, pred_x0, noise, coefs), name)
 
 
 def nchw_to_nhwc(x, out, name="nchw_to_nhwc"):
@@ -244,6 +244,14 @@ def silu_f32(x, out, name="silu"):
     lib = _lib.load()
     _require_gpu(x, out)
     return Launch(lib.rf_silu_f32, (_p(x), _p(out), x.numel()), (x, out), name)
+
+
+def gaussian_sample(moments, eps, out, *, scale, name="gaussian_sample"):
+    lib = _lib.load()
+    _require_gpu(moments, eps, out)
+    B, C2, H, W_ = moments.shape
+    assert moments.is_contiguous() and out.is_contiguous() and (eps is None or eps.is_contiguous())
+    return Launch(lib.rf_gaussian_sample, (_p(moments), _p(eps), float(scale), _p(out), B, C2 // 2, H * W_), (moments, eps, out), name)
 
 
 def run(launches, stream=None):

@@ -1,0 +1,410 @@
+"""UNetModel -- the 9-channel SD-inpainting UNet of REFace on hand-written HIP kernels.
+
+Interface mirrors ldm/modules/diffusionmodules/openaimodel.py:528-907 (constructor kwargs from
+configs/train.yaml:33-47, ``forward(x, timesteps, context)`` -> eps, NCHW fp32); parameters carry
+the reference's ``state_dict`` names.  The arithmetic is a prepared list of kernel launches
+(``UNetEngine``) over channels-last activations:
+
+* ResBlock (openaimodel.py:255-275): GN+SiLU -> conv3x3 (+bias +timestep row-vector) -> GN+SiLU ->
+  conv3x3 (+bias +skip) ; skip = identity or 1x1 conv.
+* SpatialTransformer (attention.py:278-289, 239-243): GN -> 1x1 -> LN -> fused QKV GEMM -> fused
+  attention -> out-proj (+bias +residual +cross-attention row-vector) -> LN -> GEGLU GEMM -> GEMM
+  (+residual) -> 1x1 (+residual).
+* Cross-attention (attention.py:179-221 with a 1-token context, ddpm.py:1012,1022): the softmax
+  over a single key is exactly 1, so attn2(x) == to_out(to_v(c)) for every token -- a per-sample
+  vector computed once per conditioning and added in the attn1 out-projection epilogue.  norm2 and
+  attn2.to_q / to_k never influence the output.
+* torch.cat([h, hs.pop()]) (openaimodel.py:898) is zero-copy: producers write straight into the
+  two halves of a preallocated concat buffer (strided outputs).
+* Upsample (openaimodel.py:116-118): nearest x2 is folded into the conv's input addressing.
+* The timestep path (util.py:151-166, openaimodel.py:632-636, 218-224) runs in fp32 for every
+  compute dtype: one GEMM produces the 22 ResBlock embedding vectors at once.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .modules import ParamTree, flat_state, weights_version
+from .params import UNetConfig, unet_param_specs, unet_plan
+
+F32 = torch.float32
+
+
+class _Pool:
+    """Free-list of device tensors keyed by (numel, dtype); launch order == allocation order."""
+
+    def __init__(self, device):
+        self.device, self.free, self.bytes = device, {}, 0
+
+    def get(self, shape, dtype):
+        n = 1
+        for s in shape:
+            n *= s
+        lst = self.free.get((n, dtype))
+        if lst:
+            return lst.pop().view(shape)
+        self.bytes += n * (4 if dtype == F32 else 2)
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def put(self, t):
+        self.free.setdefault((t.numel(), t.dtype), []).append(t.reshape(-1))
+
+
+class UNetEngine:
+    """Prepared launch list for one (batch, height, width, dtype).
+
+    ``uniform_t=True``: all samples share one timestep (DDIM sampling): the embedding buffer has one
+    row that every sample reads (row-vector pitch 0).
+    """
+
+    CPAD = 16      # 9 input channels stored in 16 (multiple of the 16-byte vector for both dtypes)
+
+    def __init__(self, sd, cfg: UNetConfig, B, H, W, dtype, device, uniform_t=False, emb_rows=None):
+        self.cfg, self.B, self.H, self.W, self.dt, self.dev = cfg, B, H, W, dtype, device
+        self.uniform_t = uniform_t
+        self.pool = _Pool(device)
+        self.sd = {k: v.detach().to(device=device, dtype=F32) for k, v in sd.items()}
+        self.plan = unet_plan(cfg)
+        nds = len(cfg.channel_mult) - 1
+        if H % (1 << nds) or W % (1 << nds):
+            raise ValueError(f"latent size {H}x{W} must be a multiple of {1 << nds}")
+        self.x_in = torch.zeros((B, H, W, self.CPAD), dtype=dtype, device=device)
+        self.eps = torch.empty((B, H, W, 4), dtype=F32, device=device)
+        self.gn_partial = torch.empty(B * ops.GN_MAX_CHUNKS * 64, dtype=torch.float64, device=device)
+        self._build_emb(emb_rows if emb_rows is not None else (1 if uniform_t else B))
+        self._build_ctx()
+        self.main = []
+        self._build_main()
+        self.sd = None      # packed copies are held by the launches
+
+    # ------------------------------------------------------------------ weights
+    def w(self, key, dtype=None):
+        return self.sd[key].to(dtype or self.dt).contiguous()
+
+    def f32(self, key):
+        return self.sd[key].contiguous()
+
+    # ------------------------------------------------------------------ timestep path (fp32)
+    def _res_prefixes(self):
+        ib, mid, ob = self.plan
+        out = []
+        for i, layers in enumerate(ib):
+            out += [(f"input_blocks.{i}.{j}", l[2]) for j, l in enumerate(layers) if l[0] == "res"]
+        out += [(f"middle_block.{j}", l[2]) for j, l in enumerate(mid) if l[0] == "res"]
+        for i, layers in enumerate(ob):
+            out += [(f"output_blocks.{i}.{j}", l[2]) for j, l in enumerate(layers) if l[0] == "res"]
+        return out
+
+    def _build_emb(self, rows):
+        cfg, dev = self.cfg, self.dev
+        mc, td = cfg.model_channels, cfg.time_embed_dim
+        half = mc // 2
+        # util.py:160-162 -- frequency table built exactly as the reference does (fp32 torch ops)
+        self.freqs = torch.exp(-math.log(10000.0) * torch.arange(0, half, dtype=F32) / half).to(dev)
+        res = self._res_prefixes()
+        self.emb_off, off = {}, 0
+        for p, cout in res:
+            self.emb_off[p] = (off, cout)
+            off += cout
+        self.E = off
+        wcat = torch.cat([self.f32(f"{p}.emb_layers.1.weight") for p, _ in res], 0).contiguous()
+        bcat = torch.cat([self.f32(f"{p}.emb_layers.1.bias") for p, _ in res], 0).contiguous()
+        self._emb_w = (self.f32("time_embed.0.weight"), self.f32("time_embed.0.bias"),
+                       self.f32("time_embed.2.weight"), self.f32("time_embed.2.bias"), wcat, bcat)
+        self.emb_rows = rows
+        self.t_f32 = torch.zeros(rows, dtype=F32, device=dev)
+        self.emb_table = torch.zeros((rows, self.E), dtype=F32, device=dev)
+        self.emb_launches = self.make_emb_launches(self.t_f32, self.emb_table)
+
+    def make_emb_launches(self, t_f32, table):
+        """Launch chain  t[n] -> table[n, E]  (all ResBlock ``emb_layers`` outputs)."""
+        n = t_f32.shape[0]
+        mc, td, dev = self.cfg.model_channels, self.cfg.time_embed_dim, self.dev
+        w0, b0, w2, b2, wcat, bcat = self._emb_w
+        temb = torch.empty((n, mc), dtype=F32, device=dev)
+        h = torch.empty((n, td), dtype=F32, device=dev)
+        emb = torch.empty((n, td), dtype=F32, device=dev)
+        semb = torch.empty((n, td), dtype=F32, device=dev)
+        return [ops.timestep_embedding(t_f32, self.freqs, temb),
+                ops.linear(temb, w0, h, b0, act=ops.ACT_SILU, name="time_embed.0"),
+                ops.linear(h, w2, emb, b2, name="time_embed.2"),
+                ops.silu_f32(emb, semb),
+                ops.linear(semb, wcat, table, bcat, name="emb_layers")]
+
+    def emb_vec(self, p):
+        off, cout = self.emb_off[p]
+        return self.emb_table[:, off:off + cout]
+
+    # ------------------------------------------------------------------ conditioning path (fp32)
+    def _st_prefixes(self):
+        ib, mid, ob = self.plan
+        out = []
+        for i, layers in enumerate(ib):
+            out += [(f"input_blocks.{i}.{j}", l[1]) for j, l in enumerate(layers) if l[0] == "st"]
+        out += [(f"middle_block.{j}", l[1]) for j, l in enumerate(mid) if l[0] == "st"]
+        for i, layers in enumerate(ob):
+            out += [(f"output_blocks.{i}.{j}", l[1]) for j, l in enumerate(layers) if l[0] == "st"]
+        return out
+
+    def _build_ctx(self):
+        B, dev = self.B, self.dev
+        sts = self._st_prefixes()
+        self.ctx_off, off = {}, 0
+        for p, c in sts:
+            self.ctx_off[p] = (off, c)
+            off += c
+        self.ctx_in = torch.zeros((B, self.cfg.context_dim), dtype=F32, device=dev)
+        self.ctx_table = torch.zeros((B, max(off, 1)), dtype=F32, device=dev)
+        self.ctx_launches = []
+        for p, c in sts:
+            t = f"{p}.transformer_blocks.0.attn2"
+            v = torch.empty((B, c), dtype=F32, device=dev)
+            o, _ = self.ctx_off[p]
+            self.ctx_launches.append(ops.linear(self.ctx_in, self.f32(f"{t}.to_v.weight"), v, None, name=t + ".to_v"))
+            self.ctx_launches.append(ops.linear(v, self.f32(f"{t}.to_out.0.weight"), self.ctx_table[:, o:o + c],
+                                                self.f32(f"{t}.to_out.0.bias"), name=t + ".to_out"))
+
+    def ctx_vec(self, p):
+        off, c = self.ctx_off[p]
+        return self.ctx_table[:, off:off + c]
+
+    # ------------------------------------------------------------------ main graph
+    def _gn(self, x, key, eps, silu):
+        out = self.pool.get(tuple(x.shape), self.dt)
+        self.main += ops.groupnorm(x, self.f32(key + ".weight"), self.f32(key + ".bias"), out, self.gn_partial, eps=eps,
+                                   silu=silu, name=key)
+        return out
+
+    def _res(self, p, x, cin, cout, dst):
+        B, H, W, _ = x.shape
+        t1 = self._gn(x, f"{p}.in_layers.0", 1e-5, True)
+        h1 = self.pool.get((B, H, W, cout), self.dt)
+        rv = self.emb_vec(p)
+        if self.uniform_t:
+            rv = rv.as_strided((B, cout), (0, 1), rv.storage_offset())      # every sample reads row 0
+        self.main.append(ops.conv2d(t1, ops.pack_conv_weight(self.sd[f"{p}.in_layers.2.weight"], self.dt), h1,
+                                    self.f32(f"{p}.in_layers.2.bias"), rowvec=rv, name=f"{p}.in_layers.2"))
+        self.pool.put(t1)
+        t2 = self._gn(h1, f"{p}.out_layers.0", 1e-5, True)
+        self.pool.put(h1)
+        if cin != cout:
+            skip = self.pool.get((B, H, W, cout), self.dt)
+            self.main.append(ops.conv2d(x, self.w(f"{p}.skip_connection.weight").reshape(cout, cin), skip,
+                                        self.f32(f"{p}.skip_connection.bias"), ksize=1, pad=(0, 0), name=f"{p}.skip_connection"))
+        else:
+            skip = x
+        y = dst if dst is not None else self.pool.get((B, H, W, cout), self.dt)
+        self.main.append(ops.conv2d(t2, ops.pack_conv_weight(self.sd[f"{p}.out_layers.3.weight"], self.dt), y,
+                                    self.f32(f"{p}.out_layers.3.bias"), residual=skip, name=f"{p}.out_layers.3"))
+        self.pool.put(t2)
+        if cin != cout:
+            self.pool.put(skip)
+        return y
+
+    def _st(self, p, x, c, heads, dst):
+        B, H, W, _ = x.shape
+        M, d = B * H * W, c // heads
+        t = f"{p}.transformer_blocks.0"
+        g = self._gn(x, f"{p}.norm", 1e-6, False)
+        tok = self.pool.get((M, c), self.dt)
+        self.main.append(ops.linear(g.view(M, c), self.w(f"{p}.proj_in.weight").reshape(c, c), tok, self.f32(f"{p}.proj_in.bias"),
+                                    name=f"{p}.proj_in"))
+        self.pool.put(g)
+        ln = self.pool.get((M, c), self.dt)
+        self.main.append(ops.layernorm(tok, self.f32(f"{t}.norm1.weight"), self.f32(f"{t}.norm1.bias"), ln, name=f"{t}.norm1"))
+        qkv = self.pool.get((M, 3 * c), self.dt)
+        wqkv = torch.cat([self.sd[f"{t}.attn1.to_q.weight"], self.sd[f"{t}.attn1.to_k.weight"], self.sd[f"{t}.attn1.to_v.weight"]], 0)
+        self.main.append(ops.linear(ln, wqkv.to(self.dt).contiguous(), qkv, None, name=f"{t}.attn1.qkv"))
+        att = ln    # reuse the LayerNorm buffer for the attention output
+        q3 = qkv.view(B, H * W, 3 * c)
+        self.main.append(ops.attention(q3[..., :c], q3[..., c:2 * c], q3[..., 2 * c:], att.view(B, H * W, c), heads=heads,
+                                       scale=d ** -0.5, name=f"{t}.attn1"))
+        x1 = self.pool.get((M, c), self.dt)
+        # attn1 out-projection + residual + the (token-independent) cross-attention output
+        self.main.append(ops.linear(att, self.w(f"{t}.attn1.to_out.0.weight"), x1, self.f32(f"{t}.attn1.to_out.0.bias"), residual=tok,
+                                    rowvec=self.ctx_vec(p), rows_per_sample=H * W, name=f"{t}.attn1.to_out"))
+        self.pool.put(qkv)
+        self.pool.put(tok)
+        self.main.append(ops.layernorm(x1, self.f32(f"{t}.norm3.weight"), self.f32(f"{t}.norm3.bias"), ln, name=f"{t}.norm3"))
+        wg, bg = ops.pack_geglu(self.sd[f"{t}.ff.net.0.proj.weight"], self.sd[f"{t}.ff.net.0.proj.bias"], self.dt)
+        gg = self.pool.get((M, 4 * c), self.dt)
+        self.main.append(ops.linear(ln, wg, gg, bg, act=ops.ACT_GEGLU, name=f"{t}.ff.net.0"))
+        x2 = ln
+        self.main.append(ops.linear(gg, self.w(f"{t}.ff.net.2.weight"), x2, self.f32(f"{t}.ff.net.2.bias"), residual=x1, name=f"{t}.ff.net.2"))
+        self.pool.put(gg)
+        self.pool.put(x1)
+        y = dst if dst is not None else self.pool.get((B, H, W, c), self.dt)
+        self.main.append(ops.conv2d(x2.view(B, H, W, c), self.w(f"{p}.proj_out.weight").reshape(c, c), y, self.f32(f"{p}.proj_out.bias"),
+                                    ksize=1, pad=(0, 0), residual=x, name=f"{p}.proj_out"))
+        self.pool.put(x2)
+        return y
+
+    def _block(self, prefix, layers, x, dst):
+        """TimestepEmbedSequential (openaimodel.py:80-88); the last layer writes into ``dst``."""
+        B = self.B
+        for j, l in enumerate(layers):
+            p = f"{prefix}.{j}"
+            last = j == len(layers) - 1
+            d = dst if last else None
+            H, W = x.shape[1], x.shape[2]
+            if l[0] == "conv":
+                y = d if d is not None else self.pool.get((B, H, W, l[2]), self.dt)
+                self.main.append(ops.conv2d(x, ops.pack_conv_weight(self.sd[f"{p}.weight"], self.dt, cin_pad=self.CPAD), y,
+                                            self.f32(f"{p}.bias"), name=p))
+            elif l[0] == "res":
+                y = self._res(p, x, l[1], l[2], d)
+            elif l[0] == "st":
+                y = self._st(p, x, l[1], l[2], d)
+            elif l[0] == "down":
+                y = d if d is not None else self.pool.get((B, H // 2, W // 2, l[1]), self.dt)
+                self.main.append(ops.conv2d(x, ops.pack_conv_weight(self.sd[f"{p}.op.weight"], self.dt), y, self.f32(f"{p}.op.bias"),
+                                            stride=2, name=f"{p}.op"))
+            elif l[0] == "up":
+                y = d if d is not None else self.pool.get((B, 2 * H, 2 * W, l[1]), self.dt)
+                self.main.append(ops.conv2d(x, ops.pack_conv_weight(self.sd[f"{p}.conv.weight"], self.dt), y, self.f32(f"{p}.conv.bias"),
+                                            ups=1, name=f"{p}.conv"))
+            else:
+                raise ValueError(l)
+            if j > 0 and x is not None:
+                self.pool.put(x)           # intra-block intermediate
+            x = y
+        return x
+
+    @staticmethod
+    def _out_ch(layers):
+        for l in reversed(layers):
+            if l[0] in ("res", "conv"):
+                return l[2]
+        return layers[-1][1]
+
+    def _build_main(self):
+        cfg, B, dev = self.cfg, self.B, self.dev
+        ib, mid, ob = self.plan
+        # shapes of every input-block output (the skips) and the h entering each output block
+        skip_shapes, H, W = [], self.H, self.W
+        for layers in ib:
+            if layers[0][0] == "down":
+                H, W = H // 2, W // 2
+                skip_shapes.append((H, W, layers[0][1]))
+            else:
+                skip_shapes.append((H, W, self._out_ch(layers)))
+        hch = self._out_ch(mid)
+        cats, hH, hW = [], H, W
+        stack = list(skip_shapes)
+        for layers in ob:
+            sh, sw, sc = stack.pop()
+            assert (sh, sw) == (hH, hW), "skip / decoder resolution mismatch"
+            cats.append(torch.empty((B, sh, sw, hch + sc), dtype=self.dt, device=dev))
+            hch = self._out_ch(layers)
+            if layers[-1][0] == "up":
+                hH, hW = 2 * hH, 2 * hW
+        n_in = len(ib)
+        # input block i's output is the skip of output block (n_in - 1 - i): right part of that concat buffer
+        x = self.x_in
+        for i, layers in enumerate(ib):
+            cat = cats[n_in - 1 - i]
+            c1 = skip_shapes[i][2]
+            dst = cat[..., cat.shape[3] - c1:]
+            x = self._block(f"input_blocks.{i}", layers, x, dst)
+        c0 = cats[0].shape[3] - skip_shapes[-1][2]
+        self._block("middle_block", mid, x, cats[0][..., :c0])
+        final = None
+        for i, layers in enumerate(ob):
+            if i + 1 < len(ob):
+                nxt = cats[i + 1]
+                c0n = nxt.shape[3] - skip_shapes[n_in - 2 - i][2]
+                dst = nxt[..., :c0n]
+            else:
+                dst = None
+            final = self._block(f"output_blocks.{i}", layers, cats[i], dst)
+        g = self._gn(final, "out.0", 1e-5, True)
+        self.main.append(ops.conv2d(g, ops.pack_conv_weight(self.sd["out.2.weight"], self.dt), self.eps, self.f32("out.2.bias"), name="out.2"))
+        self.cats = cats
+
+    # ------------------------------------------------------------------ execution
+    def set_context(self, context):
+        """context: [B, 1, ctx_dim] or [B, ctx_dim] (device fp32)."""
+        c = context.reshape(self.B, -1).to(device=self.dev, dtype=F32)
+        self.ctx_in.copy_(c)
+        ops.run(self.ctx_launches)
+
+    def set_timesteps(self, t):
+        self.t_f32.copy_(t.reshape(-1)[: self.emb_rows].to(device=self.dev, dtype=F32))
+        ops.run(self.emb_launches)
+
+    def run(self, stream=None):
+        ops.run(self.main, stream)
+
+
+class UNetModel(nn.Module):
+    """Drop-in for ``ldm.modules.diffusionmodules.openaimodel.UNetModel`` (inference only)."""
+
+    def __init__(self, image_size=32, in_channels=9, model_channels=320, out_channels=4, num_res_blocks=2,
+                 attention_resolutions=(4, 2, 1), dropout=0, channel_mult=(1, 2, 4, 4), conv_resample=True, dims=2,
+                 num_classes=None, use_checkpoint=False, use_fp16=False, num_heads=-1, num_head_channels=-1,
+                 num_heads_upsample=-1, use_scale_shift_norm=False, resblock_updown=False, use_new_attention_order=False,
+                 use_spatial_transformer=False, transformer_depth=1, context_dim=None, n_embed=None, legacy=True,
+                 add_conv_in_front_of_unet=False, sep_head_att=False, land_mark_id_seperate_layers=False, head_splits=None,
+                 compute_dtype=None):
+        super().__init__()
+        # the REFace path (configs/train.yaml:33-47); anything else is outside this build's scope
+        unsupported = dict(dims=(dims, 2), num_classes=(num_classes, None), use_scale_shift_norm=(use_scale_shift_norm, False),
+                           resblock_updown=(resblock_updown, False), n_embed=(n_embed, None), legacy=(legacy, False),
+                           add_conv_in_front_of_unet=(add_conv_in_front_of_unet, False), sep_head_att=(sep_head_att, False),
+                           land_mark_id_seperate_layers=(land_mark_id_seperate_layers, False), conv_resample=(conv_resample, True),
+                           use_spatial_transformer=(use_spatial_transformer, True), num_head_channels=(num_head_channels, -1))
+        for k, (got, want) in unsupported.items():
+            if got != want:
+                raise NotImplementedError(f"UNetModel({k}={got!r}) is not on the REFace inference path (expected {want!r})")
+        if context_dim is None or num_heads == -1:
+            raise NotImplementedError("UNetModel needs context_dim and num_heads (spatial-transformer configuration)")
+        if isinstance(context_dim, (list, tuple)):
+            context_dim = list(context_dim)[0]
+        self.cfg = UNetConfig(in_channels=in_channels, model_channels=model_channels, out_channels=out_channels,
+                              num_res_blocks=num_res_blocks, attention_resolutions=tuple(attention_resolutions),
+                              channel_mult=tuple(channel_mult), num_heads=num_heads, transformer_depth=transformer_depth,
+                              context_dim=context_dim)
+        self.image_size, self.in_channels, self.model_channels, self.out_channels = image_size, in_channels, model_channels, out_channels
+        self.num_res_blocks, self.attention_resolutions, self.channel_mult = num_res_blocks, attention_resolutions, channel_mult
+        self.num_heads, self.use_checkpoint, self.dtype = num_heads, use_checkpoint, torch.float32
+        self.compute_dtype = compute_dtype or torch.float32
+        tree = ParamTree(unet_param_specs(self.cfg))
+        for name, child in tree.named_children():
+            self.add_module(name, child)
+        self._engines = {}
+
+    def set_compute_dtype(self, dtype):
+        self.compute_dtype = dtype
+        self._engines.clear()
+
+    def engine(self, B, H, W, uniform_t=False, emb_rows=None):
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("reface_amd.UNetModel runs on the GPU only (HIP kernels; there is no CPU fallback)")
+        key = (B, H, W, self.compute_dtype, uniform_t, emb_rows, weights_version(self))
+        eng = self._engines.get(key)
+        if eng is None:
+            self._engines = {k: v for k, v in self._engines.items() if k[-1] == key[-1]}   # drop engines of stale weights
+            eng = UNetEngine(flat_state(self), self.cfg, B, H, W, self.compute_dtype, dev, uniform_t=uniform_t, emb_rows=emb_rows)
+            self._engines[key] = eng
+        return eng
+
+    @torch.no_grad()
+    def forward(self, x, timesteps=None, context=None, y=None, return_features=False, **kwargs):
+        """x: [N, 9, h, w] fp32 NCHW; timesteps: [N]; context: [N, 1, 768] -> eps [N, 4, h, w] fp32."""
+        assert y is None, "must specify y if and only if the model is class-conditional"
+        if return_features:
+            raise NotImplementedError("return_features is a training-time option")
+        if context is None or context.shape[1] != 1:
+            raise NotImplementedError("REFace conditioning is a single 768-d token per sample")
+        N, C, H, W = x.shape
+        eng = self.engine(N, H, W)
+        ops.nchw_to_nhwc(x.float().contiguous(), eng.x_in)()
+        eng.set_context(context)
+        eng.set_timesteps(timesteps)
+        eng.run()
+        out = torch.empty((N, self.out_channels, H, W), dtype=torch.float32, device=x.device)
+        ops.nhwc_to_nchw(eng.eps, out)()
+        return out

@@ -236,8 +236,9 @@ def test_ddim_glue():
     noise = rnd((B, 4, h, h), 35)
     imgd = img.to(DEV).clone()
     px0 = torch.empty_like(imgd)
-    ops.ddim_update(eps.to(DEV), imgd, px0, noise.to(DEV), cfg=True, scale=3.5, sqrt_at=math.sqrt(a_t),
-                    sqrt_1m_at=math.sqrt(1 - a_t), sqrt_aprev=math.sqrt(a_prev), dir_coef=math.sqrt(1 - a_prev - sig ** 2), sigma=sig)()
+    coefs = torch.tensor([math.sqrt(a_t), math.sqrt(1 - a_t), math.sqrt(a_prev), math.sqrt(1 - a_prev - sig ** 2), sig],
+                         dtype=torch.float32, device=DEV)
+    ops.ddim_update(eps.to(DEV), imgd, px0, noise.to(DEV), coefs, cfg=True, scale=3.5)()
     torch.cuda.synchronize()
     e = eps[..., :4].permute(0, 3, 1, 2)
     e = e[:B] + 3.5 * (e[B:] - e[:B])

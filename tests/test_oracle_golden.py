@@ -18,7 +18,7 @@ from oracle import schedule, unet, vae, ddim, encoders
 rnd = P.seeded_randn
 torch.set_grad_enabled(False)
 
-SMALL_UNET = dict(in_channels=9, model_channels=32, out_channels=4, num_res_blocks=2,
+SMALL_UNET = dict(in_channels=9, model_channels=64, out_channels=4, num_res_blocks=2,
                   attention_resolutions=(4, 2, 1), channel_mult=(1, 2, 4, 4), num_heads=8, context_dim=768)
 SMALL_VAE = dict(ch=32, ch_mult=(1, 2, 4, 4), num_res_blocks=2, in_channels=3, out_ch=3, z_channels=4,
                  embed_dim=4, double_z=True, attn_resolutions=(), resolution=256)

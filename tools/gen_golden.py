@@ -115,7 +115,7 @@ def gen_unet_ops():
     save("unet_ops", **res)
 
 
-SMALL_UNET = dict(in_channels=9, model_channels=32, out_channels=4, num_res_blocks=2,
+SMALL_UNET = dict(in_channels=9, model_channels=64, out_channels=4, num_res_blocks=2,
                   attention_resolutions=(4, 2, 1), channel_mult=(1, 2, 4, 4), num_heads=8, context_dim=768)
 
 
@@ -325,7 +325,7 @@ def gen_e2e():
     DDIMSampler.register_buffer = lambda self, n, a: setattr(self, n, a)
     raw = yaml.safe_load(open("/root/reference/configs/train.yaml"))
     mp = raw["model"]["params"]
-    mp["unet_config"]["params"]["model_channels"] = 32
+    mp["unet_config"]["params"]["model_channels"] = 64
     mp["first_stage_config"]["params"]["ddconfig"]["ch"] = 32
     ccfg = P.CLIPVisionConfig(**SMALL_CLIP)
     arc_sd = P.seeded_state_dict(P.arcface_param_specs(), 77)
