@@ -132,6 +132,8 @@ int rf_timestep_embedding(const float* t, int n, int dim, const float* freqs, fl
 /* KL-VAE posterior sample (distributions.py:24-37, ddpm.py:857): moments NCHW [B, 2C, HW] = (mean | logvar),
  * eps NCHW [B, C, HW] or NULL (mode):  out = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * eps) */
 int rf_gaussian_sample(const float* moments, const float* eps, float scale, float* out, int B, int C, int HW, void* stream);
+/* y = clamp((x + 1) / 2, 0, 1)  (scripts/inference_test_bench.py:494) */
+int rf_to_image(const float* x, float* y, int64_t n, void* stream);
 /* elementwise y = silu(x) on fp32 (emb path, openaimodel.py:219) */
 int rf_silu_f32(const float* x, float* y, int64_t n, void* stream);
 

@@ -52,6 +52,7 @@ _SIGS = {
     "rf_cast": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "rf_timestep_embedding": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rf_silu_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "rf_to_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rf_gaussian_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 

@@ -112,6 +112,12 @@ __global__ void gaussian_sample_kernel(const float* __restrict__ moments, const 
     out[i] = scale * x;
 }
 
+// inference_test_bench.py:494: clamp((x + 1) / 2, 0, 1)
+__global__ void to_image_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = fminf(fmaxf((x[i] + 1.0f) / 2.0f, 0.0f), 1.0f);
+}
+
 static inline dim3 grid1d(long long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
 }  // namespace rf
@@ -188,5 +194,12 @@ extern "C" int rf_gaussian_sample(const float* moments, const float* eps, float 
     RF_CHECK(moments && out && B > 0 && C > 0 && HW > 0, "rf_gaussian_sample: bad arguments");
     hipLaunchKernelGGL(gaussian_sample_kernel, grid1d((long long)B * C * HW), dim3(256), 0, (hipStream_t)stream, moments, eps, scale, out, B, C, HW);
     RF_LAUNCH_CHECK("rf_gaussian_sample");
+    return 0;
+}
+
+extern "C" int rf_to_image(const float* x, float* y, int64_t n, void* stream) {
+    RF_CHECK(x && y && n > 0, "rf_to_image: bad arguments");
+    hipLaunchKernelGGL(to_image_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, x, y, (long long)n);
+    RF_LAUNCH_CHECK("rf_to_image");
     return 0;
 }

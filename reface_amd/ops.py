@@ -246,6 +246,13 @@ def silu_f32(x, out, name="silu"):
     return Launch(lib.rf_silu_f32, (_p(x), _p(out), x.numel()), (x, out), name)
 
 
+def to_image(x, out, name="to_image"):
+    lib = _lib.load()
+    _require_gpu(x, out)
+    assert x.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
+    return Launch(lib.rf_to_image, (_p(x), _p(out), x.numel()), (x, out), name)
+
+
 def gaussian_sample(moments, eps, out, *, scale, name="gaussian_sample"):
     lib = _lib.load()
     _require_gpu(moments, eps, out)

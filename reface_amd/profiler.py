@@ -1,0 +1,64 @@
+"""Per-launch timing with HIP events (on the stream the kernels are launched on) and the
+algorithmic FLOP / byte accounting used for the roofline numbers of bench.py."""
+import collections
+
+import torch
+
+from ._lib import ConvGemmDesc
+
+
+def launch_family(l):
+    n = l.fn.__name__
+    if n == "rf_conv_gemm":
+        d = l.keep[0]
+        return f"rf_conv_gemm[{'bf16' if d.dtype == 1 else 'f32'}]"
+    return n
+
+
+def gemm_flops(l):
+    """Algorithmic FLOPs of one rf_conv_gemm launch: 2*M*N*K_real (padding excluded); GEGLU N counts both halves."""
+    if l.fn.__name__ != "rf_conv_gemm":
+        return 0.0
+    d = l.keep[0]
+    k_real = d.KH * d.KW * (d.C0 + d.C1)
+    return 2.0 * d.M * d.N * min(k_real, d.K) * d.batch
+
+
+def attention_flops(l):
+    if l.fn.__name__ != "rf_attention":
+        return 0.0
+    a = l.args          # (dtype, q, k, v, out, B, heads, d, Nq, Nk, ...)
+    B, heads, d, Nq, Nk = a[5], a[6], a[7], a[8], a[9]
+    return 4.0 * B * heads * Nq * Nk * d
+
+
+def time_launches(launches, reps=3, warmup=1):
+    """Time every launch individually (HIP events on the current torch stream, which is the stream
+    the launches run on).  Returns a list of (launch, mean_ms)."""
+    stream = torch.cuda.current_stream()
+    sp = stream.cuda_stream
+    out = []
+    for l in launches:
+        for _ in range(warmup):
+            l(sp)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for s, e in ev:
+            s.record(stream)
+            l(sp)
+            e.record(stream)
+        torch.cuda.synchronize()
+        out.append((l, sum(s.elapsed_time(e) for s, e in ev) / reps))
+    return out
+
+
+def summarize(timed):
+    """Aggregate per kernel family: calls, total ms, algorithmic TFLOP, TFLOP/s."""
+    fam = collections.OrderedDict()
+    for l, ms in timed:
+        f = fam.setdefault(launch_family(l), dict(calls=0, ms=0.0, flops=0.0))
+        f["calls"] += 1
+        f["ms"] += ms
+        f["flops"] += gemm_flops(l) + attention_flops(l)
+    for f in fam.values():
+        f["tflops_per_s"] = (f["flops"] / (f["ms"] * 1e-3) / 1e12) if f["ms"] > 0 else 0.0
+    return fam
