@@ -28,7 +28,8 @@ extern "C" {
 enum { RF_F32 = 0, RF_BF16 = 1 };
 
 /* epilogue activations of rf_conv_gemm */
-enum { RF_ACT_NONE = 0, RF_ACT_GEGLU = 1, RF_ACT_SILU = 2, RF_ACT_QUICK_GELU = 3, RF_ACT_GELU = 4 };
+enum { RF_ACT_NONE = 0, RF_ACT_GEGLU = 1, RF_ACT_SILU = 2, RF_ACT_QUICK_GELU = 3, RF_ACT_GELU = 4,
+       RF_ACT_RELU = 5, RF_ACT_SIGMOID = 6, RF_ACT_PRELU = 7 };
 
 const char* rf_last_error(void);
 int rf_version(void);
@@ -74,6 +75,7 @@ typedef struct rf_conv_gemm_desc {
     float alpha;
     int32_t batch;        /* >= 1 */
     int64_t sA, sW, sO, sR;   /* batch strides (elements) of src0, W, out, residual */
+    const float* act_vec; /* [N] fp32 per-column activation parameter (PReLU slopes) or NULL */
 } rf_conv_gemm_desc;
 
 int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream);
@@ -132,6 +134,29 @@ int rf_timestep_embedding(const float* t, int n, int dim, const float* freqs, fl
 /* KL-VAE posterior sample (distributions.py:24-37, ddpm.py:857): moments NCHW [B, 2C, HW] = (mean | logvar),
  * eps NCHW [B, C, HW] or NULL (mode):  out = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * eps) */
 int rf_gaussian_sample(const float* moments, const float* eps, float scale, float* out, int B, int C, int HW, void* stream);
+/*
+ * Conditioning-encoder side kernels (ArcFace IR-SE50: src/Face_models/encoders/helpers.py:56-119, model_irse.py:20-69,
+ * ldm/models/diffusion/ddpm.py:112-124; CLIP ViT: HF CLIPVisionEmbeddings; ddpm.py:907-912).
+ *   rf_channel_affine  : y[m,c] = prelu(x[m,c]*a[c] + b[c])   (eval BatchNorm as affine, optional PReLU slopes)
+ *   rf_spatial_mean    : [B,HW,C] -> fp32 [B,C]              (SE squeeze, AdaptiveAvgPool2d(1))
+ *   rf_se_scale_add    : out = r * s[b,c] + shortcut[b, oy*stride, ox*stride, c]   (SE excite + MaxPool2d(1,stride) shortcut)
+ *   rf_adaptive_avgpool: AdaptiveAvgPool2d over a crop window of NCHW fp32 with input affine; NCHW fp32 or NHWC out
+ *   rf_bilinear_resize : F.interpolate(bilinear, align_corners=False, antialias=False) of NCHW fp32 with input affine
+ *   rf_clip_tokens     : [cls + pos[0] ; patch + pos[1:]] token assembly
+ *   rf_l2norm_rows     : x / ||x||_2 per row (fp32)
+ */
+int rf_channel_affine(int dtype, const void* x, int ldx, const float* a, const float* b, const float* slope, int out_dtype,
+                      void* y, int ldy, int64_t M, int C, void* stream);
+int rf_spatial_mean(int dtype, const void* x, int B, int HW, int C, int ldx, float* out, void* stream);
+int rf_se_scale_add(int dtype, const void* r, const float* s, const void* sc, int ldsc, int Hs, int Ws, int stride, void* out,
+                    int B, int Ho, int Wo, int C, void* stream);
+int rf_adaptive_avgpool(const float* x, int B, int C, int Hf, int Wf, int y0, int x0, int hc, int wc, const float* a, const float* b,
+                        int Ho, int Wo, int out_nhwc, int out_dtype, int Cpad, void* out, void* stream);
+int rf_bilinear_resize(const float* x, int B, int C, int Hi, int Wi, const float* a, const float* b, int Ho, int Wo, float* out, void* stream);
+int rf_clip_tokens(int dtype, const void* patch, const float* cls, const float* pos, void* out, int B, int NP, int C, void* stream);
+int rf_l2norm_rows(const float* x, float* y, int rows, int cols, void* stream);
+/* conditioning combine (ddpm.py:1038-1039): out = (a*wa + b*wb + c*wc) / den (den = 0: no division); b, c may be NULL */
+int rf_combine3(const float* a, const float* b, const float* c, float wa, float wb, float wc, float den, float* out, int64_t n, void* stream);
 /* y = clamp((x + 1) / 2, 0, 1)  (scripts/inference_test_bench.py:494) */
 int rf_to_image(const float* x, float* y, int64_t n, void* stream);
 /* elementwise y = silu(x) on fp32 (emb path, openaimodel.py:219) */

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libreface_hip.so")
 
 RF_F32, RF_BF16 = 0, 1
-ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU, ACT_GELU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_PRELU = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 class ConvGemmDesc(C.Structure):
@@ -29,6 +29,7 @@ class ConvGemmDesc(C.Structure):
         ("out", C.c_void_p), ("ldo", C.c_int32), ("alpha", C.c_float),
         ("batch", C.c_int32),
         ("sA", C.c_int64), ("sW", C.c_int64), ("sO", C.c_int64), ("sR", C.c_int64),
+        ("act_vec", C.c_void_p),
     ]
 
 
@@ -53,6 +54,18 @@ _SIGS = {
     "rf_timestep_embedding": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rf_silu_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rf_to_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "rf_channel_affine": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                    C.c_int64, C.c_int, C.c_void_p]),
+    "rf_spatial_mean": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "rf_se_scale_add": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "rf_adaptive_avgpool": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "rf_bilinear_resize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p]),
+    "rf_clip_tokens": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "rf_l2norm_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "rf_combine3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "rf_gaussian_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
@@ -69,6 +82,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own HIP runtime; it must be loaded first so that libreface_hip.so binds to the
+    # SAME libamdhip64 instance (device pointers and streams are shared with torch).  Loading this library
+    # before torch pulls in /opt/rocm's runtime instead and every launch fails with "no ROCm-capable device".
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RefaceHipError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m reface_amd.build` "

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libreface_hip.so")
-SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "encoder.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 
 

@@ -28,6 +28,7 @@ struct GemmParams {
     int rows_per_sample, ldv;
     const void* residual;
     int ldr, act;
+    const float* act_vec;
     void* out;
     int ldo;
     float alpha;
@@ -247,6 +248,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                     if (p.act == RF_ACT_SILU) v = silu_exact(v);
                     else if (p.act == RF_ACT_QUICK_GELU) v = quick_gelu(v);
                     else if (p.act == RF_ACT_GELU) v = gelu_erf(v);
+                    else if (p.act == RF_ACT_RELU) v = fmaxf(v, 0.0f);
+                    else if (p.act == RF_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                    else if (p.act == RF_ACT_PRELU) v = v >= 0.0f ? v : v * p.act_vec[col];
                     if (resp) v += load_out<TO>(resp + (long long)row * p.ldr + col);
                     store_out<TO>(outp + (long long)row * p.ldo + col, v);
                 }
@@ -308,6 +312,7 @@ extern "C" int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream) {
     RF_CHECK(((uintptr_t)d->src0 | (uintptr_t)d->src1 | (uintptr_t)d->W) % 16 == 0, "rf_conv_gemm: operands must be 16-byte aligned");
     RF_CHECK(d->act != RF_ACT_GEGLU || (d->N % 64 == 0 && !d->rowvec), "rf_conv_gemm: GEGLU needs N %% 64 == 0 and no rowvec");
     RF_CHECK(!d->rowvec || d->rows_per_sample > 0, "rf_conv_gemm: rowvec needs rows_per_sample");
+    RF_CHECK(d->act != RF_ACT_PRELU || d->act_vec, "rf_conv_gemm: PReLU needs act_vec (per-column slopes)");
     const bool conv = !(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->ups == 0 &&
                         d->C1 == 0 && d->Hin == d->Hout && d->Win == d->Wout);
     RF_CHECK(!conv || d->batch == 1, "rf_conv_gemm: batch > 1 only for plain GEMM");
@@ -319,7 +324,7 @@ extern "C" int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream) {
     p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout;
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.ups = d->ups;
     p.W = d->W; p.ldw = d->ldw > 0 ? d->ldw : d->K; p.bias = d->bias; p.rowvec = d->rowvec; p.rows_per_sample = d->rows_per_sample; p.ldv = d->ldv;
-    p.residual = d->residual; p.ldr = d->ldr; p.act = d->act; p.out = d->out; p.ldo = d->ldo; p.alpha = d->alpha;
+    p.residual = d->residual; p.ldr = d->ldr; p.act = d->act; p.act_vec = d->act_vec; p.out = d->out; p.ldo = d->ldo; p.alpha = d->alpha;
     p.sA = d->sA; p.sW = d->sW; p.sO = d->sO; p.sR = d->sR;
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == RF_F32) {

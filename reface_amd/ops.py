@@ -9,7 +9,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, RF_BF16, RF_F32, ConvGemmDesc)
+from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_PRELU, ACT_QUICK_GELU, ACT_RELU, ACT_SIGMOID, ACT_SILU, RF_BF16, RF_F32,
+                   ConvGemmDesc)
 
 
 def code(dt):
@@ -86,7 +87,7 @@ class Launch:
 
 def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, Win=1, Hout=1, Wout=1, KH=1, KW=1,
               stride=1, pad_t=0, pad_l=0, ups=0, bias=None, rowvec=None, rows_per_sample=0, ldv=0, residual=None, ldr=0,
-              act=ACT_NONE, ldo=None, alpha=1.0, batch=1, sA=0, sW=0, sO=0, sR=0, ldw=0, name="rf_conv_gemm"):
+              act=ACT_NONE, ldo=None, alpha=1.0, batch=1, sA=0, sW=0, sO=0, sR=0, ldw=0, act_vec=None, name="rf_conv_gemm"):
     """Prepare an rf_conv_gemm launch (see include/reface_hip.h)."""
     lib = _lib.load()
     _require_gpu(src0, W, out, src1, bias, rowvec, residual)
@@ -106,10 +107,11 @@ def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, 
     d.residual, d.ldr, d.act = _p(residual), ldr, act
     d.out, d.ldo, d.alpha = _p(out), (ldo if ldo is not None else (N // 2 if act == ACT_GEGLU else N)), alpha
     d.batch, d.sA, d.sW, d.sO, d.sR = batch, sA, sW, sO, sR
-    return Launch(lib.rf_conv_gemm, (C.byref(d),), (d, src0, src1, W, out, bias, rowvec, residual), name)
+    d.act_vec = _p(act_vec)
+    return Launch(lib.rf_conv_gemm, (C.byref(d),), (d, src0, src1, W, out, bias, rowvec, residual, act_vec), name)
 
 
-def linear(x, W, out, bias=None, *, act=ACT_NONE, residual=None, rowvec=None, rows_per_sample=0, alpha=1.0, name="linear"):
+def linear(x, W, out, bias=None, *, act=ACT_NONE, residual=None, rowvec=None, rows_per_sample=0, alpha=1.0, act_vec=None, name="linear"):
     """out[M, N] = act(x[M, K] @ W[N, K]^T + bias) (+ residual).  x / out may be row-strided 2-D views."""
     M, K = x.shape
     N = W.shape[0]
@@ -117,11 +119,11 @@ def linear(x, W, out, bias=None, *, act=ACT_NONE, residual=None, rowvec=None, ro
     return conv_gemm(x, W, out, M=M, N=N, K=K, C0=K, ld0=x.stride(0), Hin=1, Win=M, Hout=1, Wout=M, bias=bias, act=act,
                      residual=residual, ldr=(residual.stride(0) if residual is not None else 0), rowvec=rowvec,
                      rows_per_sample=rows_per_sample, ldv=(rowvec.stride(0) if rowvec is not None else 0),
-                     ldo=out.stride(0), alpha=alpha, name=name)
+                     ldo=out.stride(0), alpha=alpha, act_vec=act_vec, name=name)
 
 
 def conv2d(x, W, out, bias=None, *, ksize=3, stride=1, pad=(1, 1), ups=0, x2=None, residual=None, rowvec=None,
-           act=ACT_NONE, name="conv2d"):
+           act=ACT_NONE, act_vec=None, name="conv2d"):
     """Channels-last convolution.  x: [B, Hin, Win, C0] (+ optional x2 [B, Hin, Win, C1] concatenated
     on channels); W: packed [Cout, k*k*(C0+C1)]; out: [B, Hout, Wout, Cout]."""
     B, Hin, Win, C0 = x.shape
@@ -133,7 +135,7 @@ def conv2d(x, W, out, bias=None, *, ksize=3, stride=1, pad=(1, 1), ups=0, x2=Non
                      ld1=(x2.stride(2) if x2 is not None else 0), Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, KH=ksize, KW=ksize,
                      stride=stride, pad_t=pad[0], pad_l=pad[1], ups=ups, bias=bias, residual=residual,
                      ldr=(residual.stride(2) if residual is not None else 0), rowvec=rowvec, rows_per_sample=Hout * Wout,
-                     ldv=(rowvec.stride(0) if rowvec is not None else 0), act=act, ldo=out.stride(2), name=name)
+                     ldv=(rowvec.stride(0) if rowvec is not None else 0), act=act, act_vec=act_vec, ldo=out.stride(2), name=name)
 
 
 GN_MAX_CHUNKS = 32
@@ -265,3 +267,76 @@ def run(launches, stream=None):
     s = stream if stream is not None else stream_ptr()
     for l in launches:
         l(s)
+
+
+# ------------------------------------------------------------------------------------------------
+# conditioning-encoder side kernels (reface_amd/csrc/encoder.hip)
+# ------------------------------------------------------------------------------------------------
+def channel_affine(x, a, b, out, slope=None, name="channel_affine"):
+    """out[..., c] = prelu(x[..., c] * a[c] + b[c]); x/out channels-last (any leading dims, uniform pixel pitch)."""
+    lib = _lib.load()
+    _require_gpu(x, a, b, out, slope)
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    return Launch(lib.rf_channel_affine, (code(x.dtype), _p(x), x.stride(-2), _p(a), _p(b), _p(slope), code(out.dtype), _p(out),
+                                          out.stride(-2), M, Cc), (x, a, b, slope, out), name)
+
+
+def spatial_mean(x, out, name="spatial_mean"):
+    lib = _lib.load()
+    _require_gpu(x, out)
+    B, H, W_, Cc = x.shape
+    assert out.dtype == torch.float32 and out.is_contiguous()
+    return Launch(lib.rf_spatial_mean, (code(x.dtype), _p(x), B, H * W_, Cc, x.stride(2), _p(out)), (x, out), name)
+
+
+def se_scale_add(r, s, shortcut, out, *, stride, name="se_scale_add"):
+    lib = _lib.load()
+    _require_gpu(r, s, shortcut, out)
+    B, Ho, Wo, Cc = r.shape
+    assert r.is_contiguous() and out.is_contiguous() and s.dtype == torch.float32 and shortcut.dtype == r.dtype
+    return Launch(lib.rf_se_scale_add, (code(r.dtype), _p(r), _p(s), _p(shortcut), shortcut.stride(2), shortcut.shape[1], shortcut.shape[2],
+                                        stride, _p(out), B, Ho, Wo, Cc), (r, s, shortcut, out), name)
+
+
+def adaptive_avgpool(x, out, *, crop=None, a=None, b=None, nhwc=False, name="adaptive_avgpool"):
+    """x: NCHW fp32; crop = (y0, x0, h, w) window (default full).  out: NCHW fp32 [B,C,Ho,Wo] or (nhwc) [B,Ho,Wo,Cpad]."""
+    lib = _lib.load()
+    _require_gpu(x, out, a, b)
+    B, Cc, Hf, Wf = x.shape
+    y0, x0, hc, wc = crop if crop is not None else (0, 0, Hf, Wf)
+    Ho, Wo = (out.shape[1], out.shape[2]) if nhwc else (out.shape[2], out.shape[3])
+    assert x.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
+    return Launch(lib.rf_adaptive_avgpool, (_p(x), B, Cc, Hf, Wf, y0, x0, hc, wc, _p(a), _p(b), Ho, Wo, int(nhwc), code(out.dtype),
+                                            out.shape[-1] if nhwc else Cc, _p(out)), (x, out, a, b), name)
+
+
+def bilinear_resize(x, out, a=None, b=None, name="bilinear_resize"):
+    lib = _lib.load()
+    _require_gpu(x, out, a, b)
+    B, Cc, Hi, Wi = x.shape
+    assert x.dtype == torch.float32 and out.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
+    return Launch(lib.rf_bilinear_resize, (_p(x), B, Cc, Hi, Wi, _p(a), _p(b), out.shape[2], out.shape[3], _p(out)), (x, out, a, b), name)
+
+
+def clip_tokens(patch, cls, pos, out, name="clip_tokens"):
+    lib = _lib.load()
+    _require_gpu(patch, cls, pos, out)
+    B, NP, Cc = patch.shape
+    assert patch.is_contiguous() and out.is_contiguous() and patch.dtype == out.dtype
+    return Launch(lib.rf_clip_tokens, (code(patch.dtype), _p(patch), _p(cls), _p(pos), _p(out), B, NP, Cc), (patch, cls, pos, out), name)
+
+
+def l2norm_rows(x, out, name="l2norm_rows"):
+    lib = _lib.load()
+    _require_gpu(x, out)
+    assert x.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
+    return Launch(lib.rf_l2norm_rows, (_p(x), _p(out), x.shape[0], x.shape[1]), (x, out), name)
+
+
+def combine3(a, b, c, out, *, wa, wb, wc, den, name="combine3"):
+    lib = _lib.load()
+    _require_gpu(a, b, c, out)
+    for t in (a, b, c, out):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    return Launch(lib.rf_combine3, (_p(a), _p(b), _p(c), float(wa), float(wb), float(wc), float(den), _p(out), a.numel()), (a, b, c, out), name)

@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Test-bench CLI of REFace on the MI355X-native engines.
+
+Same flags, loop and on-disk outputs as the reference's scripts/inference_test_bench.py:145-566:
+  <outdir>/results/<id>.png, <outdir>/grid/grid-<id>.png, <outdir>/samples/<id>_{mask,GT,inpaint,ref}.png
+Differences, all at the edges of the scope table:
+  * no module-import network access (the reference loads an HF safety checker it never calls);
+  * ``--dataset synthetic`` (seeded items of the dataset tensor contract) is available because no dataset is
+    reachable offline; CelebA / FFHQ / FF++ folder readers are the "next" row 8f.1;
+  * ``--ckpt none`` runs on seeded random weights (no checkpoint is reachable offline);
+  * ``--precision bf16`` selects the bf16 MFMA UNet (``full`` = exact-fp32 MFMA; ``autocast`` maps to bf16);
+  * one process per GPU under torch.distributed.run shards the pairs ``rank::world`` (weights broadcast once).
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from ldm.models.diffusion.ddim import DDIMSampler  # noqa: E402
+from ldm.util import instantiate_from_config  # noqa: E402
+from reface_amd import config as rcfg  # noqa: E402
+from reface_amd import ops  # noqa: E402
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--prompt", type=str, nargs="?", default="a photograph of an astronaut riding a horse")
+    p.add_argument("--device_ID", type=int, default=5)
+    p.add_argument("--outdir", type=str, nargs="?", default="results/debug")
+    p.add_argument("--skip_grid", action="store_true")
+    p.add_argument("--skip_save", action="store_true", help="do not save individual samples. For speed measurements.")
+    p.add_argument("--ddim_steps", type=int, default=50)
+    p.add_argument("--plms", action="store_true")
+    p.add_argument("--laion400m", action="store_true")
+    p.add_argument("--fixed_code", action="store_true")
+    p.add_argument("--Guidance", action="store_true")
+    p.add_argument("--Start_from_target", action="store_true")
+    p.add_argument("--target_start_noise_t", type=int, default=1000)
+    p.add_argument("--ddim_eta", type=float, default=0.0)
+    p.add_argument("--n_iter", type=int, default=2)
+    p.add_argument("--H", type=int, default=512)
+    p.add_argument("--W", type=int, default=512)
+    p.add_argument("--C", type=int, default=4)
+    p.add_argument("--f", type=int, default=8)
+    p.add_argument("--n_samples", type=int, default=5)
+    p.add_argument("--n_rows", type=int, default=0)
+    p.add_argument("--scale", type=float, default=5)
+    p.add_argument("--dataset", type=str, default="CelebA", help="CelebA | FFHQ | FF++ | synthetic")
+    p.add_argument("--dataset_dir", type=str, default="dataset/FaceData/CelebAMask-HQ")
+    p.add_argument("--from-file", type=str)
+    p.add_argument("--config", type=str, default="models/REFace/configs/project_ffhq.yaml")
+    p.add_argument("--ckpt", type=str, default="models/REFace/checkpoints/last.ckpt")
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--rank", type=int, default=0)
+    p.add_argument("--precision", type=str, choices=["full", "autocast", "bf16"], default="full")
+    # additions (not in the reference)
+    p.add_argument("--n_items", type=int, default=8, help="number of synthetic pairs (--dataset synthetic)")
+    p.add_argument("--clip_vision_config", type=str, default=None, help="JSON dict overriding the CLIP ViT dims (tests)")
+    return p
+
+
+def load_model_from_config(config, ckpt, verbose=False):
+    """inference_test_bench.py:96-113.  ``ckpt == 'none'``: seeded random weights of the same architecture."""
+    model = instantiate_from_config(config.model)
+    if ckpt and ckpt.lower() != "none":
+        print(f"Loading model from {ckpt}")
+        pl_sd = torch.load(ckpt, map_location="cpu")
+        if "global_step" in pl_sd:
+            print(f"Global Step: {pl_sd['global_step']}")
+        m, u = model.load_state_dict(pl_sd["state_dict"], strict=False)
+        if verbose:
+            print("missing keys:", m, "\nunexpected keys:", u)
+    else:
+        from reface_amd import params as P
+        sd = {}
+        unet, vae, clip = model.model.diffusion_model, model.first_stage_model, model.cond_stage_model
+        sd.update(P.seeded_state_dict(P.unet_param_specs(unet.cfg), 1234, "model.diffusion_model."))
+        sd.update(P.seeded_state_dict(P.vae_param_specs(vae.cfg), 55, "first_stage_model."))
+        sd.update(P.seeded_state_dict(P.clip_param_specs(clip.cfg), 88, "cond_stage_model."))
+        sd.update(P.seeded_state_dict(P.arcface_param_specs(), 77, "face_ID_model.facenet."))
+        sd.update(P.seeded_state_dict(P.cond_head_specs(), 9))
+        m, u = model.load_state_dict(sd, strict=False)
+        assert not u, u[:5]
+        print(f"[reface_amd] --ckpt none: seeded random weights ({len(sd)} tensors)")
+    model.cuda()
+    model.eval()
+    return model
+
+
+def save_png(arr_chw01, path):
+    from PIL import Image
+    img = (255.0 * arr_chw01.transpose(1, 2, 0)).astype(np.uint8)          # truncation, as inference_test_bench.py:536-537
+    Image.fromarray(img).save(path)
+
+
+def main(argv=None):
+    opt = build_parser().parse_args(argv)
+    print(opt)
+    if opt.plms or opt.laion400m or opt.Guidance:
+        raise NotImplementedError("--plms / --laion400m / --Guidance are outside the REFace DDIM hot path (SURVEY.md section 2)")
+    torch.manual_seed(opt.seed)
+    np.random.seed(opt.seed)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+
+    config = rcfg.load(opt.config)
+    if opt.clip_vision_config:
+        import json
+        config.model.params.cond_stage_config["params"] = {"vision_config": json.loads(opt.clip_vision_config)}
+    model = load_model_from_config(config, opt.ckpt)
+    device = torch.device("cuda")
+    model = model.to(device)
+    if opt.precision in ("autocast", "bf16"):
+        model.set_compute_dtype(torch.bfloat16)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, 0)
+    sampler = DDIMSampler(model)
+
+    outpath = opt.outdir
+    sample_path, result_path, grid_path = (os.path.join(outpath, d) for d in ("samples", "results", "grid"))
+    for d in (outpath, sample_path, result_path, grid_path):
+        os.makedirs(d, exist_ok=True)
+    batch_size = opt.n_samples
+
+    if opt.dataset == "synthetic":
+        from reface_amd.data import SyntheticPairs, shard_indices
+        full = SyntheticPairs(n=opt.n_items, image_size=opt.H, seed=opt.seed)
+        test_dataset = torch.utils.data.Subset(full, shard_indices(len(full), rank, world))
+    else:
+        raise NotImplementedError(f"--dataset {opt.dataset}: the CelebA/FFHQ/FF++ folder readers (ldm/data/test_bench_dataset.py) are the "
+                                  "'next' row 8f.1 of the scope table; use --dataset synthetic")
+    loader = torch.utils.data.DataLoader(test_dataset, batch_size=batch_size, num_workers=0, shuffle=False, drop_last=False)
+
+    start_code = None
+    if opt.fixed_code:
+        start_code = torch.randn([opt.n_samples, opt.C, opt.H // opt.f, opt.W // opt.f], device=device)
+
+    n_done, t_start = 0, time.time()
+    with torch.no_grad(), model.ema_scope():
+        for test_batch, prior, test_model_kwargs, segment_id_batch in loader:
+            if opt.Start_from_target:
+                raise NotImplementedError("--Start_from_target is the 'next' row 8f.4 of the scope table")
+            test_model_kwargs = {n: test_model_kwargs[n].to(device, non_blocking=True) for n in test_model_kwargs}
+            B = test_batch.shape[0]
+            uc = model.learnable_vector.repeat(B, 1, 1) if opt.scale != 1.0 else None
+            landmarks = model.get_landmarks(test_batch) if model.Landmark_cond else None
+            c = model.conditioning_with_feat(test_model_kwargs["ref_imgs"].squeeze(1).to(torch.float32), landmarks=landmarks,
+                                             tar=test_batch.to("cuda").to(torch.float32)).float()
+            if len(c.shape) == 2:
+                c = c.unsqueeze(1)
+            inpaint_image, inpaint_mask = test_model_kwargs["inpaint_image"], test_model_kwargs["inpaint_mask"]
+            z_inpaint = model.get_first_stage_encoding(model.encode_first_stage(inpaint_image)).detach()
+            test_model_kwargs["inpaint_image"] = z_inpaint
+            h = z_inpaint.shape[-1]
+            m64 = torch.empty((B, 1, h, h), dtype=torch.float32, device=device)
+            ops.bilinear_resize(inpaint_mask.float().contiguous(), m64)()     # torchvision Resize on a tensor (inference_test_bench.py:465)
+            test_model_kwargs["inpaint_mask"] = m64
+            shape = [opt.C, opt.H // opt.f, opt.W // opt.f]
+            x_T = None if start_code is None else start_code[:B]
+            samples_ddim, _ = sampler.sample(S=opt.ddim_steps, conditioning=c, batch_size=B, shape=shape, verbose=False,
+                                             unconditional_guidance_scale=opt.scale, unconditional_conditioning=uc, eta=opt.ddim_eta,
+                                             x_T=x_T, log_every_t=100, test_model_kwargs=test_model_kwargs)
+            x_dec = model.decode_first_stage(samples_ddim)
+            x_img = torch.empty_like(x_dec)
+            ops.to_image(x_dec, x_img)()
+            x_np = x_img.cpu().numpy()
+            n_done += B
+            if not opt.skip_save:
+                un = lambda t: np.clip((t.cpu().numpy() + 1.0) / 2.0, 0.0, 1.0)
+                gt, inp = un(test_batch), un(inpaint_image)
+                for i in range(B):
+                    sid = segment_id_batch[i]
+                    save_png(x_np[i], os.path.join(result_path, sid + ".png"))
+                    save_png(np.repeat(inpaint_mask[i].cpu().numpy(), 3, 0), os.path.join(sample_path, sid + "_mask.png"))
+                    save_png(gt[i], os.path.join(sample_path, sid + "_GT.png"))
+                    save_png(inp[i], os.path.join(sample_path, sid + "_inpaint.png"))
+                    if not opt.skip_grid:
+                        grid = np.concatenate([inp[i], gt[i], x_np[i]], axis=2)
+                        save_png(grid, os.path.join(grid_path, "grid-" + sid + ".png"))
+    torch.cuda.synchronize()
+    dt = time.time() - t_start
+    print(f"Your samples are ready and waiting for you here: \n{outpath} \n ({n_done} images on rank {rank} in {dt:.1f}s)\nEnjoy.")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return n_done
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,138 @@
+"""GPU parity of the conditioning encoders and of the WHOLE reference chain
+(scripts/inference_test_bench.py:441-495: landmarks -> conditioning_with_feat -> VAE encode + posterior sample ->
+DDIM (CFG 3.5) -> VAE decode -> clamp) against outputs of the reference itself (tests/golden), through the
+reference's own class / method surface built from a YAML registry config."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from reface_amd import params as P
+from reface_amd.params import seeded_randn as rnd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL_CLIP = dict(hidden=128, intermediate=512, layers=2, heads=4)
+
+
+def G(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def maxerr(a, b):
+    a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    return float(np.abs(a.astype(np.float64) - np.asarray(b).astype(np.float64)).max())
+
+
+def test_arcface_vs_reference_golden(golden_dir):
+    from reface_amd.encoders import Backbone
+    g = G(golden_dir, "arcface")
+    net = Backbone(input_size=112, num_layers=50, drop_ratio=0.6, mode="ir_se")
+    net.load_state_dict(P.seeded_state_dict(P.arcface_param_specs(), 77), strict=True)
+    net.to(DEV)
+    f112 = net(rnd((2, 3, 112, 112), 51).to(DEV))[0]
+    assert maxerr(f112, g["feats112"]) < 1e-5, maxerr(f112, g["feats112"])
+    f = net.forward_from_clip_image(rnd((2, 3, 224, 224), 50).to(DEV))[0]
+    assert maxerr(f, g["feats"]) < 1e-5, maxerr(f, g["feats"])
+    assert torch.allclose(f.norm(dim=1).cpu(), torch.ones(2), atol=1e-6)
+
+
+def test_clip_vs_reference_golden(golden_dir):
+    from reface_amd.encoders import FrozenCLIPEmbedder
+    g = G(golden_dir, "clip_small")
+    m = FrozenCLIPEmbedder(vision_config=SMALL_CLIP)
+    m.load_state_dict(P.seeded_state_dict(P.clip_param_specs(m.cfg), 88), strict=True)
+    m.to(DEV)
+    z = m.encode(rnd((2, 3, 224, 224), 60).to(DEV))
+    assert z.shape == (2, 1, 768)
+    assert maxerr(m._engine(2).pooled, g["pooled"]) < 5e-5
+    assert maxerr(z, g["z"]) < 5e-5, maxerr(z, g["z"])
+    g = G(golden_dir, "clip_l14_1layer")                      # full ViT-L/14 width (1024 / 16 heads / 257 tokens), 1 layer
+    m = FrozenCLIPEmbedder(vision_config=dict(layers=1))
+    m.load_state_dict(P.seeded_state_dict(P.clip_param_specs(m.cfg), 89), strict=True)
+    m.to(DEV)
+    z = m.encode(rnd((1, 3, 224, 224), 61).to(DEV))
+    assert maxerr(z, g["z"]) < 5e-5, maxerr(z, g["z"])
+
+
+def _small_pipeline():
+    from ldm.util import instantiate_from_config
+    from reface_amd import config as rcfg
+    cfg = rcfg.load(os.path.join(ROOT, "tests", "configs", "reface_small.yaml"))
+    cfg.model.params.cond_stage_config["params"] = {"vision_config": SMALL_CLIP}
+    model = instantiate_from_config(cfg.model)
+    sd = {}
+    sd.update(P.seeded_state_dict(P.unet_param_specs(model.model.diffusion_model.cfg), 7, "model.diffusion_model."))
+    sd.update(P.seeded_state_dict(P.vae_param_specs(model.first_stage_model.cfg), 55, "first_stage_model."))
+    sd.update(P.seeded_state_dict(P.clip_param_specs(model.cond_stage_model.cfg), 88, "cond_stage_model."))
+    # the fixture's ArcFace weights were seeded on the un-prefixed keys (they went through an arcface_path file)
+    sd.update({"face_ID_model.facenet." + k: v for k, v in P.seeded_state_dict(P.arcface_param_specs(), 77).items()})
+    sd.update(P.seeded_state_dict(P.cond_head_specs(), 9))
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected
+    model.cuda()
+    model.eval()
+    return model
+
+
+def test_whole_chain_vs_reference_golden(golden_dir):
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from reface_amd import ops
+    g = G(golden_dir, "e2e_small")
+    model = _small_pipeline()
+    B, H = 2, 256
+    target = torch.tanh(rnd((B, 3, H, H), 70))
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(H), indexing="ij")
+    ell = (((yy - H / 2) / (0.30 * H)) ** 2 + ((xx - H / 2) / (0.38 * H)) ** 2) <= 1.0
+    inpaint_mask = (~ell).float()[None, None].repeat(B, 1, 1, 1)
+    inpaint_image = target * inpaint_mask
+    ref = rnd((B, 3, 224, 224), 71)
+    x_T = rnd((B, 4, H // 8, H // 8), 72)
+
+    sampler = DDIMSampler(model)
+    uc = model.learnable_vector.repeat(B, 1, 1)
+    assert maxerr(uc, g["uc"]) == 0
+    landmarks = model.get_landmarks(target)                    # no dlib here -> the no-face branch, as in the fixture
+    assert maxerr(landmarks, g["landmarks"]) < 1e-6
+    c = model.conditioning_with_feat(ref.to(DEV), landmarks=landmarks, tar=target.to(DEV)).float()
+    assert c.shape == (B, 1, 768)
+    assert maxerr(c, g["c"]) < 5e-5, maxerr(c, g["c"])
+    post = model.encode_first_stage(inpaint_image.to(DEV))
+    assert maxerr(post.mean, g["post_mean"]) < 1e-4 and maxerr(post.logvar, g["post_logvar"]) < 1e-4
+    z_inpaint = model.get_first_stage_encoding(post, noise=torch.from_numpy(g["eps"]))
+    assert maxerr(z_inpaint, g["z_inpaint"]) < 5e-5
+    m64 = torch.empty((B, 1, H // 8, H // 8), dtype=torch.float32, device=DEV)
+    ops.bilinear_resize(inpaint_mask.to(DEV), m64)()
+    assert maxerr(m64, g["mask64"]) == 0
+    samples, _ = sampler.sample(S=5, conditioning=c, batch_size=B, shape=[4, H // 8, H // 8], verbose=False,
+                                unconditional_guidance_scale=3.5, unconditional_conditioning=uc, eta=0.0, x_T=x_T.to(DEV),
+                                test_model_kwargs={"inpaint_image": z_inpaint, "inpaint_mask": m64})
+    assert maxerr(samples, g["samples"]) < 3e-4, maxerr(samples, g["samples"])
+    x_dec = model.decode_first_stage(samples)
+    e = maxerr(x_dec, g["x_dec"])
+    assert e < 1e-3, e                                        # the north-star pixel bound (images are in [-1, 1] here)
+    img = torch.empty_like(x_dec)
+    ops.to_image(x_dec, img)()
+    u8 = (255.0 * img.permute(0, 2, 3, 1).cpu().numpy()).astype(np.uint8)
+    assert (np.abs(u8.astype(int) - g["u8"].astype(int)) <= 1).all() and (u8 != g["u8"]).mean() < 2e-3
+
+
+def test_cli_synthetic_run(tmp_path):
+    """scripts/inference_test_bench.py end to end on seeded weights: writes the reference's output tree."""
+    import json
+    out = tmp_path / "out"
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "inference_test_bench.py"), "--outdir", str(out), "--config",
+           os.path.join(ROOT, "tests", "configs", "reface_small.yaml"), "--ckpt", "none", "--dataset", "synthetic", "--n_items", "3",
+           "--n_samples", "2", "--ddim_steps", "5", "--scale", "3.5", "--H", "256", "--W", "256", "--clip_vision_config", json.dumps(SMALL_CLIP)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    res = sorted(os.listdir(out / "results"))
+    assert res == ["000000000000.png", "000000000001.png", "000000000002.png"]
+    assert len(os.listdir(out / "grid")) == 3 and len(os.listdir(out / "samples")) == 9
+    from PIL import Image
+    im = np.asarray(Image.open(out / "results" / res[0]))
+    assert im.shape == (256, 256, 3) and im.std() > 1.0
