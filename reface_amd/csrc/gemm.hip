@@ -34,6 +34,7 @@ struct GemmParams {
     float alpha;
     long long sA, sW, sO, sR;
     int tiles_m, tiles_n;
+    int vec_ok;      // epilogue may use 16-byte (fp32) / 8-byte (bf16) vector accesses
 };
 
 template <typename T> struct MmaFrag;
@@ -211,49 +212,123 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         __syncthreads();
     }
 
-    // ---- epilogue
+    // ---- epilogue: accumulators -> LDS (fp32 [BM][BN]) -> coalesced 16-byte row segments.
+    // (the main loop ended on a barrier, so the operand tiles are dead and the LDS can be reused)
+    float* const stage = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                stage[rl * BN + (wn * TN + j) * 32 + lrow] = acc[i][j][r];
+            }
+    __syncthreads();
     TO* outp = (TO*)p.out + zb * p.sO;
     const TO* resp = p.residual ? (const TO*)p.residual + zb * p.sR : nullptr;
-    const bool geglu = p.act == RF_ACT_GEGLU;
+    if (p.act == RF_ACT_GEGLU) {
+        constexpr int OV = BN / 8;                      // output 4-column vectors per row (N/2 columns)
+        for (int idx = tid; idx < BM * OV; idx += NT) {
+            const int rl = idx / OV, oc = (idx - rl * OV) * 4;
+            const int row = m0 + rl;
+            const int lv = (oc >> 5) * 64 + (oc & 31), lg = lv + 32;      // local value / gate columns
+            const int ocol = (n0 >> 1) + oc;
+            if (row >= p.M || n0 + lg >= p.N) continue;
+            const f32x4_t a4 = *(const f32x4_t*)(stage + rl * BN + lv);
+            const f32x4_t g4 = *(const f32x4_t*)(stage + rl * BN + lg);
+            float v[4];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-            if (row >= p.M) continue;
-            const float* rv = p.rowvec ? p.rowvec + (long long)(row / p.rows_per_sample) * p.ldv : nullptr;
-            if (geglu) {
-                if constexpr (TN % 2 == 0) {
-#pragma unroll
-                    for (int j = 0; j < TN; j += 2) {
-                        const int cv_ = n0 + (wn * TN + j) * 32 + lrow;      // packed column of the value half
-                        const int cg_ = cv_ + 32;
-                        if (cg_ >= p.N) continue;
-                        float a_ = acc[i][j][r] * p.alpha, g_ = acc[i][j + 1][r] * p.alpha;
-                        if (p.bias) { a_ += p.bias[cv_]; g_ += p.bias[cg_]; }
-                        const int oc = ((n0 + (wn * TN + j) * 32) >> 1) + lrow;
-                        float v = a_ * gelu_erf(g_);
-                        if (resp) v += load_out<TO>(resp + (long long)row * p.ldr + oc);
-                        store_out<TO>(outp + (long long)row * p.ldo + oc, v);
+            for (int e = 0; e < 4; ++e) {
+                float a_ = a4[e] * p.alpha, g_ = g4[e] * p.alpha;
+                if (p.bias) { a_ += p.bias[n0 + lv + e]; g_ += p.bias[n0 + lg + e]; }
+                v[e] = a_ * gelu_erf(g_);
+            }
+            TO* dst = outp + (long long)row * p.ldo + ocol;
+            if (p.vec_ok) {
+                if (resp) {
+                    float rr[4];
+                    if constexpr (sizeof(TO) == 2) {
+                        const u32x2_t q = *(const u32x2_t*)(resp + (long long)row * p.ldr + ocol);
+                        rr[0] = as_f32(q[0] << 16); rr[1] = as_f32(q[0] & 0xffff0000u); rr[2] = as_f32(q[1] << 16); rr[3] = as_f32(q[1] & 0xffff0000u);
+                    } else {
+                        const f32x4_t q = *(const f32x4_t*)(resp + (long long)row * p.ldr + ocol);
+                        rr[0] = q[0]; rr[1] = q[1]; rr[2] = q[2]; rr[3] = q[3];
                     }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rr[e];
+                }
+                if constexpr (sizeof(TO) == 2) {
+                    u32x2_t w; w[0] = pack_bf2(v[0], v[1]); w[1] = pack_bf2(v[2], v[3]);
+                    *(u32x2_t*)dst = w;
+                } else {
+                    *(f32x4_t*)dst = f32x4_t{v[0], v[1], v[2], v[3]};
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int col = n0 + (wn * TN + j) * 32 + lrow;
-                    if (col >= p.N) continue;
-                    float v = acc[i][j][r] * p.alpha;
-                    if (p.bias) v += p.bias[col];
-                    if (rv) v += rv[col];
-                    if (p.act == RF_ACT_SILU) v = silu_exact(v);
-                    else if (p.act == RF_ACT_QUICK_GELU) v = quick_gelu(v);
-                    else if (p.act == RF_ACT_GELU) v = gelu_erf(v);
-                    else if (p.act == RF_ACT_RELU) v = fmaxf(v, 0.0f);
-                    else if (p.act == RF_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
-                    else if (p.act == RF_ACT_PRELU) v = v >= 0.0f ? v : v * p.act_vec[col];
-                    if (resp) v += load_out<TO>(resp + (long long)row * p.ldr + col);
-                    store_out<TO>(outp + (long long)row * p.ldo + col, v);
+                for (int e = 0; e < 4; ++e) {
+                    float y = v[e];
+                    if (resp) y += load_out<TO>(resp + (long long)row * p.ldr + ocol + e);
+                    store_out<TO>(dst + e, y);
                 }
+            }
+        }
+    } else {
+        constexpr int VPR = BN / 4;
+        for (int idx = tid; idx < BM * VPR; idx += NT) {
+            const int rl = idx / VPR, cl = (idx - rl * VPR) * 4;
+            const int row = m0 + rl, col = n0 + cl;
+            if (row >= p.M || col >= p.N) continue;
+            const f32x4_t a4 = *(const f32x4_t*)(stage + rl * BN + cl);
+            float v[4] = {a4[0] * p.alpha, a4[1] * p.alpha, a4[2] * p.alpha, a4[3] * p.alpha};
+            const float* rv = p.rowvec ? p.rowvec + (long long)(row / p.rows_per_sample) * p.ldv : nullptr;
+            const bool full = p.vec_ok && col + 3 < p.N;
+            if (full) {
+                if (p.bias) { const f32x4_t b4 = *(const f32x4_t*)(p.bias + col); v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3]; }
+                if (rv) { const f32x4_t r4 = *(const f32x4_t*)(rv + col); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < p.N) { if (p.bias) v[e] += p.bias[col + e]; if (rv) v[e] += rv[col + e]; }
+            }
+            if (p.act != RF_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float y = v[e];
+                    if (p.act == RF_ACT_SILU) y = silu_exact(y);
+                    else if (p.act == RF_ACT_QUICK_GELU) y = quick_gelu(y);
+                    else if (p.act == RF_ACT_GELU) y = gelu_erf(y);
+                    else if (p.act == RF_ACT_RELU) y = fmaxf(y, 0.0f);
+                    else if (p.act == RF_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
+                    else if (p.act == RF_ACT_PRELU) y = y >= 0.0f ? y : y * p.act_vec[min(col + e, p.N - 1)];
+                    v[e] = y;
+                }
+            }
+            TO* dst = outp + (long long)row * p.ldo + col;
+            if (full) {
+                if (resp) {
+                    if constexpr (sizeof(TO) == 2) {
+                        const u32x2_t q = *(const u32x2_t*)(resp + (long long)row * p.ldr + col);
+                        v[0] += as_f32(q[0] << 16); v[1] += as_f32(q[0] & 0xffff0000u); v[2] += as_f32(q[1] << 16); v[3] += as_f32(q[1] & 0xffff0000u);
+                    } else {
+                        const f32x4_t q = *(const f32x4_t*)(resp + (long long)row * p.ldr + col);
+                        v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
+                    }
+                }
+                if constexpr (sizeof(TO) == 2) {
+                    u32x2_t w; w[0] = pack_bf2(v[0], v[1]); w[1] = pack_bf2(v[2], v[3]);
+                    *(u32x2_t*)dst = w;
+                } else {
+                    *(f32x4_t*)dst = f32x4_t{v[0], v[1], v[2], v[3]};
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < p.N) {
+                        float y = v[e];
+                        if (resp) y += load_out<TO>(resp + (long long)row * p.ldr + col + e);
+                        store_out<TO>(dst + e, y);
+                    }
             }
         }
     }
@@ -262,7 +337,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 template <typename T, typename TO, int WM, int WN, int TM, int TN>
 static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr int smem = 2 * (BM + BN) * 128;
+    constexpr int smem_ml = 2 * (BM + BN) * 128, smem_ep = BM * BN * 4;
+    constexpr int smem = smem_ml > smem_ep ? smem_ml : smem_ep;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     dim3 grid(p.tiles_m * p.tiles_n, d->batch, 1), block(WM * WN * 64);
@@ -326,6 +402,15 @@ extern "C" int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream) {
     p.W = d->W; p.ldw = d->ldw > 0 ? d->ldw : d->K; p.bias = d->bias; p.rowvec = d->rowvec; p.rows_per_sample = d->rows_per_sample; p.ldv = d->ldv;
     p.residual = d->residual; p.ldr = d->ldr; p.act = d->act; p.act_vec = d->act_vec; p.out = d->out; p.ldo = d->ldo; p.alpha = d->alpha;
     p.sA = d->sA; p.sW = d->sW; p.sO = d->sO; p.sR = d->sR;
+    {
+        const uintptr_t oa = d->out_dtype == RF_F32 ? 16 : 8;
+        const int nout = d->act == RF_ACT_GEGLU ? d->N / 2 : d->N;
+        bool ok = (d->N % 4 == 0) && (nout % 4 == 0) && (d->ldo % 4 == 0) && ((uintptr_t)d->out % oa == 0) && (d->sO % 4 == 0);
+        if (d->residual) ok = ok && (d->ldr % 4 == 0) && ((uintptr_t)d->residual % oa == 0) && (d->sR % 4 == 0);
+        if (d->bias) ok = ok && ((uintptr_t)d->bias % 16 == 0);
+        if (d->rowvec) ok = ok && (d->ldv % 4 == 0) && ((uintptr_t)d->rowvec % 16 == 0);
+        p.vec_ok = ok ? 1 : 0;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == RF_F32) {
         if (d->out_dtype == RF_F32) return launch_typed<float, float>(d, p, conv, st);

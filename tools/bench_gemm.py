@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of rf_conv_gemm / rf_attention / norms on the UNet's representative shapes (CFG batch 16, 512x512 images).
+Usage: python tools/bench_gemm.py [--dtype bf16|f32] [--only substr] [--reps N] [--json out.json]"""
+import argparse
+import json
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from reface_amd import ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--only", default="")
+ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--bc", type=int, default=16)
+ap.add_argument("--json", default=None)
+args = ap.parse_args()
+dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+dev = "cuda"
+Bc = args.bc
+
+
+def r(*shape, scale=1.0, dtype=None):
+    return (torch.randn(*shape, device=dev) * scale).to(dtype or dt)
+
+
+cases = []
+
+
+def conv(name, cin, cout, hw, *, c1=0, stride=1, ups=0):
+    hin = hw // 2 if ups else hw
+    ho = hw // stride
+    x = r(Bc, hin, hin, cin)
+    x2 = r(Bc, hin, hin, c1) if c1 else None
+    w = r(cout, 9 * (cin + c1), scale=1 / math.sqrt(9 * (cin + c1)))
+    out = torch.empty(Bc, ho, ho, cout, device=dev, dtype=dt)
+    res = r(Bc, ho, ho, cout)
+    b = r(cout, dtype=torch.float32)
+    l = ops.conv2d(x, w, out, b, stride=stride, ups=ups, x2=x2, residual=res, name=name)
+    cases.append((name, l, 2.0 * Bc * ho * ho * cout * 9 * (cin + c1)))
+
+
+def lin(name, M, N, K, act=ops.ACT_NONE):
+    x = r(M, K)
+    w = r(N, K, scale=1 / math.sqrt(K))
+    b = r(N, dtype=torch.float32)
+    out = torch.empty(M, N // 2 if act == ops.ACT_GEGLU else N, device=dev, dtype=dt)
+    cases.append((name, ops.linear(x, w, out, b, act=act, name=name), 2.0 * M * N * K))
+
+
+def attn(name, heads, d, N):
+    c = heads * d
+    qkv = r(Bc, N, 3 * c)
+    out = torch.empty(Bc, N, c, device=dev, dtype=dt)
+    cases.append((name, ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], out, heads=heads, scale=d ** -0.5, name=name),
+                  4.0 * Bc * heads * N * N * d))
+
+
+def gn(name, c, hw):
+    x = r(Bc, hw, hw, c)
+    out = torch.empty_like(x)
+    part = torch.empty(Bc * ops.GN_MAX_CHUNKS * 64, dtype=torch.float64, device=dev)
+    g, b = r(c, dtype=torch.float32), r(c, dtype=torch.float32)
+    a, bb = ops.groupnorm(x, g, b, out, part, eps=1e-5, silu=True, name=name)
+    nbytes = x.numel() * x.element_size()
+    cases.append((name + ".stats", a, -float(nbytes)))
+    cases.append((name + ".apply", bb, -2.0 * nbytes))
+
+
+def ln(name, M, c):
+    x = r(M, c)
+    out = torch.empty_like(x)
+    g, b = r(c, dtype=torch.float32), r(c, dtype=torch.float32)
+    cases.append((name, ops.layernorm(x, g, b, out, name=name), -2.0 * x.numel() * x.element_size()))
+
+
+conv("conv3x3 320->320 @64", 320, 320, 64)
+conv("conv3x3 640->640 @32", 640, 640, 32)
+conv("conv3x3 1280->1280 @16", 1280, 1280, 16)
+conv("conv3x3 1280->1280 @8", 1280, 1280, 8)
+conv("conv3x3 cat2560->1280 @8", 1280, 1280, 8, c1=1280)
+conv("conv3x3 cat1920->640 @32", 1280, 640, 32, c1=640)
+conv("conv3x3 cat960->320 @64", 640, 320, 64, c1=320)
+conv("conv3x3 cat640->320 @64", 320, 320, 64, c1=320)
+conv("down 320 @64->32", 320, 320, 64, stride=2)
+conv("up 640 @32->64", 640, 640, 64, ups=1)
+lin("geglu 320->2560 @64", Bc * 4096, 2560, 320, ops.ACT_GEGLU)
+lin("ff2 1280->320 @64", Bc * 4096, 320, 1280)
+lin("qkv 320->960 @64", Bc * 4096, 960, 320)
+lin("proj 320->320 @64", Bc * 4096, 320, 320)
+lin("geglu 640->5120 @32", Bc * 1024, 5120, 640, ops.ACT_GEGLU)
+lin("ff2 2560->640 @32", Bc * 1024, 640, 2560)
+lin("geglu 1280->10240 @16", Bc * 256, 10240, 1280, ops.ACT_GEGLU)
+lin("ff2 5120->1280 @16", Bc * 256, 1280, 5120)
+lin("skip1x1 2560->1280 @8", Bc * 64, 1280, 2560)
+attn("attn d40 N4096", 8, 40, 4096)
+attn("attn d80 N1024", 8, 80, 1024)
+attn("attn d160 N256", 8, 160, 256)
+attn("attn d160 N64", 8, 160, 64)
+gn("gn 320 @64", 320, 64)
+gn("gn 640 @64", 640, 64)
+gn("gn 1280 @16", 1280, 16)
+ln("ln 320 @64", Bc * 4096, 320)
+
+results = []
+stream = torch.cuda.current_stream()
+for name, l, work in cases:
+    if args.only and args.only not in name:
+        continue
+    for _ in range(3):
+        l()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record(stream)
+    for _ in range(args.reps):
+        l()
+    e.record(stream)
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) / args.reps * 1e3
+    if work > 0:
+        rate, unit = work / us / 1e6, "TFLOP/s"
+    else:
+        rate, unit = -work / us / 1e3, "GB/s"
+    results.append(dict(name=name, us=us, rate=rate, unit=unit))
+    print(f"{name:32s} {us:10.1f} us  {rate:9.1f} {unit}", flush=True)
+if args.json:
+    json.dump(results, open(args.json, "w"), indent=1)
