@@ -34,6 +34,8 @@ struct GemmParams {
     float alpha;
     long long sA, sW, sO, sR;
     int tiles_m, tiles_n;
+    unsigned a_bytes, w_bytes;   // extents of src0 / W (per batch element) for the buffer descriptors
+    int glds;        // use the direct-to-LDS main loop
     int vec_ok;      // epilogue may use 16-byte (fp32) / 8-byte (bf16) vector accesses
 };
 
@@ -60,7 +62,7 @@ template <typename TO> __device__ __forceinline__ float load_out(const TO* p);
 template <> __device__ __forceinline__ float load_out<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float load_out<bf16_t>(const bf16_t* p) { return bf2f(*p); }
 
-template <typename T, typename TO, int WM, int WN, int TM, int TN, bool CONV>
+template <typename T, typename TO, int WM, int WN, int TM, int TN, bool CONV, bool GLDS>
 __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = 32 * TM * WM;
@@ -97,8 +99,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
     const T* src1 = (const T*)p.src1;
     const T* Wp = (const T*)p.W + zb * p.sW;
 
-    const int slot = tid & 7;
     const int r0 = tid >> 3;
+    // GLDS: the LDS image of a direct-to-LDS load is lane-linear, so the XOR swizzle moves to the SOURCE: the lane that
+    // lands on 16-byte position p of row r fetches k-slot p ^ ((r >> 1) & 7)  (r0 + 32*i keeps (r >> 1) & 7 for every i)
+    const int slot = GLDS ? ((tid & 7) ^ ((r0 >> 1) & 7)) : (tid & 7);
 
     // ---- per-thread A row descriptors
     int a_pix[AV];     // CONV: b*Hin*Win ; plain: row index (or -1 invalid)
@@ -185,14 +189,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int nk = (p.K + BK - 1) / BK;
-    load_tiles();
-    store_tiles(0);
-    __syncthreads();
-
     const int lrow = lane & 31, lhalf = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles();
+
+    auto compute_tile = [&](int buf) {
         const char* a = ldsA + buf * BM * 128;
         const char* b = ldsB + buf * BN * 128;
 #pragma unroll
@@ -208,8 +207,69 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
                 for (int j = 0; j < TN; ++j) MmaFrag<T>::mma(acc[i][j], fa[i], fb[j]);
         }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
+    };
+
+    if constexpr (GLDS) {
+        // direct global -> LDS staging (buffer_load_dwordx4 ... lds): out-of-range byte offsets return zeros, which gives the
+        // conv zero padding / M, N, K tails for free.  Tile kt+1 streams in while tile kt is on the matrix cores.
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)src0, 0, p.a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, p.w_bytes, 0x00020000);
+        constexpr int OOB = 0x7fffffff;
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        auto issue_tiles = [&](int buf) {
+            const bool kval = kvec < p.K;
+            char* a = ldsA + buf * BM * 128 + wave_u * 1024;
+            char* b = ldsB + buf * BN * 128 + wave_u * 1024;
+#pragma unroll
+            for (int i = 0; i < AV; ++i) {
+                int off = OOB;
+                if (CONV) {
+                    int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+                    const bool ok = kval && a_pix[i] >= 0 && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+                    if (ok) {
+                        if (p.ups) { iy >>= 1; ix >>= 1; }
+                        off = ((a_pix[i] + iy * p.Win + ix) * p.ld0 + cv) * (int)sizeof(T);
+                    }
+                } else {
+                    if (kval && a_pix[i] >= 0) off = (a_pix[i] * p.ld0 + kvec) * (int)sizeof(T);
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(a + i * (RPP * 128)), 16, off, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < BV; ++j) {
+                const int n = n0 + r0 + j * RPP;
+                const int off = (kval && n < p.N) ? (n * p.ldw + kvec) * (int)sizeof(T) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(b + j * (RPP * 128)), 16, off, 0, 0, 0);
+            }
+            kvec += BK;
+            if (CONV) {
+                cv += BK;
+                while (cv >= p.Ctot) {
+                    cv -= p.Ctot;
+                    if (++kx == p.KW) { kx = 0; ++ky; }
+                }
+            }
+        };
+        issue_tiles(0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // tile kt landed for every wave; every wave is done reading tile kt-1
+            if (kt + 1 < nk) issue_tiles(buf ^ 1);
+            compute_tile(buf);
+        }
         __syncthreads();
+    } else {
+        load_tiles();
+        store_tiles(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load_tiles();
+            compute_tile(buf);
+            if (kt + 1 < nk) store_tiles(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: accumulators -> LDS (fp32 [BM][BN]) -> coalesced 16-byte row segments.
@@ -342,17 +402,18 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     dim3 grid(p.tiles_m * p.tiles_n, d->batch, 1), block(WM * WN * 64);
-    if (conv) {
-        auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, true>;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
-        hipLaunchKernelGGL(k, grid, block, smem, st, p);
-    } else {
-        auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, false>;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
-        hipLaunchKernelGGL(k, grid, block, smem, st, p);
+#define RF_LAUNCH_VARIANT(CONV_, GLDS_)                                                                                         \
+    {                                                                                                                            \
+        auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_>;                                                          \
+        static bool attr = false;                                                                                                \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; } \
+        hipLaunchKernelGGL(k, grid, block, smem, st, p);                                                                         \
     }
+    if (conv && p.glds) RF_LAUNCH_VARIANT(true, true)
+    else if (conv) RF_LAUNCH_VARIANT(true, false)
+    else if (p.glds) RF_LAUNCH_VARIANT(false, true)
+    else RF_LAUNCH_VARIANT(false, false)
+#undef RF_LAUNCH_VARIANT
     RF_LAUNCH_CHECK("rf_conv_gemm");
     return 0;
 }
@@ -410,6 +471,16 @@ extern "C" int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream) {
         if (d->bias) ok = ok && ((uintptr_t)d->bias % 16 == 0);
         if (d->rowvec) ok = ok && (d->ldv % 4 == 0) && ((uintptr_t)d->rowvec % 16 == 0);
         p.vec_ok = ok ? 1 : 0;
+    }
+    {
+        // direct-to-LDS main loop needs one source and 31-bit byte offsets
+        const long long es = d->dtype == RF_F32 ? 4 : 2;
+        const long long rows_a = conv ? (long long)(d->M / (d->Hout * d->Wout)) * d->Hin * d->Win : d->M;
+        const long long ab = ((rows_a - 1) * d->ld0 + (conv ? d->C0 : d->K)) * es;
+        const long long wb = ((long long)(d->N - 1) * p.ldw + d->K) * es;
+        p.glds = (d->C1 == 0 && ab < 0x7fff0000LL && wb < 0x7fff0000LL) ? 1 : 0;
+        p.a_bytes = (unsigned)(p.glds ? ab : 0);
+        p.w_bytes = (unsigned)(p.glds ? wb : 0);
     }
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == RF_F32) {
