@@ -76,6 +76,8 @@ typedef struct rf_conv_gemm_desc {
     int32_t batch;        /* >= 1 */
     int64_t sA, sW, sO, sR;   /* batch strides (elements) of src0, W, out, residual */
     const float* act_vec; /* [N] fp32 per-column activation parameter (PReLU slopes) or NULL */
+    int32_t korder;       /* 0: k = tap*(C0+C1) + c.  1: k = ((c / BK)*KH*KW + tap)*BK + c % BK with BK = 64 (bf16) / 32 (fp32):
+                             the taps of one channel chunk are consecutive K-tiles (input rows stay L1/L2-resident) */
 } rf_conv_gemm_desc;
 
 int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream);

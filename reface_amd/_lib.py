@@ -29,7 +29,7 @@ class ConvGemmDesc(C.Structure):
         ("out", C.c_void_p), ("ldo", C.c_int32), ("alpha", C.c_float),
         ("batch", C.c_int32),
         ("sA", C.c_int64), ("sW", C.c_int64), ("sO", C.c_int64), ("sR", C.c_int64),
-        ("act_vec", C.c_void_p),
+        ("act_vec", C.c_void_p), ("korder", C.c_int32),
     ]
 
 

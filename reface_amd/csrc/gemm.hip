@@ -36,6 +36,7 @@ struct GemmParams {
     int tiles_m, tiles_n;
     unsigned a_bytes, w_bytes;   // extents of src0 / W (per batch element) for the buffer descriptors
     int glds;        // use the direct-to-LDS main loop
+    int korder;      // 1: K is ordered (channel chunk of BK, tap, channel-in-chunk) instead of (tap, channel)
     int vec_ok;      // epilogue may use 16-byte (fp32) / 8-byte (bf16) vector accesses
 };
 
@@ -62,7 +63,7 @@ template <typename TO> __device__ __forceinline__ float load_out(const TO* p);
 template <> __device__ __forceinline__ float load_out<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float load_out<bf16_t>(const bf16_t* p) { return bf2f(*p); }
 
-template <typename T, typename TO, int WM, int WN, int TM, int TN, bool CONV, bool GLDS>
+template <typename T, typename TO, int WM, int WN, int TM, int TN, bool CONV, bool GLDS, int NST>
 __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = 32 * TM * WM;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ldsA = smem;                       // [2][BM][128]
-    char* const ldsB = smem + 2 * BM * 128;        // [2][BN][128]
+    char* const ldsB = smem + NST * BM * 128;      // [NST][BN][128]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -133,6 +134,22 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
     }
     const int Hv = p.ups ? p.Hin * 2 : p.Hin, Wv = p.ups ? p.Win * 2 : p.Win;
 
+    // advance this thread's K position to the next K tile
+    auto advance_k = [&]() {
+        kvec += BK;
+        if (CONV) {
+            if (p.korder) {       // channel-chunk-major K: the KH*KW taps of one BK-channel chunk are consecutive tiles
+                if (++kx == p.KW) { kx = 0; if (++ky == p.KH) { ky = 0; cv += BK; } }
+            } else {
+                cv += BK;
+                while (cv >= p.Ctot) {
+                    cv -= p.Ctot;
+                    if (++kx == p.KW) { kx = 0; ++ky; }
+                }
+            }
+        }
+    };
+
     u32x4_t ra[AV], rb[BV];
 
     auto load_tiles = [&]() {
@@ -162,14 +179,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             rb[j] = v;
         }
         // advance to the next K tile
-        kvec += BK;
-        if (CONV) {
-            cv += BK;
-            while (cv >= p.Ctot) {
-                cv -= p.Ctot;
-                if (++kx == p.KW) { kx = 0; ++ky; }
-            }
-        }
+        advance_k();
     };
     auto store_tiles = [&](int buf) {
         char* a = ldsA + buf * BM * 128;
@@ -241,21 +251,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 const int off = (kval && n < p.N) ? (n * p.ldw + kvec) * (int)sizeof(T) : OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(b + j * (RPP * 128)), 16, off, 0, 0, 0);
             }
-            kvec += BK;
-            if (CONV) {
-                cv += BK;
-                while (cv >= p.Ctot) {
-                    cv -= p.Ctot;
-                    if (++kx == p.KW) { kx = 0; ++ky; }
-                }
-            }
+            advance_k();
         };
-        issue_tiles(0);
+        // NST-deep ring: tiles kt+1 .. kt+NST-1 are in flight while tile kt is on the matrix cores
+#pragma unroll
+        for (int st = 0; st < NST - 1; ++st)
+            if (st < nk) issue_tiles(st);
         for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int buf = kt % NST;
+            // wait until tile kt has landed: at most the NST-2 younger tiles of this wave may stay in flight
+            if (kt + NST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (AV + BV)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();          // tile kt landed for every wave; every wave is done reading tile kt-1
-            if (kt + 1 < nk) issue_tiles(buf ^ 1);
+            if (kt + NST - 1 < nk) issue_tiles((kt + NST - 1) % NST);
             compute_tile(buf);
         }
         __syncthreads();
@@ -272,26 +280,32 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         }
     }
 
-    // ---- epilogue: accumulators -> LDS (fp32 [BM][BN]) -> coalesced 16-byte row segments.
+    // ---- epilogue: accumulators -> LDS (fp32 [ER][BN]) -> coalesced 16-byte row segments, in NCH row chunks
     // (the main loop ended on a barrier, so the operand tiles are dead and the LDS can be reused)
+    constexpr int NCH = (BM * BN * 4 > 96 * 1024) ? WM : 1;      // big tiles: one chunk per wave row
+    constexpr int ER = BM / NCH;
     float* const stage = (float*)smem;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                stage[rl * BN + (wn * TN + j) * 32 + lrow] = acc[i][j][r];
-            }
-    __syncthreads();
     TO* outp = (TO*)p.out + zb * p.sO;
     const TO* resp = p.residual ? (const TO*)p.residual + zb * p.sR : nullptr;
+    for (int ch = 0; ch < NCH; ++ch) {
+    if (NCH == 1 || wm == ch) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = ((NCH == 1 ? wm * TM : 0) + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                    stage[rl * BN + (wn * TN + j) * 32 + lrow] = acc[i][j][r];
+                }
+    }
+    __syncthreads();
+    const int mch = m0 + ch * ER;
     if (p.act == RF_ACT_GEGLU) {
         constexpr int OV = BN / 8;                      // output 4-column vectors per row (N/2 columns)
-        for (int idx = tid; idx < BM * OV; idx += NT) {
+        for (int idx = tid; idx < ER * OV; idx += NT) {
             const int rl = idx / OV, oc = (idx - rl * OV) * 4;
-            const int row = m0 + rl;
+            const int row = mch + rl;
             const int lv = (oc >> 5) * 64 + (oc & 31), lg = lv + 32;      // local value / gate columns
             const int ocol = (n0 >> 1) + oc;
             if (row >= p.M || n0 + lg >= p.N) continue;
@@ -335,9 +349,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         }
     } else {
         constexpr int VPR = BN / 4;
-        for (int idx = tid; idx < BM * VPR; idx += NT) {
+        for (int idx = tid; idx < ER * VPR; idx += NT) {
             const int rl = idx / VPR, cl = (idx - rl * VPR) * 4;
-            const int row = m0 + rl, col = n0 + cl;
+            const int row = mch + rl, col = n0 + cl;
             if (row >= p.M || col >= p.N) continue;
             const f32x4_t a4 = *(const f32x4_t*)(stage + rl * BN + cl);
             float v[4] = {a4[0] * p.alpha, a4[1] * p.alpha, a4[2] * p.alpha, a4[3] * p.alpha};
@@ -392,19 +406,23 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             }
         }
     }
+    if (NCH > 1) __syncthreads();
+    }
 }
 
 template <typename T, typename TO, int WM, int WN, int TM, int TN>
 static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr int smem_ml = 2 * (BM + BN) * 128, smem_ep = BM * BN * 4;
+    constexpr int NST = 2;            // LDS stages of the direct-to-LDS main loop (3 stages at 1 block/CU measured slower)
+    constexpr int NCH = (BM * BN * 4 > 96 * 1024) ? WM : 1;
+    constexpr int smem_ml = NST * (BM + BN) * 128, smem_ep = (BM / NCH) * BN * 4;
     constexpr int smem = smem_ml > smem_ep ? smem_ml : smem_ep;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     dim3 grid(p.tiles_m * p.tiles_n, d->batch, 1), block(WM * WN * 64);
 #define RF_LAUNCH_VARIANT(CONV_, GLDS_)                                                                                         \
     {                                                                                                                            \
-        auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_>;                                                          \
+        auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NST : 2)>;                                                          \
         static bool attr = false;                                                                                                \
         if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; } \
         hipLaunchKernelGGL(k, grid, block, smem, st, p);                                                                         \
@@ -421,6 +439,12 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
 template <typename T, typename TO>
 static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipStream_t st) {
     const int N = p.N;
+    // big tiles (8 waves, wave tile 64 x 160 / 64 x 128): half the LDS and L2 traffic per FLOP; only when they fill the chip
+    const long long mt256 = (p.M + 255) / 256;
+    if (p.glds && d->batch == 1) {
+        if (d->act != RF_ACT_GEGLU && N % 320 == 0 && mt256 * (N / 320) >= 192) return launch_cfg<T, TO, 4, 2, 2, 5>(d, p, conv, st);
+        if (N % 256 == 0 && mt256 * (N / 256) >= 192) return launch_cfg<T, TO, 4, 2, 2, 4>(d, p, conv, st);
+    }
     if (d->act == RF_ACT_GEGLU) return launch_cfg<T, TO, 2, 2, 2, 2>(d, p, conv, st);
     if (N <= 64) return launch_cfg<T, TO, 4, 1, 1, 2>(d, p, conv, st);
     const int pad128 = ((N + 127) / 128) * 128, pad160 = ((N + 159) / 160) * 160;
@@ -449,6 +473,8 @@ extern "C" int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream) {
     RF_CHECK(((uintptr_t)d->src0 | (uintptr_t)d->src1 | (uintptr_t)d->W) % 16 == 0, "rf_conv_gemm: operands must be 16-byte aligned");
     RF_CHECK(d->act != RF_ACT_GEGLU || (d->N % 64 == 0 && !d->rowvec), "rf_conv_gemm: GEGLU needs N %% 64 == 0 and no rowvec");
     RF_CHECK(!d->rowvec || d->rows_per_sample > 0, "rf_conv_gemm: rowvec needs rows_per_sample");
+    RF_CHECK(d->korder == 0 || (d->korder == 1 && ctot % (8 * vec) == 0 && d->K == d->KH * d->KW * ctot),
+             "rf_conv_gemm: korder=1 needs (C0+C1) to be a multiple of %d", 8 * vec);
     RF_CHECK(d->act != RF_ACT_PRELU || d->act_vec, "rf_conv_gemm: PReLU needs act_vec (per-column slopes)");
     const bool conv = !(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->ups == 0 &&
                         d->C1 == 0 && d->Hin == d->Hout && d->Win == d->Wout);
@@ -479,6 +505,7 @@ extern "C" int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream) {
         const long long ab = ((rows_a - 1) * d->ld0 + (conv ? d->C0 : d->K)) * es;
         const long long wb = ((long long)(d->N - 1) * p.ldw + d->K) * es;
         p.glds = (d->C1 == 0 && ab < 0x7fff0000LL && wb < 0x7fff0000LL) ? 1 : 0;
+        p.korder = d->korder;
         p.a_bytes = (unsigned)(p.glds ? ab : 0);
         p.w_bytes = (unsigned)(p.glds ? wb : 0);
     }

@@ -42,12 +42,22 @@ def _require_gpu(*ts):
 # ------------------------------------------------------------------------------------------------
 # weight packing (done once at load time)
 # ------------------------------------------------------------------------------------------------
-def pack_conv_weight(w, dtype, cin_pad=None):
-    """[Cout, Cin, KH, KW] -> [Cout, KH*KW*Cin_pad] with k = (ky*KW + kx)*Cin_pad + c."""
+def conv_korder(cin, dtype, ksize=3):
+    """1 when the channel-chunk-major K order applies (input channels a multiple of the K tile)."""
+    return 1 if (ksize > 1 and cin % (8 * vec(dtype)) == 0) else 0
+
+
+def pack_conv_weight(w, dtype, cin_pad=None, korder=0):
+    """[Cout, Cin, KH, KW] -> [Cout, KH*KW*Cin_pad].
+    korder 0: k = (ky*KW + kx)*Cin_pad + c.   korder 1: k = ((c // BK)*KH*KW + tap)*BK + c % BK (BK = K-tile elements)."""
     co, ci, kh, kw = w.shape
     cp = ci if cin_pad is None else cin_pad
     wp = torch.zeros((co, kh, kw, cp), dtype=torch.float32, device=w.device)
     wp[..., :ci] = w.float().permute(0, 2, 3, 1)
+    if korder:
+        bk = 8 * vec(dtype)
+        assert cp % bk == 0
+        wp = wp.reshape(co, kh * kw, cp // bk, bk).permute(0, 2, 1, 3)
     return wp.reshape(co, kh * kw * cp).to(dtype).contiguous()
 
 
@@ -87,7 +97,7 @@ class Launch:
 
 def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, Win=1, Hout=1, Wout=1, KH=1, KW=1,
               stride=1, pad_t=0, pad_l=0, ups=0, bias=None, rowvec=None, rows_per_sample=0, ldv=0, residual=None, ldr=0,
-              act=ACT_NONE, ldo=None, alpha=1.0, batch=1, sA=0, sW=0, sO=0, sR=0, ldw=0, act_vec=None, name="rf_conv_gemm"):
+              act=ACT_NONE, ldo=None, alpha=1.0, batch=1, sA=0, sW=0, sO=0, sR=0, ldw=0, act_vec=None, korder=0, name="rf_conv_gemm"):
     """Prepare an rf_conv_gemm launch (see include/reface_hip.h)."""
     lib = _lib.load()
     _require_gpu(src0, W, out, src1, bias, rowvec, residual)
@@ -108,6 +118,7 @@ def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, 
     d.out, d.ldo, d.alpha = _p(out), (ldo if ldo is not None else (N // 2 if act == ACT_GEGLU else N)), alpha
     d.batch, d.sA, d.sW, d.sO, d.sR = batch, sA, sW, sO, sR
     d.act_vec = _p(act_vec)
+    d.korder = korder
     return Launch(lib.rf_conv_gemm, (C.byref(d),), (d, src0, src1, W, out, bias, rowvec, residual, act_vec), name)
 
 
@@ -123,7 +134,7 @@ def linear(x, W, out, bias=None, *, act=ACT_NONE, residual=None, rowvec=None, ro
 
 
 def conv2d(x, W, out, bias=None, *, ksize=3, stride=1, pad=(1, 1), ups=0, x2=None, residual=None, rowvec=None,
-           act=ACT_NONE, act_vec=None, name="conv2d"):
+           act=ACT_NONE, act_vec=None, korder=0, name="conv2d"):
     """Channels-last convolution.  x: [B, Hin, Win, C0] (+ optional x2 [B, Hin, Win, C1] concatenated
     on channels); W: packed [Cout, k*k*(C0+C1)]; out: [B, Hout, Wout, Cout]."""
     B, Hin, Win, C0 = x.shape
@@ -135,7 +146,7 @@ def conv2d(x, W, out, bias=None, *, ksize=3, stride=1, pad=(1, 1), ups=0, x2=Non
                      ld1=(x2.stride(2) if x2 is not None else 0), Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, KH=ksize, KW=ksize,
                      stride=stride, pad_t=pad[0], pad_l=pad[1], ups=ups, bias=bias, residual=residual,
                      ldr=(residual.stride(2) if residual is not None else 0), rowvec=rowvec, rows_per_sample=Hout * Wout,
-                     ldv=(rowvec.stride(0) if rowvec is not None else 0), act=act, act_vec=act_vec, ldo=out.stride(2), name=name)
+                     ldv=(rowvec.stride(0) if rowvec is not None else 0), act=act, act_vec=act_vec, ldo=out.stride(2), korder=korder, name=name)
 
 
 GN_MAX_CHUNKS = 32

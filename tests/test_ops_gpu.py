@@ -265,3 +265,19 @@ def test_layout_and_embedding():
     torch.cuda.synchronize()
     args = t[:, None] * freqs[None]
     check(emb, torch.cat([torch.cos(args), torch.sin(args)], -1), torch.float32, scale=0.1)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("stride,ups,Ci", [(1, 0, 128), (2, 0, 64), (1, 1, 192)])
+def test_conv_channel_chunk_major_k(dt, stride, ups, Ci):
+    """korder=1: K runs (channel chunk, tap, channel-in-chunk); weights packed to match (ops.pack_conv_weight)."""
+    B, H, W_, Co = 2, 10, 12, 160
+    assert ops.conv_korder(Ci, dt) == 1
+    x, xr = q(rnd((B, H, W_, Ci), 40), dt)
+    w = rnd((Co, Ci, 3, 3), 41) / math.sqrt(Ci * 9)
+    b = rnd((Co,), 42)
+    ref = _conv_ref(xr, w.to(dt).float(), b, stride, (1, 1, 1, 1), ups)
+    out = torch.empty(ref.shape, dtype=dt, device=DEV)
+    ops.conv2d(x, ops.pack_conv_weight(w, dt, korder=1).to(DEV), out, b.to(DEV), stride=stride, ups=ups, korder=1)()
+    torch.cuda.synchronize()
+    check(out, ref, dt)

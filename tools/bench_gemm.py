@@ -19,10 +19,12 @@ ap.add_argument("--only", default="")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--bc", type=int, default=16)
 ap.add_argument("--json", default=None)
+ap.add_argument("--korder", type=int, default=1)
 args = ap.parse_args()
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 dev = "cuda"
 Bc = args.bc
+KORDER = args.korder
 
 
 def r(*shape, scale=1.0, dtype=None):
@@ -35,13 +37,13 @@ cases = []
 def conv(name, cin, cout, hw, *, c1=0, stride=1, ups=0):
     hin = hw // 2 if ups else hw
     ho = hw // stride
-    x = r(Bc, hin, hin, cin)
-    x2 = r(Bc, hin, hin, c1) if c1 else None
+    x = r(Bc, hin, hin, cin + c1)       # the UNet's skip concat is ONE buffer (zero-copy), so a single source
+    x2, cin, c1 = None, cin + c1, 0
     w = r(cout, 9 * (cin + c1), scale=1 / math.sqrt(9 * (cin + c1)))
     out = torch.empty(Bc, ho, ho, cout, device=dev, dtype=dt)
     res = r(Bc, ho, ho, cout)
     b = r(cout, dtype=torch.float32)
-    l = ops.conv2d(x, w, out, b, stride=stride, ups=ups, x2=x2, residual=res, name=name)
+    l = ops.conv2d(x, w, out, b, stride=stride, ups=ups, x2=x2, residual=res, korder=KORDER, name=name)
     cases.append((name, l, 2.0 * Bc * ho * ho * cout * 9 * (cin + c1)))
 
 
