@@ -55,8 +55,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     constexpr int VPR = D / VEC;                      // 16-byte vectors per K/V row
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const ldsK = smem;                          // [64][KROW]
-    char* const ldsV = smem + KV_TILE * KROW;         // [DVB*32][VROW]
+    constexpr int TILE_BYTES = KV_TILE * KROW + DVB * 32 * VROW;      // one stage: K [64][KROW] + V^T [DVB*32][VROW]
+    constexpr int NS = (2 * TILE_BYTES <= 160 * 1024) ? 2 : 1;        // double-buffer when it fits (fp32 d=160 does not)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, lh = lane >> 5;
@@ -79,45 +79,72 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
             qf[s] = v;
         }
     }
-    // zero the pad columns of the K tile / pad rows of V^T once (they are never rewritten)
-    for (int i = tid; i < (KV_TILE * KROW + DVB * 32 * VROW) / 16; i += 256) ((u32x4_t*)smem)[i] = u32x4_t{0u, 0u, 0u, 0u};
+    // zero both stages once: the pad columns of K / pad rows of V^T are never rewritten
+    for (int i = tid; i < NS * TILE_BYTES / 16; i += 256) ((u32x4_t*)smem)[i] = u32x4_t{0u, 0u, 0u, 0u};
 
     f32x16_t o[DVB];
 #pragma unroll
     for (int i = 0; i < DVB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;          // running max of the RAW scores, running sum (this lane's keys)
+    const float c2 = p.scale_log2e;
 
-    const int ntiles = (p.Nk + KV_TILE - 1) / KV_TILE;
-    for (int t = 0; t < ntiles; ++t) {
-        const int kv0 = t * KV_TILE;
-        __syncthreads();     // previous tile fully consumed (also orders the one-time zero fill)
-        // ---- stage K (row-major) and V^T (transposed, permuted key order) into LDS
-        for (int idx = tid; idx < KV_TILE * VPR; idx += 256) {
+    // K / V tile staging through registers: the loads of tile t+1 are issued before the MFMAs of tile t and written to
+    // the other LDS stage afterwards (one barrier per tile)
+    constexpr int NV = (KV_TILE * VPR + 255) / 256;               // 16-byte vectors per thread per operand
+    u32x4_t rk[NV], rv[NV];
+    auto load_kv = [&](int kv0) {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int idx = tid + u * 256;
             const int r = idx / VPR, c = idx - r * VPR;
             const int kv = kv0 + r;
-            u32x4_t kvv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-            if (kv < p.Nk) {
-                kvv = *(const u32x4_t*)(K + (long long)kv * p.ldk + c * VEC);
+            u32x4_t kk = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+            if (idx < KV_TILE * VPR && kv < p.Nk) {
+                kk = *(const u32x4_t*)(K + (long long)kv * p.ldk + c * VEC);
                 vv = *(const u32x4_t*)(V + (long long)kv * p.ldv + c * VEC);
             }
-            *(u32x4_t*)(ldsK + r * KROW + c * 16) = kvv;
-            const int pos = (r & ~15) + vt_pos<T>(r & 15);
-            if constexpr (sizeof(T) == 2) {
+            rk[u] = kk;
+            rv[u] = vv;
+        }
+    };
+    auto store_kv = [&](int stage) {
+        char* ldsK = smem + stage * TILE_BYTES;
+        char* ldsV = ldsK + KV_TILE * KROW;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    *(bf16_t*)(ldsV + (c * 8 + 2 * e) * VROW + pos * 2) = (bf16_t)(vv[e] & 0xffffu);
-                    *(bf16_t*)(ldsV + (c * 8 + 2 * e + 1) * VROW + pos * 2) = (bf16_t)(vv[e] >> 16);
+        for (int u = 0; u < NV; ++u) {
+            const int idx = tid + u * 256;
+            if (idx < KV_TILE * VPR) {
+                const int r = idx / VPR, c = idx - r * VPR;
+                *(u32x4_t*)(ldsK + r * KROW + c * 16) = rk[u];
+                const int pos = (r & ~15) + vt_pos<T>(r & 15);
+                if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        *(bf16_t*)(ldsV + (c * 8 + 2 * e) * VROW + pos * 2) = (bf16_t)(rv[u][e] & 0xffffu);
+                        *(bf16_t*)(ldsV + (c * 8 + 2 * e + 1) * VROW + pos * 2) = (bf16_t)(rv[u][e] >> 16);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) *(uint32_t*)(ldsV + (c * 4 + e) * VROW + pos * 4) = rv[u][e];
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) *(uint32_t*)(ldsV + (c * 4 + e) * VROW + pos * 4) = vv[e];
             }
         }
-        __syncthreads();
+    };
 
-        // ---- S^T = K Q^T for the two 32-key blocks of this tile
+    const int ntiles = (p.Nk + KV_TILE - 1) / KV_TILE;
+    load_kv(0);
+    __syncthreads();            // zero fill done
+    store_kv(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t * KV_TILE;
+        const char* ldsK = smem + (NS == 2 ? (t & 1) : 0) * TILE_BYTES;
+        const char* ldsV = ldsK + KV_TILE * KROW;
+        if (t + 1 < ntiles) load_kv(kv0 + KV_TILE);
+
+        // ---- S^T = K Q^T for the two 32-key blocks of this tile (raw, unscaled scores)
         f32x16_t s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -129,36 +156,41 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
                 AttnMma<T>::mma(s[kb], kf, qf[st]);
             }
         }
-        // ---- online softmax (per-lane query column; keys of this lane: kb*32 + 8*(r>>2) + 4*lh + (r&3))
-        float mx = -INFINITY;
+        // ---- online softmax on raw scores (scale > 0): p = exp2(c2 * s - c2 * m); keys of this lane: kb*32 + 8*(r>>2) + 4*lh + (r&3)
+        if (kv0 + KV_TILE > p.Nk) {       // tail tile only: mask keys beyond Nk
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kv0 + kb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3) >= p.Nk) s[kb][r] = -INFINITY;
+        }
+        float mx = s[0][0];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kv = kv0 + kb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
-                float x = s[kb][r] * p.scale_log2e;
-                if (kv >= p.Nk) x = -INFINITY;
-                s[kb][r] = x;
-                mx = fmaxf(mx, x);
-            }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);      // m_run = -inf on the first tile -> 0
-        m_run = m_new;
+        const float mc = m_new * c2;
+        if (__any(m_new != m_run)) {       // rescale only when some query's running max moved (wave-uniform branch)
+            const float alpha = __builtin_amdgcn_exp2f(m_run * c2 - mc);      // m_run = -inf on the first tile -> 0
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < DVB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            m_run = m_new;
+        }
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = exp2f(s[kb][r] - m_new);
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c2, -mc));
                 s[kb][r] = e;
                 psum += e;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < DVB; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        l_run += psum;
 
         // ---- O^T += V^T P^T
 #pragma unroll
@@ -180,7 +212,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
                 for (int g = 0; g < 4; ++g) {          // 8 keys per 4-MFMA group
                     u32x4_t pf;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pf[e] = as_u32( s[kb][4 * g + e]);
+                    for (int e = 0; e < 4; ++e) pf[e] = as_u32(s[kb][4 * g + e]);
 #pragma unroll
                     for (int i = 0; i < DVB; ++i) {
                         const u32x4_t vf = *(const u32x4_t*)(ldsV + (i * 32 + lq) * VROW + (kb * 32 + g * 8) * 4 + lh * 16);
@@ -189,6 +221,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
                 }
             }
         }
+        if (t + 1 < ntiles) {
+            if (NS == 1) __syncthreads();                  // single stage: every wave must be done reading tile t
+            store_kv(NS == 2 ? ((t + 1) & 1) : 0);          // NS == 2: that stage was last read in iteration t-1
+        }
+        __syncthreads();
     }
     // ---- normalise and store: lane holds O[q][dv = i*32 + 8*(r>>2) + 4*lh + (r&3)]
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -221,7 +258,8 @@ static int launch_attn(const AttnParams& p, int B, hipStream_t st) {
     constexpr int VEC = elem<T>::VEC, KSTEP = 2 * VEC, STEPS = (D + KSTEP - 1) / KSTEP, DVB = (D + 31) / 32;
     constexpr int KROW = STEPS * 32 + (((STEPS * 2) & 1) ? 0 : 16);
     constexpr int VROW = KV_TILE * (int)sizeof(T) + 16;
-    constexpr int smem = KV_TILE * KROW + DVB * 32 * VROW;
+    constexpr int tile_bytes = KV_TILE * KROW + DVB * 32 * VROW;
+    constexpr int smem = (2 * tile_bytes <= 160 * 1024 ? 2 : 1) * tile_bytes;
     auto k = attention_kernel<T, D>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }

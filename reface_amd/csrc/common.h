@@ -42,15 +42,15 @@ void set_error(const char* fmt, ...);
 __device__ __forceinline__ float as_f32(uint32_t x) { return __builtin_bit_cast(float, x); }
 __device__ __forceinline__ uint32_t as_u32(float x) { return __builtin_bit_cast(uint32_t, x); }
 
-// round-to-nearest-even fp32 -> bf16 (NaN preserved), same rule as torch .to(bfloat16)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = as_u32( f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even (same rule as torch .to(bfloat16)): native conversions, which hipcc lowers to
+// v_cvt_pk_bf16_f32 on gfx950 (one instruction per pair instead of ~5 integer ops per value).
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
-__device__ __forceinline__ float bf2f(bf16_t h) { return as_f32( ((uint32_t)h) << 16); }
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ float bf2f(bf16_t h) { return as_f32(((uint32_t)h) << 16); }
 
 template <typename T> struct elem;
 template <> struct elem<float> {
