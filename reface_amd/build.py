@@ -13,6 +13,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libreface_hip.so")
 SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "encoder.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+# per-file extras.  attention: keep MFMA accumulators in VGPRs -- the online softmax reads every score and rescales O each
+# tile, and with AGPR accumulators hipcc emitted ~160 v_accvgpr_read/write per KV tile (40 % of the loop's VALU work).
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _stale(obj, deps):
@@ -32,7 +35,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd)))

@@ -10,6 +10,8 @@
 // Same byte geometry for both storage types (16-byte fragments):
 //   bf16: v_mfma_f32_32x32x16_bf16, fp32: 4 x v_mfma_f32_32x32x2_f32 (exact fp32).
 // Block = 4 waves = 128 queries of one (batch, head); KV tile = 64 keys.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace rf {
@@ -33,6 +35,7 @@ struct AttnParams {
     int heads, d, Nq, Nk, ldq, ldk, ldv, ldo;
     long long sq, sk, sv, so;
     float scale_log2e;
+    int nqb;          // q-blocks (of 128 queries) per (batch, head)
 };
 
 constexpr int KV_TILE = 64;
@@ -43,91 +46,131 @@ template <typename T> __device__ __forceinline__ int vt_pos(int j);
 template <> __device__ __forceinline__ int vt_pos<bf16_t>(int j) { return (j < 4 || j >= 12) ? j : (j < 8 ? j + 4 : j - 4); }
 template <> __device__ __forceinline__ int vt_pos<float>(int j) { return j; }
 
-// D = head dim (multiple of 8).  STEPS = 16-byte k-steps over D per lane-half pair.
-template <typename T, int D>
+// D = head dim (multiple of 8).  STEPS = 16-byte k-steps over D per lane-half pair.  QB = 32-query blocks per wave
+// (QB = 2: each K / V^T fragment read from LDS feeds two MFMAs and the staging / barrier cost per query halves).
+template <typename T, int D, int QB>
 __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     constexpr int VEC = elem<T>::VEC;                 // elements per 16 B
     constexpr int KSTEP = 2 * VEC;                    // d consumed per fragment pair (two lane halves)
     constexpr int STEPS = (D + KSTEP - 1) / KSTEP;
     constexpr int DVB = (D + 31) / 32;                // 32-row blocks of O^T
-    constexpr int KROW = STEPS * 32 + (((STEPS * 2) & 1) ? 0 : 16);   // K row bytes, (KROW/16) odd
+    constexpr int KROW = STEPS * 32 + 16;             // K row bytes, (KROW/16) odd
     constexpr int VROW = KV_TILE * (int)sizeof(T) + 16;               // V^T row bytes, (VROW/16) odd
     constexpr int VPR = D / VEC;                      // 16-byte vectors per K/V row
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int QW = 32 * QB;                       // queries per wave
     constexpr int TILE_BYTES = KV_TILE * KROW + DVB * 32 * VROW;      // one stage: K [64][KROW] + V^T [DVB*32][VROW]
     constexpr int NS = (2 * TILE_BYTES <= 160 * 1024) ? 2 : 1;        // double-buffer when it fits (fp32 d=160 does not)
 
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, lh = lane >> 5;
-    const int bh = blockIdx.y, b = bh / p.heads, h = bh % p.heads;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // XCD-aware block order: XCD x (= dispatch id mod 8) owns a contiguous run of (batch*head, q-block) pairs with the
+    // q-blocks of one head adjacent, so the K/V of the heads in flight on an XCD stay resident in its 4 MiB L2.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bh = bid / p.nqb, qblk = bid - bh * p.nqb;
+    const int b = bh / p.heads, h = bh % p.heads;
+    const int q0 = qblk * (4 * QW) + wave * QW;
     const T* Q = (const T*)p.q + b * p.sq + h * D;
     const T* K = (const T*)p.k + b * p.sk + h * D;
     const T* V = (const T*)p.v + b * p.sv + h * D;
     T* O = (T*)p.out + b * p.so + h * D;
 
     // ---- Q fragments (B operand): lane (q, half) holds Q[q][s*KSTEP + half*VEC .. +VEC)
-    u32x4_t qf[STEPS];
-    {
-        const int qi = q0 + lq;
+    u32x4_t qf[QB][STEPS];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qi = q0 + qb * 32 + lq;
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             const int c = s * KSTEP + lh * VEC;
             u32x4_t v = {0u, 0u, 0u, 0u};
             if (qi < p.Nq && c < D) v = *(const u32x4_t*)(Q + (long long)qi * p.ldq + c);
-            qf[s] = v;
+            qf[qb][s] = v;
         }
     }
-    // zero both stages once: the pad columns of K / pad rows of V^T are never rewritten
+    // zero the stages once: the pad columns of K / pad rows of V^T are never rewritten
     for (int i = tid; i < NS * TILE_BYTES / 16; i += 256) ((u32x4_t*)smem)[i] = u32x4_t{0u, 0u, 0u, 0u};
 
-    f32x16_t o[DVB];
+    f32x16_t o[QB][DVB];
 #pragma unroll
-    for (int i = 0; i < DVB; ++i)
+    for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;          // running max of the RAW scores, running sum (this lane's keys)
+        for (int i = 0; i < DVB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][i][r] = 0.f;
+    float m_run[QB], l_run[QB];          // running max of the RAW scores, running sum (this lane's keys)
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; }
     const float c2 = p.scale_log2e;
 
     // K / V tile staging through registers: the loads of tile t+1 are issued before the MFMAs of tile t and written to
-    // the other LDS stage afterwards (one barrier per tile)
-    constexpr int NV = (KV_TILE * VPR + 255) / 256;               // 16-byte vectors per thread per operand
-    u32x4_t rk[NV], rv[NV];
+    // the other LDS stage afterwards (one barrier per tile).
+    //   K : work item = (row r, 16-byte chunk c), row-major image.
+    //   V : work item = (key pair pr, chunk c): the two keys 2pr, 2pr+1 are adjacent in the V^T row, so each transposed
+    //       element pair is ONE 32-bit LDS store; lanes of a half-wave hold distinct pairs of one chunk => conflict-free.
+    constexpr int NKV = (KV_TILE * VPR + 255) / 256;
+    constexpr int NVP = ((KV_TILE / 2) * VPR + 255) / 256;
+    u32x4_t rk[NKV], rv0[NVP], rv1[NVP];
     auto load_kv = [&](int kv0) {
 #pragma unroll
-        for (int u = 0; u < NV; ++u) {
+        for (int u = 0; u < NKV; ++u) {
             const int idx = tid + u * 256;
             const int r = idx / VPR, c = idx - r * VPR;
-            const int kv = kv0 + r;
-            u32x4_t kk = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-            if (idx < KV_TILE * VPR && kv < p.Nk) {
-                kk = *(const u32x4_t*)(K + (long long)kv * p.ldk + c * VEC);
-                vv = *(const u32x4_t*)(V + (long long)kv * p.ldv + c * VEC);
-            }
+            u32x4_t kk = {0u, 0u, 0u, 0u};
+            if (idx < KV_TILE * VPR && kv0 + r < p.Nk) kk = *(const u32x4_t*)(K + (long long)(kv0 + r) * p.ldk + c * VEC);
             rk[u] = kk;
-            rv[u] = vv;
+        }
+#pragma unroll
+        for (int u = 0; u < NVP; ++u) {
+            const int idx = tid + u * 256;
+            const int c = idx / (KV_TILE / 2), pr = idx - c * (KV_TILE / 2);
+            u32x4_t a = {0u, 0u, 0u, 0u}, bq = {0u, 0u, 0u, 0u};
+            if (idx < (KV_TILE / 2) * VPR) {
+                const int kv = kv0 + 2 * pr;
+                if (kv < p.Nk) a = *(const u32x4_t*)(V + (long long)kv * p.ldv + c * VEC);
+                if (kv + 1 < p.Nk) bq = *(const u32x4_t*)(V + (long long)(kv + 1) * p.ldv + c * VEC);
+            }
+            rv0[u] = a;
+            rv1[u] = bq;
         }
     };
     auto store_kv = [&](int stage) {
         char* ldsK = smem + stage * TILE_BYTES;
         char* ldsV = ldsK + KV_TILE * KROW;
 #pragma unroll
-        for (int u = 0; u < NV; ++u) {
+        for (int u = 0; u < NKV; ++u) {
             const int idx = tid + u * 256;
             if (idx < KV_TILE * VPR) {
                 const int r = idx / VPR, c = idx - r * VPR;
                 *(u32x4_t*)(ldsK + r * KROW + c * 16) = rk[u];
-                const int pos = (r & ~15) + vt_pos<T>(r & 15);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NVP; ++u) {
+            const int idx = tid + u * 256;
+            if (idx < (KV_TILE / 2) * VPR) {
+                const int c = idx / (KV_TILE / 2), pr = idx - c * (KV_TILE / 2);
+                const int r = 2 * pr;
+                const int pos = (r & ~15) + vt_pos<T>(r & 15);          // even; key r+1 sits at pos+1
                 if constexpr (sizeof(T) == 2) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        *(bf16_t*)(ldsV + (c * 8 + 2 * e) * VROW + pos * 2) = (bf16_t)(rv[u][e] & 0xffffu);
-                        *(bf16_t*)(ldsV + (c * 8 + 2 * e + 1) * VROW + pos * 2) = (bf16_t)(rv[u][e] >> 16);
+                        const uint32_t x0 = rv0[u][e], x1 = rv1[u][e];
+                        *(uint32_t*)(ldsV + (c * 8 + 2 * e) * VROW + pos * 2) = (x0 & 0xffffu) | (x1 << 16);
+                        *(uint32_t*)(ldsV + (c * 8 + 2 * e + 1) * VROW + pos * 2) = (x0 >> 16) | (x1 & 0xffff0000u);
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) *(uint32_t*)(ldsV + (c * 4 + e) * VROW + pos * 4) = rv[u][e];
+                    for (int e = 0; e < 4; ++e) {
+                        u32x2_t w; w[0] = rv0[u][e]; w[1] = rv1[u][e];
+                        *(u32x2_t*)(ldsV + (c * 4 + e) * VROW + pos * 4) = w;
+                    }
                 }
             }
         }
@@ -145,78 +188,93 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         if (t + 1 < ntiles) load_kv(kv0 + KV_TILE);
 
         // ---- S^T = K Q^T for the two 32-key blocks of this tile (raw, unscaled scores)
-        f32x16_t s[2];
+        f32x16_t s[QB][2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-#pragma unroll
-            for (int st = 0; st < STEPS; ++st) {
-                const u32x4_t kf = *(const u32x4_t*)(ldsK + (kb * 32 + lq) * KROW + st * 32 + lh * 16);
-                AttnMma<T>::mma(s[kb], kf, qf[st]);
-            }
-        }
-        // ---- online softmax on raw scores (scale > 0): p = exp2(c2 * s - c2 * m); keys of this lane: kb*32 + 8*(r>>2) + 4*lh + (r&3)
-        if (kv0 + KV_TILE > p.Nk) {       // tail tile only: mask keys beyond Nk
+        for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kv0 + kb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3) >= p.Nk) s[kb][r] = -INFINITY;
-        }
-        float mx = s[0][0];
+                for (int r = 0; r < 16; ++r) s[qb][kb][r] = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float mc = m_new * c2;
-        if (__any(m_new != m_run)) {       // rescale only when some query's running max moved (wave-uniform branch)
-            const float alpha = __builtin_amdgcn_exp2f(m_run * c2 - mc);      // m_run = -inf on the first tile -> 0
-            l_run *= alpha;
+            for (int st = 0; st < STEPS; ++st) {
+                const u32x4_t kf = *(const u32x4_t*)(ldsK + (kb * 32 + lq) * KROW + st * 32 + lh * 16);
 #pragma unroll
-            for (int i = 0; i < DVB; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-            m_run = m_new;
-        }
-        float psum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c2, -mc));
-                s[kb][r] = e;
-                psum += e;
+                for (int qb = 0; qb < QB; ++qb) AttnMma<T>::mma(s[qb][kb], kf, qf[qb][st]);
             }
-        l_run += psum;
+        // ---- online softmax on raw scores (scale > 0): p = exp2(c2 * s - c2 * m); keys of this lane: kb*32 + 8*(r>>2) + 4*lh + (r&3)
+        if (kv0 + KV_TILE > p.Nk) {       // tail tile only: mask keys beyond Nk
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kv0 + kb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3) >= p.Nk) s[qb][kb][r] = -INFINITY;
+        }
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float mx = s[qb][0][0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][kb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qb], mx);
+            const float mc = m_new * c2;
+            if (__any(m_new != m_run[qb])) {       // rescale only when some query's running max moved (wave-uniform branch)
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qb] * c2 - mc);      // m_run = -inf on the first tile -> 0
+                l_run[qb] *= alpha;
+#pragma unroll
+                for (int i = 0; i < DVB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[qb][i][r] *= alpha;
+                m_run[qb] = m_new;
+            }
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[qb][kb][r], c2, -mc));
+                    s[qb][kb][r] = e;
+                    psum += e;
+                }
+            l_run[qb] += psum;
+        }
 
-        // ---- O^T += V^T P^T
+        // ---- O^T += V^T P^T   (each V^T fragment feeds the QB query blocks)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             if constexpr (sizeof(T) == 2) {
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {          // 16 keys per MFMA
-                    u32x4_t pf;
+                    u32x4_t pf[QB];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pf[e] = pack_bf2(s[kb][8 * g + 2 * e], s[kb][8 * g + 2 * e + 1]);
+                    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pf[qb][e] = pack_bf2(s[qb][kb][8 * g + 2 * e], s[qb][kb][8 * g + 2 * e + 1]);
 #pragma unroll
                     for (int i = 0; i < DVB; ++i) {
                         const u32x4_t vf = *(const u32x4_t*)(ldsV + (i * 32 + lq) * VROW + (kb * 32 + g * 16) * 2 + lh * 16);
-                        AttnMma<T>::mma(o[i], vf, pf);
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) AttnMma<T>::mma(o[qb][i], vf, pf[qb]);
                     }
                 }
             } else {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {          // 8 keys per 4-MFMA group
-                    u32x4_t pf;
+                    u32x4_t pf[QB];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pf[e] = as_u32(s[kb][4 * g + e]);
+                    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pf[qb][e] = as_u32(s[qb][kb][4 * g + e]);
 #pragma unroll
                     for (int i = 0; i < DVB; ++i) {
                         const u32x4_t vf = *(const u32x4_t*)(ldsV + (i * 32 + lq) * VROW + (kb * 32 + g * 8) * 4 + lh * 16);
-                        AttnMma<T>::mma(o[i], vf, pf);
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) AttnMma<T>::mma(o[qb][i], vf, pf[qb]);
                     }
                 }
             }
@@ -228,45 +286,60 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         __syncthreads();
     }
     // ---- normalise and store: lane holds O[q][dv = i*32 + 8*(r>>2) + 4*lh + (r&3)]
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    const int qi = q0 + lq;
-    if (qi < p.Nq) {
 #pragma unroll
-        for (int i = 0; i < DVB; ++i)
+    for (int qb = 0; qb < QB; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int qi = q0 + qb * 32 + lq;
+        if (qi < p.Nq) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int dv = i * 32 + 8 * g + 4 * lh;
-                if (dv < D) {
-                    T* dst = O + (long long)qi * p.ldo + dv;
-                    if constexpr (sizeof(T) == 2) {
-                        u32x2_t w;
-                        w[0] = pack_bf2(o[i][4 * g] * inv, o[i][4 * g + 1] * inv);
-                        w[1] = pack_bf2(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
-                        *(u32x2_t*)dst = w;
-                    } else {
-                        f32x4_t w = {o[i][4 * g] * inv, o[i][4 * g + 1] * inv, o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv};
-                        *(f32x4_t*)dst = w;
+            for (int i = 0; i < DVB; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int dv = i * 32 + 8 * g + 4 * lh;
+                    if (dv < D) {
+                        T* dst = O + (long long)qi * p.ldo + dv;
+                        if constexpr (sizeof(T) == 2) {
+                            u32x2_t w;
+                            w[0] = pack_bf2(o[qb][i][4 * g] * inv, o[qb][i][4 * g + 1] * inv);
+                            w[1] = pack_bf2(o[qb][i][4 * g + 2] * inv, o[qb][i][4 * g + 3] * inv);
+                            *(u32x2_t*)dst = w;
+                        } else {
+                            f32x4_t w = {o[qb][i][4 * g] * inv, o[qb][i][4 * g + 1] * inv, o[qb][i][4 * g + 2] * inv, o[qb][i][4 * g + 3] * inv};
+                            *(f32x4_t*)dst = w;
+                        }
                     }
                 }
-            }
+        }
     }
+}
+
+template <typename T, int D, int QB>
+static int launch_attn_qb(const AttnParams& p, int B, hipStream_t st) {
+    constexpr int VEC = elem<T>::VEC, KSTEP = 2 * VEC, STEPS = (D + KSTEP - 1) / KSTEP, DVB = (D + 31) / 32;
+    constexpr int KROW = STEPS * 32 + 16;
+    constexpr int VROW = KV_TILE * (int)sizeof(T) + 16;
+    constexpr int tile_bytes = KV_TILE * KROW + DVB * 32 * VROW;
+    constexpr int smem = (2 * tile_bytes <= 160 * 1024 ? 2 : 1) * tile_bytes;
+    auto k = attention_kernel<T, D, QB>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+    AttnParams pp = p;
+    pp.nqb = (p.Nq + 128 * QB - 1) / (128 * QB);
+    dim3 grid(pp.nqb * B * p.heads);
+    hipLaunchKernelGGL(k, grid, dim3(256), smem, st, pp);
+    RF_LAUNCH_CHECK("rf_attention");
+    return 0;
 }
 
 template <typename T, int D>
 static int launch_attn(const AttnParams& p, int B, hipStream_t st) {
-    constexpr int VEC = elem<T>::VEC, KSTEP = 2 * VEC, STEPS = (D + KSTEP - 1) / KSTEP, DVB = (D + 31) / 32;
-    constexpr int KROW = STEPS * 32 + (((STEPS * 2) & 1) ? 0 : 16);
-    constexpr int VROW = KV_TILE * (int)sizeof(T) + 16;
-    constexpr int tile_bytes = KV_TILE * KROW + DVB * 32 * VROW;
-    constexpr int smem = (2 * tile_bytes <= 160 * 1024 ? 2 : 1) * tile_bytes;
-    auto k = attention_kernel<T, D>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
-    dim3 grid((p.Nq + 127) / 128, B * p.heads);
-    hipLaunchKernelGGL(k, grid, dim3(256), smem, st, p);
-    RF_LAUNCH_CHECK("rf_attention");
-    return 0;
+    // QB = 2 (two query blocks per wave, every K / V^T fragment feeds two MFMAs) pays for the small head dim when the
+    // grid still fills the chip: d=40, N=4096: 687 us vs 739 us; it loses at d=80 (N=1024: 99 us vs 85 us).
+    if constexpr (sizeof(T) == 2 && D <= 40) {
+        if ((long long)((p.Nq + 255) / 256) * B * p.heads >= 512) return launch_attn_qb<T, D, 2>(p, B, st);
+    }
+    return launch_attn_qb<T, D, 1>(p, B, st);
 }
 
 template <typename T>
@@ -295,7 +368,7 @@ extern "C" int rf_attention(int dtype, const void* q, const void* k, const void*
     const int vec = dtype == RF_F32 ? 4 : 8;
     RF_CHECK(d % 8 == 0 && ldq % vec == 0 && ldk % vec == 0 && ldv % vec == 0 && ldo % 4 == 0, "rf_attention: d/ld alignment (d=%d)", d);
     RF_CHECK(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16 == 0, "rf_attention: operands must be 16-byte aligned");
-    RF_CHECK((long long)B * heads <= 65535, "rf_attention: B*heads too large");
+    RF_CHECK((long long)B * heads * ((Nq + 127) / 128) < (1LL << 31), "rf_attention: grid too large");
     AttnParams p;
     p.q = q; p.k = k; p.v = v; p.out = out;
     p.heads = heads; p.d = d; p.Nq = Nq; p.Nk = Nk; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
