@@ -76,8 +76,9 @@ typedef struct rf_conv_gemm_desc {
     int32_t batch;        /* >= 1 */
     int64_t sA, sW, sO, sR;   /* batch strides (elements) of src0, W, out, residual */
     const float* act_vec; /* [N] fp32 per-column activation parameter (PReLU slopes) or NULL */
-    int32_t korder;       /* 0: k = tap*(C0+C1) + c.  1: k = ((c / BK)*KH*KW + tap)*BK + c % BK with BK = 64 (bf16) / 32 (fp32):
-                             the taps of one channel chunk are consecutive K-tiles (input rows stay L1/L2-resident) */
+    int32_t korder;       /* 0: k = tap*(C0+C1) + c;  1: k = ((c / BK)*KH*KW + tap)*BK + c % BK, BK = 64 (bf16) / 32 (fp32) */
+    void* workspace;      /* optional fp32 scratch for split-K (small-M / long-K problems that cannot fill 256 CUs); NULL = never split */
+    int64_t workspace_bytes;
 } rf_conv_gemm_desc;
 
 int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream);

@@ -30,6 +30,7 @@ class ConvGemmDesc(C.Structure):
         ("batch", C.c_int32),
         ("sA", C.c_int64), ("sW", C.c_int64), ("sO", C.c_int64), ("sR", C.c_int64),
         ("act_vec", C.c_void_p), ("korder", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 

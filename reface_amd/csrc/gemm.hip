@@ -38,6 +38,8 @@ struct GemmParams {
     int glds;        // use the direct-to-LDS main loop
     int korder;      // 1: K is ordered (channel chunk of BK, tap, channel-in-chunk) instead of (tap, channel)
     int vec_ok;      // epilogue may use 16-byte (fp32) / 8-byte (bf16) vector accesses
+    int splitk;      // > 1: blockIdx.z owns a K range and writes raw fp32 partial sums to `ws` (epilogue in splitk_reduce_kernel)
+    float* ws;       // [splitk][M][N] fp32
 };
 
 template <typename T> struct MmaFrag;
@@ -198,7 +200,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nk = (p.K + BK - 1) / BK;
+    int nk = (p.K + BK - 1) / BK;
+    if (p.splitk > 1) {          // this block's K-tile range [kb0, kb0 + nk)
+        const int per = (nk + p.splitk - 1) / p.splitk;
+        const int kb0 = blockIdx.z * per;
+        nk = max(0, min(nk, kb0 + per) - kb0);
+        for (int i = 0; i < kb0; ++i) advance_k();
+    }
     const int lrow = lane & 31, lhalf = lane >> 5;
 
     auto compute_tile = [&](int buf) {
@@ -287,6 +295,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
     float* const stage = (float*)smem;
     TO* outp = (TO*)p.out + zb * p.sO;
     const TO* resp = p.residual ? (const TO*)p.residual + zb * p.sR : nullptr;
+    const bool partial_out = p.splitk > 1;
     for (int ch = 0; ch < NCH; ++ch) {
     if (NCH == 1 || wm == ch) {
 #pragma unroll
@@ -301,7 +310,22 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
     }
     __syncthreads();
     const int mch = m0 + ch * ER;
-    if (p.act == RF_ACT_GEGLU) {
+    if (partial_out) {            // split-K: raw fp32 partial sums, coalesced; bias / activation / residual happen in the reduce pass
+        constexpr int VPRS = BN / 4;
+        float* wsz = p.ws + (long long)blockIdx.z * p.M * p.N;
+        for (int idx = tid; idx < ER * VPRS; idx += NT) {
+            const int rl = idx / VPRS, cl = (idx - rl * VPRS) * 4;
+            const int row = mch + rl, col = n0 + cl;
+            if (row >= p.M || col >= p.N) continue;
+            const f32x4_t a4 = *(const f32x4_t*)(stage + rl * BN + cl);
+            float* dst = wsz + (long long)row * p.N + col;
+            if ((p.N & 3) == 0) *(f32x4_t*)dst = a4;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (col + e < p.N) dst[e] = a4[e];
+            }
+        }
+    } else if (p.act == RF_ACT_GEGLU) {
         constexpr int OV = BN / 8;                      // output 4-column vectors per row (N/2 columns)
         for (int idx = tid; idx < ER * OV; idx += NT) {
             const int rl = idx / OV, oc = (idx - rl * OV) * 4;
@@ -410,6 +434,44 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
     }
 }
 
+// split-K second pass: out = act(alpha * sum_z ws[z] + bias + rowvec) + residual   (elementwise, 4 columns per thread)
+template <typename TO>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+    const long long nvec = (long long)p.M * ((p.N + 3) / 4);
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvec) return;
+    const int nv = (p.N + 3) / 4;
+    const int row = (int)(i / nv), col = (int)(i - (long long)row * nv) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = (p.N & 3) == 0;
+    for (int z = 0; z < p.splitk; ++z) {
+        const float* src = p.ws + ((long long)z * p.M + row) * p.N + col;
+        if (vec) { const f32x4_t a = *(const f32x4_t*)src; v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3]; }
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (col + e < p.N) v[e] += src[e];
+        }
+    }
+    TO* outp = (TO*)p.out;
+    const TO* resp = (const TO*)p.residual;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = col + e;
+        if (c >= p.N) break;
+        float y = v[e] * p.alpha;
+        if (p.bias) y += p.bias[c];
+        if (p.rowvec) y += p.rowvec[(long long)(row / p.rows_per_sample) * p.ldv + c];
+        if (p.act == RF_ACT_SILU) y = silu_exact(y);
+        else if (p.act == RF_ACT_QUICK_GELU) y = quick_gelu(y);
+        else if (p.act == RF_ACT_GELU) y = gelu_erf(y);
+        else if (p.act == RF_ACT_RELU) y = fmaxf(y, 0.0f);
+        else if (p.act == RF_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
+        else if (p.act == RF_ACT_PRELU) y = y >= 0.0f ? y : y * p.act_vec[c];
+        if (resp) y += load_out<TO>(resp + (long long)row * p.ldr + c);
+        store_out<TO>(outp + (long long)row * p.ldo + c, y);
+    }
+}
+
 template <typename T, typename TO, int WM, int WN, int TM, int TN>
 static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -419,7 +481,21 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     constexpr int smem = smem_ml > smem_ep ? smem_ml : smem_ep;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
-    dim3 grid(p.tiles_m * p.tiles_n, d->batch, 1), block(WM * WN * 64);
+    // split-K for launches that cannot fill the chip: each z-slice owns a K range, partial sums go through the caller's workspace
+    p.splitk = 1;
+    {
+        constexpr int BKE = (sizeof(T) == 2) ? 64 : 32;
+        const int nk = (p.K + BKE - 1) / BKE;
+        const long long tiles = (long long)p.tiles_m * p.tiles_n;
+        if (d->workspace && d->batch == 1 && d->act != RF_ACT_GEGLU && tiles < 200 && nk >= 16) {
+            int sk = (int)(512 / tiles);
+            if (sk > nk / 8) sk = nk / 8;
+            if (sk > 16) sk = 16;
+            while (sk > 1 && (long long)sk * p.M * p.N * 4 > d->workspace_bytes) --sk;
+            if (sk > 1) { p.splitk = sk; p.ws = (float*)d->workspace; }
+        }
+    }
+    dim3 grid(p.tiles_m * p.tiles_n, d->batch, p.splitk), block(WM * WN * 64);
 #define RF_LAUNCH_VARIANT(CONV_, GLDS_)                                                                                         \
     {                                                                                                                            \
         auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NST : 2)>;                                                          \
@@ -432,6 +508,10 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     else if (p.glds) RF_LAUNCH_VARIANT(false, true)
     else RF_LAUNCH_VARIANT(false, false)
 #undef RF_LAUNCH_VARIANT
+    if (p.splitk > 1) {
+        const long long nvec = (long long)p.M * ((p.N + 3) / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, p);
+    }
     RF_LAUNCH_CHECK("rf_conv_gemm");
     return 0;
 }

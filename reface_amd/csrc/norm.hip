@@ -310,9 +310,9 @@ extern "C" int rf_groupnorm_apply(int dtype, const void* x, int B, int HW, int C
     RF_CHECK(x && partial && gamma && beta && out && B > 0 && HW > 0, "rf_groupnorm_apply: bad arguments");
     RF_CHECK(out_dtype == RF_F32 || out_dtype == RF_BF16, "rf_groupnorm_apply: bad out_dtype");
     RF_CHECK(ldo % 8 == 0, "rf_groupnorm_apply: ldo=%d must be a multiple of 8", ldo);
-    // blocks of >= ~64 pixels, about 2 blocks per CU in total
-    int achunks = (512 + B - 1) / B;
-    const int maxc = (HW + 63) / 64;
+    // blocks of >= ~16 pixels, about 4 blocks per CU in total
+    int achunks = (1024 + B - 1) / B;
+    const int maxc = (HW + 15) / 16;
     if (achunks > maxc) achunks = maxc;
     if (achunks < 1) achunks = 1;
     dim3 grid(achunks, B);

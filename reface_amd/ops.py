@@ -95,9 +95,22 @@ class Launch:
             _lib.check(rc, self.name)
 
 
+_WORKSPACES = {}
+SPLITK_WORKSPACE_BYTES = 96 << 20
+
+
+def _default_workspace(device):
+    """One fp32 split-K scratch buffer per device, shared by every launch (launches on a stream are serialised)."""
+    ws = _WORKSPACES.get(device)
+    if ws is None:
+        ws = torch.empty(SPLITK_WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+        _WORKSPACES[device] = ws
+    return ws
+
+
 def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, Win=1, Hout=1, Wout=1, KH=1, KW=1,
               stride=1, pad_t=0, pad_l=0, ups=0, bias=None, rowvec=None, rows_per_sample=0, ldv=0, residual=None, ldr=0,
-              act=ACT_NONE, ldo=None, alpha=1.0, batch=1, sA=0, sW=0, sO=0, sR=0, ldw=0, act_vec=None, korder=0, name="rf_conv_gemm"):
+              act=ACT_NONE, ldo=None, alpha=1.0, batch=1, sA=0, sW=0, sO=0, sR=0, ldw=0, act_vec=None, korder=0, workspace=None, name="rf_conv_gemm"):
     """Prepare an rf_conv_gemm launch (see include/reface_hip.h)."""
     lib = _lib.load()
     _require_gpu(src0, W, out, src1, bias, rowvec, residual)
@@ -119,7 +132,9 @@ def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, 
     d.batch, d.sA, d.sW, d.sO, d.sR = batch, sA, sW, sO, sR
     d.act_vec = _p(act_vec)
     d.korder = korder
-    return Launch(lib.rf_conv_gemm, (C.byref(d),), (d, src0, src1, W, out, bias, rowvec, residual, act_vec), name)
+    ws = workspace if workspace is not None else _default_workspace(src0.device)
+    d.workspace, d.workspace_bytes = _p(ws), (ws.numel() * ws.element_size() if ws is not None else 0)
+    return Launch(lib.rf_conv_gemm, (C.byref(d),), (d, src0, src1, W, out, bias, rowvec, residual, act_vec, ws), name)
 
 
 def linear(x, W, out, bias=None, *, act=ACT_NONE, residual=None, rowvec=None, rows_per_sample=0, alpha=1.0, act_vec=None, name="linear"):
@@ -153,8 +168,9 @@ GN_MAX_CHUNKS = 32
 
 
 def gn_chunks(B, HW):
+    """Pixel chunks of the GroupNorm statistics pass: >= 32 pixels per block, about two blocks per CU in total."""
     n = max(1, min(GN_MAX_CHUNKS, HW // 32))
-    while B * n > 1024 and n > 1:
+    while B * n > 512 and n > 1:
         n //= 2
     return n
 

@@ -281,3 +281,19 @@ def test_conv_channel_chunk_major_k(dt, stride, ups, Ci):
     ops.conv2d(x, ops.pack_conv_weight(w, dt, korder=1).to(DEV), out, b.to(DEV), stride=stride, ups=ups, korder=1)()
     torch.cuda.synchronize()
     check(out, ref, dt)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_conv_split_k(dt):
+    """Small-M / long-K conv (8x8 level of the UNet): takes the split-K path (partials in the workspace + reduce pass)."""
+    B, H, W_, Ci, Co = 2, 8, 8, 1280, 320
+    x, xr = q(rnd((B, H, W_, Ci), 43), dt)
+    w = rnd((Co, Ci, 3, 3), 44) / math.sqrt(Ci * 9)
+    b = rnd((Co,), 45)
+    rv = rnd((B, Co), 46)
+    res, rr = q(rnd((B, H, W_, Co), 47), dt)
+    ref = _conv_ref(xr, w.to(dt).float(), b, 1, (1, 1, 1, 1), 0) + rv[:, None, None, :] + rr
+    out = torch.empty(ref.shape, dtype=dt, device=DEV)
+    ops.conv2d(x, ops.pack_conv_weight(w, dt).to(DEV), out, b.to(DEV), rowvec=rv.to(DEV), residual=res)()
+    torch.cuda.synchronize()
+    check(out, ref, dt)
