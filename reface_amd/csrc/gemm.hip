@@ -472,6 +472,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
     }
 }
 
+// Split-K factor for a launch of `tiles` output tiles, by a two-term cost model: GEMM time at ~600 TFLOP/s stretched by the
+// fraction of the 256 CUs left idle, plus the fp32 partial-sum traffic (write + re-read of sk * M * N floats at ~4 TB/s).
+static int pick_splitk(const rf_conv_gemm_desc* d, const GemmParams& p, long long tiles, int bk) {
+    const int nk = (p.K + bk - 1) / bk;
+    if (!d->workspace || d->batch != 1 || d->act == RF_ACT_GEGLU || tiles >= 200 || nk < 16) return 1;
+    int maxsk = nk / 8;
+    if (maxsk > 16) maxsk = 16;
+    const double t_gemm = 2.0 * p.M * p.N * (double)p.K / 6e14;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int sk = 1; sk <= maxsk; ++sk) {
+        if ((long long)sk * p.M * p.N * 4 > d->workspace_bytes) break;
+        const double fill = (double)(tiles * sk) / 256.0;
+        const double cost = t_gemm / (fill < 1.0 ? fill : 1.0) + (sk > 1 ? (double)sk * p.M * p.N * 8.0 / 4e12 + 3e-6 : 0.0);
+        if (cost < best_cost) { best_cost = cost; best = sk; }
+    }
+    return best;
+}
+
 template <typename T, typename TO, int WM, int WN, int TM, int TN>
 static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -482,19 +501,8 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     // split-K for launches that cannot fill the chip: each z-slice owns a K range, partial sums go through the caller's workspace
-    p.splitk = 1;
-    {
-        constexpr int BKE = (sizeof(T) == 2) ? 64 : 32;
-        const int nk = (p.K + BKE - 1) / BKE;
-        const long long tiles = (long long)p.tiles_m * p.tiles_n;
-        if (d->workspace && d->batch == 1 && d->act != RF_ACT_GEGLU && tiles < 200 && nk >= 16) {
-            int sk = (int)(512 / tiles);
-            if (sk > nk / 8) sk = nk / 8;
-            if (sk > 16) sk = 16;
-            while (sk > 1 && (long long)sk * p.M * p.N * 4 > d->workspace_bytes) --sk;
-            if (sk > 1) { p.splitk = sk; p.ws = (float*)d->workspace; }
-        }
-    }
+    p.splitk = pick_splitk(d, p, (long long)p.tiles_m * p.tiles_n, sizeof(T) == 2 ? 64 : 32);
+    if (p.splitk > 1) p.ws = (float*)d->workspace;
     dim3 grid(p.tiles_m * p.tiles_n, d->batch, p.splitk), block(WM * WN * 64);
 #define RF_LAUNCH_VARIANT(CONV_, GLDS_)                                                                                         \
     {                                                                                                                            \
@@ -519,11 +527,18 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
 template <typename T, typename TO>
 static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipStream_t st) {
     const int N = p.N;
-    // big tiles (8 waves, wave tile 64 x 160 / 64 x 128): half the LDS and L2 traffic per FLOP; only when they fill the chip
-    const long long mt256 = (p.M + 255) / 256;
+    // 8-wave blocks with 320- / 256-wide tiles: half the LDS and L2 traffic per FLOP of the 4-wave configs.  Take the tallest
+    // tile (256 rows, wave tile 64 x 160 / 64 x 128) that still gives ~one block per CU, else the 128-row variant.
     if (p.glds && d->batch == 1) {
-        if (d->act != RF_ACT_GEGLU && N % 320 == 0 && mt256 * (N / 320) >= 192) return launch_cfg<T, TO, 4, 2, 2, 5>(d, p, conv, st);
-        if (N % 256 == 0 && mt256 * (N / 256) >= 192) return launch_cfg<T, TO, 4, 2, 2, 4>(d, p, conv, st);
+        const int bk = sizeof(T) == 2 ? 64 : 32;
+        const long long mt256 = (p.M + 255) / 256, mt128 = (p.M + 127) / 128;
+        const bool n320 = d->act != RF_ACT_GEGLU && N % 320 == 0, n256 = N % 256 == 0 && !n320;
+        const long long nt = n320 ? N / 320 : (n256 ? N / 256 : 0);
+        if (nt > 0) {
+            if (mt256 * nt >= 192) return n320 ? launch_cfg<T, TO, 4, 2, 2, 5>(d, p, conv, st) : launch_cfg<T, TO, 4, 2, 2, 4>(d, p, conv, st);
+            if (mt128 * nt * pick_splitk(d, p, mt128 * nt, bk) >= 192)
+                return n320 ? launch_cfg<T, TO, 4, 2, 1, 5>(d, p, conv, st) : launch_cfg<T, TO, 4, 2, 1, 4>(d, p, conv, st);
+        }
     }
     if (d->act == RF_ACT_GEGLU) return launch_cfg<T, TO, 2, 2, 2, 2>(d, p, conv, st);
     if (N <= 64) return launch_cfg<T, TO, 4, 1, 1, 2>(d, p, conv, st);
