@@ -60,6 +60,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     constexpr int QW = 32 * QB;                       // queries per wave
     constexpr int TILE_BYTES = KV_TILE * KROW + DVB * 32 * VROW;      // one stage: K [64][KROW] + V^T [DVB*32][VROW]
     constexpr int NS = (2 * TILE_BYTES <= 160 * 1024) ? 2 : 1;        // double-buffer when it fits (fp32 d=160 does not)
+    // When D leaves a spare (zero-pad) row in the V^T tile, that row is set to all ones: the P V MFMA then also produces
+    // the softmax denominator sum_k P[k, q] (row D of O^T) and the 32 per-tile VALU adds per lane disappear.
+    constexpr bool ONES = (D % 32) != 0;
+    constexpr int L_I = D / 32, L_R = ((D % 32) / 8) * 4;             // accumulator block / register that holds row D (lane half 0)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -96,6 +100,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     }
     // zero the stages once: the pad columns of K / pad rows of V^T are never rewritten
     for (int i = tid; i < NS * TILE_BYTES / 16; i += 256) ((u32x4_t*)smem)[i] = u32x4_t{0u, 0u, 0u, 0u};
+    if constexpr (ONES) {
+        __syncthreads();
+        if (tid < NS * KV_TILE) {
+            const int stg = tid / KV_TILE, kcol = tid - stg * KV_TILE;
+            T one;
+            if constexpr (sizeof(T) == 2) one = (T)0x3f80; else one = 1.0f;
+            *(T*)(smem + stg * TILE_BYTES + KV_TILE * KROW + D * VROW + kcol * (int)sizeof(T)) = one;
+        }
+    }
 
     f32x16_t o[QB][DVB];
 #pragma unroll
@@ -239,9 +252,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
                 for (int r = 0; r < 16; ++r) {
                     const float e = __builtin_amdgcn_exp2f(fmaf(s[qb][kb][r], c2, -mc));
                     s[qb][kb][r] = e;
-                    psum += e;
+                    if constexpr (!ONES) psum += e;
                 }
-            l_run[qb] += psum;
+            if constexpr (!ONES) l_run[qb] += psum;
         }
 
         // ---- O^T += V^T P^T   (each V^T fragment feeds the QB query blocks)
@@ -288,7 +301,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     // ---- normalise and store: lane holds O[q][dv = i*32 + 8*(r>>2) + 4*lh + (r&3)]
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        float l_tot;
+        if constexpr (ONES) l_tot = __shfl(o[qb][L_I][L_R], lq, 64);        // row D of O^T lives in lane half 0
+        else l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
         const float inv = 1.0f / l_tot;
         const int qi = q0 + qb * 32 + lq;
         if (qi < p.Nq) {

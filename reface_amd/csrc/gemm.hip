@@ -56,6 +56,14 @@ template <> struct MmaFrag<float> {
     }
 };
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for vmcnt(0), i.e. for every outstanding
+// global store to be acknowledged (~1-2 us each time in the chunked epilogue)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
 template <typename TO> __device__ __forceinline__ void store_out(TO* p, float v);
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                     stage[rl * BN + (wn * TN + j) * 32 + lrow] = acc[i][j][r];
                 }
     }
-    __syncthreads();
+    lds_barrier();           // LDS-only barrier: the previous chunk's global stores may stay in flight
     const int mch = m0 + ch * ER;
     if (partial_out) {            // split-K: raw fp32 partial sums, coalesced; bias / activation / residual happen in the reduce pass
         constexpr int VPRS = BN / 4;
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             }
         }
     }
-    if (NCH > 1) __syncthreads();
+    if (NCH > 1) lds_barrier();
     }
 }
 
