@@ -115,7 +115,7 @@ __device__ __forceinline__ float erf_rational(float x) {
     b = fmaf(b, x2, -1.68282697438203e-03f);
     b = fmaf(b, x2, -7.37332916720468e-03f);
     b = fmaf(b, x2, -1.42647390514189e-02f);
-    return x * a / b;
+    return x * a * __builtin_amdgcn_rcpf(b);      // b in [-0.0143, -4.4e-2 * ...]: bounded away from 0; v_rcp_f32 is ~1 ulp
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_rational(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + expf(-1.702f * x)); }

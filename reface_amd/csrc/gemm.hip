@@ -344,10 +344,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             const f32x4_t a4 = *(const f32x4_t*)(stage + rl * BN + lv);
             const f32x4_t g4 = *(const f32x4_t*)(stage + rl * BN + lg);
             float v[4];
+            f32x4_t ba = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                if (p.vec_ok) { ba = *(const f32x4_t*)(p.bias + n0 + lv); bg = *(const f32x4_t*)(p.bias + n0 + lg); }
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ba[e] = p.bias[n0 + lv + e]; bg[e] = p.bias[n0 + lg + e]; }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float a_ = a4[e] * p.alpha, g_ = g4[e] * p.alpha;
-                if (p.bias) { a_ += p.bias[n0 + lv + e]; g_ += p.bias[n0 + lg + e]; }
+                const float a_ = a4[e] * p.alpha + ba[e], g_ = g4[e] * p.alpha + bg[e];
                 v[e] = a_ * gelu_erf(g_);
             }
             TO* dst = outp + (long long)row * p.ldo + ocol;
