@@ -242,10 +242,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, p.w_bytes, 0x00020000);
         constexpr int OOB = 0x7fffffff;
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-        auto issue_tiles = [&](int buf) {
+        // byte offsets of this thread's AV + BV 16-byte pieces of the NEXT K tile (computed once per tile, issued in phases)
+        static_assert(AV + BV <= 16, "piece table too small");
+        int offs[16];   // fixed size: a dependent-size array captured by the lambdas below loses the host-side kernel stub (hipcc 7.2)
+        auto prepare_tile = [&]() {
             const bool kval = kvec < p.K;
-            char* a = ldsA + buf * BM * 128 + wave_u * 1024;
-            char* b = ldsB + buf * BN * 128 + wave_u * 1024;
 #pragma unroll
             for (int i = 0; i < AV; ++i) {
                 int off = OOB;
@@ -259,28 +260,57 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 } else {
                     if (kval && a_pix[i] >= 0) off = (a_pix[i] * p.ld0 + kvec) * (int)sizeof(T);
                 }
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(a + i * (RPP * 128)), 16, off, 0, 0, 0);
+                offs[i] = off;
             }
 #pragma unroll
             for (int j = 0; j < BV; ++j) {
                 const int n = n0 + r0 + j * RPP;
-                const int off = (kval && n < p.N) ? (n * p.ldw + kvec) * (int)sizeof(T) : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(b + j * (RPP * 128)), 16, off, 0, 0, 0);
+                offs[AV + j] = (kval && n < p.N) ? (n * p.ldw + kvec) * (int)sizeof(T) : OOB;
             }
             advance_k();
         };
-        // NST-deep ring: tiles kt+1 .. kt+NST-1 are in flight while tile kt is on the matrix cores
+        // issue pieces [q0, q1) of the prepared tile into LDS stage `buf`
+        auto issue_pieces = [&](int buf, int q0, int q1) {
+            char* a = ldsA + buf * BM * 128 + wave_u * 1024;
+            char* b = ldsB + buf * BN * 128 + wave_u * 1024;
 #pragma unroll
-        for (int st = 0; st < NST - 1; ++st)
-            if (st < nk) issue_tiles(st);
+            for (int q = 0; q < AV + BV; ++q) {
+                if (q < q0 || q >= q1) continue;
+                if (q < AV)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(a + q * (RPP * 128)), 16, offs[q], 0, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(b + (q - AV) * (RPP * 128)), 16, offs[q], 0, 0, 0);
+            }
+        };
+        constexpr int NP = AV + BV;
+        // prologue: tile 0 in flight
+        prepare_tile();
+        issue_pieces(0, 0, NP);
         for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt % NST;
-            // wait until tile kt has landed: at most the NST-2 younger tiles of this wave may stay in flight
-            if (kt + NST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (AV + BV)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int buf = kt & 1;
+            const bool more = kt + 1 < nk;
+            if (more) prepare_tile();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();          // tile kt landed for every wave; every wave is done reading tile kt-1
-            if (kt + NST - 1 < nk) issue_tiles((kt + NST - 1) % NST);
-            compute_tile(buf);
+            // four phases: a quarter of the next tile's direct-to-LDS pieces, then this k-step's fragments and MFMAs.
+            // Spreading the DMA issue between the MFMA clusters keeps the matrix pipe fed while the loads are queued.
+            const char* a = ldsA + buf * BM * 128;
+            const char* bb = ldsB + buf * BN * 128;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (more) issue_pieces(buf ^ 1, (kk * NP) / 4, ((kk + 1) * NP) / 4);
+                const int s = kk * 2 + lhalf;
+                u32x4_t fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4_t*)(a + lds_off((wm * TM + i) * 32 + lrow, s));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = *(const u32x4_t*)(bb + lds_off((wn * TN + j) * 32 + lrow, s));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) MmaFrag<T>::mma(acc[i][j], fa[i], fb[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         __syncthreads();
     } else {
