@@ -240,9 +240,15 @@ def main():
         for k, v in dfam.items():
             log(f"   dec {k:24s} calls {v['calls']:4d}  {v['ms']:9.3f} ms  {v['tflops_per_s']:8.1f} TFLOP/s")
         if args.profile_json:
-            slow = sorted(timed, key=lambda x: -x[1])[:40]
+            def row(l, ms):
+                r = {"name": l.name, "family": profiler.launch_family(l), "ms": ms, "flop": profiler.gemm_flops(l) + profiler.attention_flops(l)}
+                if l.fn.__name__ == "rf_conv_gemm":
+                    d = l.keep[0]
+                    r.update(M=d.M, N=d.N, K=d.K, act=d.act, batch=d.batch)
+                return r
             with open(args.profile_json, "w") as f:
-                json.dump({"families": fam, "vae_families": dfam, "top_launches": [(l.name, ms, profiler.gemm_flops(l)) for l, ms in slow]}, f, indent=1)
+                json.dump({"families": fam, "vae_families": dfam, "step_launches": [row(l, ms) for l, ms in timed],
+                           "vae_launches": [row(l, ms) for l, ms in dtimed]}, f, indent=1)
     if want_cpu:
         cores = os.cpu_count() or 1
         try:

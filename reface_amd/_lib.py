@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libreface_hip.so")
+# REFACE_HIP_LIB selects another build of the same library (A/B kernel experiments); there is still no non-HIP fallback.
+LIB_PATH = os.environ.get("REFACE_HIP_LIB") or os.path.join(HERE, "lib", "libreface_hip.so")
 
 RF_F32, RF_BF16 = 0, 1
 ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_PRELU = 0, 1, 2, 3, 4, 5, 6, 7

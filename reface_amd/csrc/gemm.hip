@@ -11,6 +11,8 @@
 // asymmetric padding, nearest x2 upsample folded into the addressing, 2-source channel concat),
 // staged global -> registers -> LDS with the next tile's loads issued before the current tile's
 // MFMAs (one barrier per K-tile, double-buffered LDS).
+#include <type_traits>
+
 #include "common.h"
 
 namespace rf {
@@ -209,11 +211,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     int nk = (p.K + BK - 1) / BK;
+    int kb0_tiles = 0;       // first K tile of this block (split-K)
     if (p.splitk > 1) {          // this block's K-tile range [kb0, kb0 + nk)
         const int per = (nk + p.splitk - 1) / p.splitk;
         const int kb0 = blockIdx.z * per;
         nk = max(0, min(nk, kb0 + per) - kb0);
-        for (int i = 0; i < kb0; ++i) advance_k();
+        kb0_tiles = kb0;
+        if (!GLDS)
+            for (int i = 0; i < kb0; ++i) advance_k();
     }
     const int lrow = lane & 31, lhalf = lane >> 5;
 
@@ -236,81 +241,164 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
     };
 
     if constexpr (GLDS) {
-        // direct global -> LDS staging (buffer_load_dwordx4 ... lds): out-of-range byte offsets return zeros, which gives the
-        // conv zero padding / M, N, K tails for free.  Tile kt+1 streams in while tile kt is on the matrix cores.
+        // Direct global -> LDS staging (buffer_load_dwordx4 ... lds) with a register-level fragment pipeline.
+        // Host guarantees (launch_typed): one source, K % BK == 0 and, for convs, Ctot % BK == 0 with tap-major K -- so a K tile
+        // lies inside ONE filter tap and all of its addresses are  per-lane offset (fixed within a tap) + uniform K offset
+        // (SGPR soffset).  Out-of-range rows / padding taps carry an out-of-range voffset: the buffer range check returns zeros.
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)src0, 0, p.a_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, p.w_bytes, 0x00020000);
         constexpr int OOB = 0x7fffffff;
+        constexpr int NP = AV + BV;
+        static_assert(NP <= 16, "piece table too small");
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-        // byte offsets of this thread's AV + BV 16-byte pieces of the NEXT K tile (computed once per tile, issued in phases)
-        static_assert(AV + BV <= 16, "piece table too small");
-        int offs[16];   // fixed size: a dependent-size array captured by the lambdas below loses the host-side kernel stub (hipcc 7.2)
-        auto prepare_tile = [&]() {
-            const bool kval = kvec < p.K;
+        const int lane_k = slot * VEC * (int)sizeof(T);       // byte offset of this lane's 16-byte K slot inside a K tile
+        int offs[16];        // [0, AV): A pieces, [AV, NP): B pieces (fixed size: see the note on hipcc at `rowd`)
+        unsigned rowd[8];    // CONV: packed (sample << 20 | oy << 10 | ox) of this thread's A rows, ~0u = row beyond M
+        static_assert(AV <= 8, "row table too small");
+#pragma unroll
+        for (int j = 0; j < BV; ++j) {
+            const int n = n0 + r0 + j * RPP;
+            offs[AV + j] = n < p.N ? n * p.ldw * (int)sizeof(T) + lane_k : OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int m = m0 + r0 + i * RPP;
+            if (CONV) {
+                const int hw = p.Hout * p.Wout;
+                const int b = m / hw, rem = m - b * hw;
+                const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+                rowd[i] = m < p.M ? ((unsigned)b << 20 | (unsigned)oy << 10 | (unsigned)ox) : ~0u;
+            } else {
+                offs[i] = m < p.M ? m * p.ld0 * (int)sizeof(T) + lane_k : OOB;
+            }
+        }
+        // A-piece offsets of filter tap (ty, tx): padding / upsampling / stride live here, once per tap
+        auto set_tap = [&](int ty, int tx) {
 #pragma unroll
             for (int i = 0; i < AV; ++i) {
-                int off = OOB;
-                if (CONV) {
-                    int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
-                    const bool ok = kval && a_pix[i] >= 0 && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-                    if (ok) {
-                        if (p.ups) { iy >>= 1; ix >>= 1; }
-                        off = ((a_pix[i] + iy * p.Win + ix) * p.ld0 + cv) * (int)sizeof(T);
-                    }
-                } else {
-                    if (kval && a_pix[i] >= 0) off = (a_pix[i] * p.ld0 + kvec) * (int)sizeof(T);
-                }
-                offs[i] = off;
+                const unsigned d = rowd[i];
+                int iy = (int)((d >> 10) & 1023u) * p.stride - p.pad_t + ty;
+                int ix = (int)(d & 1023u) * p.stride - p.pad_l + tx;
+                const bool ok = d != ~0u && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+                if (p.ups) { iy >>= 1; ix >>= 1; }
+                offs[i] = ok ? (((int)(d >> 20) * p.Hin + iy) * p.Win + ix) * p.ld0 * (int)sizeof(T) + lane_k : OOB;
             }
-#pragma unroll
-            for (int j = 0; j < BV; ++j) {
-                const int n = n0 + r0 + j * RPP;
-                offs[AV + j] = (kval && n < p.N) ? (n * p.ldw + kvec) * (int)sizeof(T) : OOB;
-            }
-            advance_k();
         };
-        // issue pieces [q0, q1) of the prepared tile into LDS stage `buf`
+        // uniform K state of the NEXT tile to issue: absolute tile index, and for convs (tap, channel chunk inside the tap)
+        const int tpt = CONV ? p.Ctot / BK : 1;     // K tiles per tap
+        int it = kb0_tiles, ity = 0, itx = 0, ic = 0;
+        if (CONV) {
+            const int tap = it / tpt;
+            ic = it - tap * tpt;
+            ity = tap / p.KW;
+            itx = tap - ity * p.KW;
+            set_tap(ity, itx);
+        }
+        auto next_tile = [&]() {     // advance the issue state by one K tile
+            ++it;
+            if (CONV && ++ic == tpt) {
+                ic = 0;
+                if (++itx == p.KW) { itx = 0; ++ity; }
+                set_tap(ity, itx);
+            }
+        };
+        // issue pieces [q0, q1) of the issue-state tile into LDS stage `buf`
         auto issue_pieces = [&](int buf, int q0, int q1) {
             char* a = ldsA + buf * BM * 128 + wave_u * 1024;
             char* b = ldsB + buf * BN * 128 + wave_u * 1024;
+            const int soA = (CONV ? ic : it) * 128, soB = it * 128;
 #pragma unroll
-            for (int q = 0; q < AV + BV; ++q) {
-                if (q < q0 || q >= q1) continue;
-                if (q < AV)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(a + q * (RPP * 128)), 16, offs[q], 0, 0, 0);
-                else
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(b + (q - AV) * (RPP * 128)), 16, offs[q], 0, 0, 0);
+            for (int q = 0; q < NP; ++q) {
+                if (q >= q0 && q < q1) {
+                    if (q < AV)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(a + q * (RPP * 128)), 16, offs[q], soA, 0, 0);
+                    else
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(b + (q - AV) * (RPP * 128)), 16, offs[q], soB, 0, 0);
+                }
             }
         };
-        constexpr int NP = AV + BV;
-        // prologue: tile 0 in flight
-        prepare_tile();
-        issue_pieces(0, 0, NP);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            const bool more = kt + 1 < nk;
-            if (more) prepare_tile();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();          // tile kt landed for every wave; every wave is done reading tile kt-1
-            // four phases: a quarter of the next tile's direct-to-LDS pieces, then this k-step's fragments and MFMAs.
-            // Spreading the DMA issue between the MFMA clusters keeps the matrix pipe fed while the loads are queued.
-            const char* a = ldsA + buf * BM * 128;
-            const char* bb = ldsB + buf * BN * 128;
+        // Fragment pipeline: the ds_reads of k-step kk+1 are issued while the MFMAs of k-step kk run, so the matrix pipe does not
+        // wait on LDS latency (all waves of a block are phase-locked by the per-tile barrier, nobody else would cover it).
+        // Small wave tiles keep two full fragment sets; the 2x5 wave tile has no registers for that and rotates its B fragments
+        // in place: column j of the next k-step is fetched right after column j's MFMAs have been issued.
+        constexpr bool ROT = TM * TN > 8;
+        constexpr int JS = ROT ? 2 : 0;      // B columns whose MFMAs go ahead of the first next-fragment reads
+        u32x4_t fa[2][TM], fb[2][TN];
+        const int frag_sw = (lrow >> 1) & 7;
+        int fk[4];           // swizzled byte position of k-step kk inside a fragment row
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                if (more) issue_pieces(buf ^ 1, (kk * NP) / 4, ((kk + 1) * NP) / 4);
-                const int s = kk * 2 + lhalf;
-                u32x4_t fa[TM], fb[TN];
+        for (int kk = 0; kk < 4; ++kk) fk[kk] = ((kk * 2 + lhalf) ^ frag_sw) << 4;
+        // fragment row bases of the stage being multiplied (cur) and of the other stage (oth); swapped after every tile.
+        // The loop body is ONE straight-line block (no per-tile variants): branches around MFMAs make the register allocator
+        // keep two copies of the accumulators.
+        const char* curA = ldsA + (wm * TM) * 4096 + lrow * 128;
+        const char* curB = ldsB + (wn * TN) * 4096 + lrow * 128;
+        const char* othA = curA + BM * 128;
+        const char* othB = curB + BN * 128;
+        // one k-step: its MFMAs, the fetch of the next step's fragments (k-step 3 fetches from the other stage, after the
+        // barrier; on the last tile that fetch reads stale bytes that are never used) and a third of the next tile's pieces
+        auto phase = [&](auto KK, int stage, bool more) {
+            constexpr int kk = decltype(KK)::value;
+            constexpr int cur = kk & 1, nx = cur ^ 1;
+            constexpr int fbc = ROT ? 0 : cur, fbn = ROT ? 0 : nx;
+            constexpr int nkk = (kk + 1) & 3;
+            const char* const nA = (kk < 3 ? curA : othA) + fk[nkk];
+            const char* const nB = (kk < 3 ? curB : othB) + fk[nkk];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4_t*)(a + lds_off((wm * TM + i) * 32 + lrow, s));
+            for (int j = 0; j < JS; ++j)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = *(const u32x4_t*)(bb + lds_off((wn * TN + j) * 32 + lrow, s));
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) MmaFrag<T>::mma(acc[i][j], fa[i], fb[j]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < TM; ++i) MmaFrag<T>::mma(acc[i][j], fa[cur][i], fb[fbc][j]);
+            if (kk == 3) {
+                // own pieces of the next tile have landed and every fragment of this tile is in registers; past the barrier
+                // that holds for all waves: this stage may be overwritten (tile kt+2) and the other stage may be read
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
             }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[nx][i] = *(const u32x4_t*)(nA + i * 4096);
+#pragma unroll
+            for (int j = 0; j < (ROT ? JS : TN); ++j) fb[fbn][j] = *(const u32x4_t*)(nB + j * 4096);
+            if (kk == 3 && more) issue_pieces(stage, 0, NP);      // 'more' here: tile kt+2 exists
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = JS; j < TN; ++j) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) MmaFrag<T>::mma(acc[i][j], fa[cur][i], fb[fbc][j]);
+                if (ROT) {
+                    fb[0][j] = *(const u32x4_t*)(nB + j * 4096);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using std::integral_constant;
+        if (nk > 0) {
+            // prologue: tile 0 lands, its first fragments are fetched, the issue state points at tile 1
+            issue_pieces(0, 0, NP);
+            if (nk > 1) {
+                next_tile();
+                issue_pieces(1, 0, NP);
+                if (nk > 2) next_tile();
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[0][i] = *(const u32x4_t*)(curA + i * 4096 + fk[0]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[0][j] = *(const u32x4_t*)(curB + j * 4096 + fk[0]);
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const int stage = kt & 1;
+            const bool more = kt + 2 < nk;
+            phase(integral_constant<int, 0>{}, stage, more);
+            phase(integral_constant<int, 1>{}, stage, more);
+            phase(integral_constant<int, 2>{}, stage, more);
+            phase(integral_constant<int, 3>{}, stage, more);
+            if (kt + 3 < nk) next_tile();
+            const char* t = curA; curA = othA; othA = t;
+            t = curB; curB = othB; othB = t;
         }
         __syncthreads();
     } else {
@@ -639,12 +727,16 @@ extern "C" int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream) {
         p.vec_ok = ok ? 1 : 0;
     }
     {
-        // direct-to-LDS main loop needs one source and 31-bit byte offsets
+        // direct-to-LDS main loop needs one source, 31-bit byte offsets ...
         const long long es = d->dtype == RF_F32 ? 4 : 2;
         const long long rows_a = conv ? (long long)(d->M / (d->Hout * d->Wout)) * d->Hin * d->Win : d->M;
         const long long ab = ((rows_a - 1) * d->ld0 + (conv ? d->C0 : d->K)) * es;
         const long long wb = ((long long)(d->N - 1) * p.ldw + d->K) * es;
-        p.glds = (d->C1 == 0 && ab < 0x7fff0000LL && wb < 0x7fff0000LL) ? 1 : 0;
+        // ... and K tiles that never straddle a filter tap (uniform K offset per tile; rows packed as sample:12 | oy:10 | ox:10)
+        const int bk = (int)(128 / es);
+        const bool uniform = d->K % bk == 0 && (!conv || (ctot % bk == 0 && d->korder == 0 && d->K == d->KH * d->KW * ctot &&
+                                                         d->Hout <= 1024 && d->Wout <= 1024 && d->M / (d->Hout * d->Wout) < 4095));
+        p.glds = (d->C1 == 0 && uniform && ab < 0x7fff0000LL && wb < 0x7fff0000LL) ? 1 : 0;
         p.korder = d->korder;
         p.a_bytes = (unsigned)(p.glds ? ab : 0);
         p.w_bytes = (unsigned)(p.glds ? wb : 0);

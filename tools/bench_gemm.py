@@ -19,7 +19,8 @@ ap.add_argument("--only", default="")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--bc", type=int, default=16)
 ap.add_argument("--json", default=None)
-ap.add_argument("--korder", type=int, default=1)
+ap.add_argument("--sustain", type=float, default=0.0, help="also report the rate sustained over this many seconds (power-managed clocks)")
+ap.add_argument("--korder", type=int, default=0)
 args = ap.parse_args()
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 dev = "cuda"
@@ -128,7 +129,19 @@ for name, l, work in cases:
         rate, unit = work / us / 1e6, "TFLOP/s"
     else:
         rate, unit = -work / us / 1e3, "GB/s"
+    sus = ""
+    if args.sustain > 0:
+        n = max(10, int(args.sustain * 1e6 / us))
+        for _ in range(n // 2):
+            l()
+        s.record(stream)
+        for _ in range(n // 2):
+            l()
+        e.record(stream)
+        torch.cuda.synchronize()
+        us2 = s.elapsed_time(e) / (n // 2) * 1e3
+        sus = f"   sustained {us2:10.1f} us  {abs(work) / us2 / (1e6 if work > 0 else 1e3):9.1f}"
     results.append(dict(name=name, us=us, rate=rate, unit=unit))
-    print(f"{name:32s} {us:10.1f} us  {rate:9.1f} {unit}", flush=True)
+    print(f"{name:32s} {us:10.1f} us  {rate:9.1f} {unit}{sus}", flush=True)
 if args.json:
     json.dump(results, open(args.json, "w"), indent=1)
