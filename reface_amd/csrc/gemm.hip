@@ -11,6 +11,7 @@
 // asymmetric padding, nearest x2 upsample folded into the addressing, 2-source channel concat),
 // staged global -> registers -> LDS with the next tile's loads issued before the current tile's
 // MFMAs (one barrier per K-tile, double-buffered LDS).
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -505,61 +506,89 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             }
         }
     } else {
+        // thread -> one fixed 4-column segment and every EROWS-th row of the chunk: bias / timestep vector are loaded once, and
+        // the residual loads of U rows are issued together BEFORE the first one is consumed.  (One load -> wait -> store per
+        // row serialises the whole HBM / L2 latency per row: that alone made the K = C projection layers 2x slower in situ.)
         constexpr int VPR = BN / 4;
-        for (int idx = tid; idx < ER * VPR; idx += NT) {
-            const int rl = idx / VPR, cl = (idx - rl * VPR) * 4;
-            const int row = mch + rl, col = n0 + cl;
-            if (row >= p.M || col >= p.N) continue;
-            const f32x4_t a4 = *(const f32x4_t*)(stage + rl * BN + cl);
-            float v[4] = {a4[0] * p.alpha, a4[1] * p.alpha, a4[2] * p.alpha, a4[3] * p.alpha};
-            const float* rv = p.rowvec ? p.rowvec + (long long)(row / p.rows_per_sample) * p.ldv : nullptr;
-            const bool full = p.vec_ok && col + 3 < p.N;
+        constexpr int EROWS = NT / VPR;
+        constexpr int PASSES = (ER + EROWS - 1) / EROWS;
+        constexpr int U = 4;
+        const int cs = tid % VPR, er = tid / VPR;
+        const int cl = cs * 4, col = n0 + cl;
+        const bool t_on = er < EROWS && col < p.N;
+        const bool full = p.vec_ok && col + 3 < p.N;
+        float cadd[4] = {0.f, 0.f, 0.f, 0.f};           // bias (+ per-sample vector when the chunk lies inside one sample)
+        const bool rv_uniform = p.rowvec && (p.rows_per_sample % ER == 0);
+        if (t_on) {
+            const float* rvu = rv_uniform ? p.rowvec + (long long)(mch / p.rows_per_sample) * p.ldv : nullptr;
             if (full) {
-                if (p.bias) { const f32x4_t b4 = *(const f32x4_t*)(p.bias + col); v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3]; }
-                if (rv) { const f32x4_t r4 = *(const f32x4_t*)(rv + col); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
+                if (p.bias) { const f32x4_t b4 = *(const f32x4_t*)(p.bias + col); cadd[0] = b4[0]; cadd[1] = b4[1]; cadd[2] = b4[2]; cadd[3] = b4[3]; }
+                if (rvu) { const f32x4_t r4 = *(const f32x4_t*)(rvu + col); cadd[0] += r4[0]; cadd[1] += r4[1]; cadd[2] += r4[2]; cadd[3] += r4[3]; }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (col + e < p.N) { if (p.bias) v[e] += p.bias[col + e]; if (rv) v[e] += rv[col + e]; }
+                    if (col + e < p.N) { if (p.bias) cadd[e] = p.bias[col + e]; if (rvu) cadd[e] += rvu[col + e]; }
             }
-            if (p.act != RF_ACT_NONE) {
+        }
+        typedef typename std::conditional<sizeof(TO) == 2, u32x2_t, f32x4_t>::type resv_t;
+#pragma unroll 1
+        for (int k0 = 0; k0 < PASSES; k0 += U) {
+            resv_t rq[U];
+            bool ok[U];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float y = v[e];
-                    if (p.act == RF_ACT_SILU) y = silu_exact(y);
-                    else if (p.act == RF_ACT_QUICK_GELU) y = quick_gelu(y);
-                    else if (p.act == RF_ACT_GELU) y = gelu_erf(y);
-                    else if (p.act == RF_ACT_RELU) y = fmaxf(y, 0.0f);
-                    else if (p.act == RF_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
-                    else if (p.act == RF_ACT_PRELU) y = y >= 0.0f ? y : y * p.act_vec[min(col + e, p.N - 1)];
-                    v[e] = y;
-                }
+            for (int u = 0; u < U; ++u) {
+                const int rl = er + (k0 + u) * EROWS, row = mch + rl;
+                ok[u] = t_on && (k0 + u) < PASSES && rl < ER && row < p.M;
+                if (ok[u] && resp && full) rq[u] = *(const resv_t*)(resp + (long long)row * p.ldr + col);
             }
-            TO* dst = outp + (long long)row * p.ldo + col;
-            if (full) {
-                if (resp) {
-                    if constexpr (sizeof(TO) == 2) {
-                        const u32x2_t q = *(const u32x2_t*)(resp + (long long)row * p.ldr + col);
-                        v[0] += as_f32(q[0] << 16); v[1] += as_f32(q[0] & 0xffff0000u); v[2] += as_f32(q[1] << 16); v[3] += as_f32(q[1] & 0xffff0000u);
-                    } else {
-                        const f32x4_t q = *(const f32x4_t*)(resp + (long long)row * p.ldr + col);
-                        v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
-                    }
-                }
-                if constexpr (sizeof(TO) == 2) {
-                    u32x2_t w; w[0] = pack_bf2(v[0], v[1]); w[1] = pack_bf2(v[2], v[3]);
-                    *(u32x2_t*)dst = w;
-                } else {
-                    *(f32x4_t*)dst = f32x4_t{v[0], v[1], v[2], v[3]};
-                }
-            } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (col + e < p.N) {
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
+                const int rl = er + (k0 + u) * EROWS, row = mch + rl;
+                const f32x4_t a4 = *(const f32x4_t*)(stage + rl * BN + cl);
+                float v[4] = {a4[0] * p.alpha + cadd[0], a4[1] * p.alpha + cadd[1], a4[2] * p.alpha + cadd[2], a4[3] * p.alpha + cadd[3]};
+                if (p.rowvec && !rv_uniform) {
+                    const float* rv = p.rowvec + (long long)(row / p.rows_per_sample) * p.ldv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (col + e < p.N) v[e] += rv[col + e];
+                }
+                if (p.act != RF_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
                         float y = v[e];
-                        if (resp) y += load_out<TO>(resp + (long long)row * p.ldr + col + e);
-                        store_out<TO>(dst + e, y);
+                        if (p.act == RF_ACT_SILU) y = silu_exact(y);
+                        else if (p.act == RF_ACT_QUICK_GELU) y = quick_gelu(y);
+                        else if (p.act == RF_ACT_GELU) y = gelu_erf(y);
+                        else if (p.act == RF_ACT_RELU) y = fmaxf(y, 0.0f);
+                        else if (p.act == RF_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
+                        else if (p.act == RF_ACT_PRELU) y = y >= 0.0f ? y : y * p.act_vec[min(col + e, p.N - 1)];
+                        v[e] = y;
                     }
+                }
+                TO* dst = outp + (long long)row * p.ldo + col;
+                if (full) {
+                    if (resp) {
+                        if constexpr (sizeof(TO) == 2) {
+                            v[0] += as_f32(rq[u][0] << 16); v[1] += as_f32(rq[u][0] & 0xffff0000u); v[2] += as_f32(rq[u][1] << 16); v[3] += as_f32(rq[u][1] & 0xffff0000u);
+                        } else {
+                            v[0] += rq[u][0]; v[1] += rq[u][1]; v[2] += rq[u][2]; v[3] += rq[u][3];
+                        }
+                    }
+                    if constexpr (sizeof(TO) == 2) {
+                        u32x2_t w; w[0] = pack_bf2(v[0], v[1]); w[1] = pack_bf2(v[2], v[3]);
+                        *(u32x2_t*)dst = w;
+                    } else {
+                        *(f32x4_t*)dst = f32x4_t{v[0], v[1], v[2], v[3]};
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < p.N) {
+                            float y = v[e];
+                            if (resp) y += load_out<TO>(resp + (long long)row * p.ldr + col + e);
+                            store_out<TO>(dst + e, y);
+                        }
+                }
             }
         }
     }
@@ -660,6 +689,23 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
 template <typename T, typename TO>
 static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipStream_t st) {
     const int N = p.N;
+    {   // experiments: RF_GEMM_CFG=<0..6> forces one tile configuration (GEGLU still needs an even TN)
+        static const int forced_all = [] { const char* e = getenv("RF_GEMM_CFG"); return e ? atoi(e) : -1; }();
+        static const int small_k = [] { const char* e = getenv("RF_SMALLK_K"); return e ? atoi(e) : 0; }();          // K <= this ...
+        static const int small_cfg = [] { const char* e = getenv("RF_SMALLK_CFG"); return e ? atoi(e) : -1; }();     // ... uses this config
+        const int forced = forced_all >= 0 ? forced_all : (p.K <= small_k ? small_cfg : -1);
+        const bool g = d->act == RF_ACT_GEGLU;
+        switch (forced) {
+            case 0: if (!g && p.glds && d->batch == 1) return launch_cfg<T, TO, 4, 2, 2, 5>(d, p, conv, st); break;
+            case 1: if (p.glds && d->batch == 1) return launch_cfg<T, TO, 4, 2, 2, 4>(d, p, conv, st); break;
+            case 2: if (!g && p.glds && d->batch == 1) return launch_cfg<T, TO, 4, 2, 1, 5>(d, p, conv, st); break;
+            case 3: if (p.glds && d->batch == 1) return launch_cfg<T, TO, 4, 2, 1, 4>(d, p, conv, st); break;
+            case 4: return launch_cfg<T, TO, 2, 2, 2, 2>(d, p, conv, st);
+            case 5: return launch_cfg<T, TO, 4, 1, 1, 2>(d, p, conv, st);
+            case 6: if (!g) return launch_cfg<T, TO, 4, 1, 1, 5>(d, p, conv, st); break;
+            default: break;
+        }
+    }
     // 8-wave blocks with 320- / 256-wide tiles: half the LDS and L2 traffic per FLOP of the 4-wave configs.  Take the tallest
     // tile (256 rows, wave tile 64 x 160 / 64 x 128) that still gives ~one block per CU, else the 128-row variant.
     if (p.glds && d->batch == 1) {

@@ -101,6 +101,8 @@ lin("ff2 2560->640 @32", Bc * 1024, 640, 2560)
 lin("geglu 1280->10240 @16", Bc * 256, 10240, 1280, ops.ACT_GEGLU)
 lin("ff2 5120->1280 @16", Bc * 256, 1280, 5120)
 lin("skip1x1 2560->1280 @8", Bc * 64, 1280, 2560)
+lin("proj 640->640 @32", Bc * 1024, 640, 640)
+lin("proj 1280->1280 @16", Bc * 256, 1280, 1280)
 attn("attn d40 N4096", 8, 40, 4096)
 attn("attn d80 N1024", 8, 80, 1024)
 attn("attn d160 N256", 8, 160, 256)
