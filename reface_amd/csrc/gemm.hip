@@ -453,24 +453,29 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             }
         }
     } else if (p.act == RF_ACT_GEGLU) {
+        // same thread -> fixed column mapping as the general path below: the value / gate bias vectors are loaded once
         constexpr int OV = BN / 8;                      // output 4-column vectors per row (N/2 columns)
-        for (int idx = tid; idx < ER * OV; idx += NT) {
-            const int rl = idx / OV, oc = (idx - rl * OV) * 4;
-            const int row = mch + rl;
-            const int lv = (oc >> 5) * 64 + (oc & 31), lg = lv + 32;      // local value / gate columns
-            const int ocol = (n0 >> 1) + oc;
-            if (row >= p.M || n0 + lg >= p.N) continue;
+        constexpr int EROWS = NT / OV;
+        constexpr int PASSES = (ER + EROWS - 1) / EROWS;
+        const int oc = (tid % OV) * 4, er = tid / OV;
+        const int lv = (oc >> 5) * 64 + (oc & 31), lg = lv + 32;      // local value / gate columns
+        const int ocol = (n0 >> 1) + oc;
+        const bool t_on = er < EROWS && n0 + lg < p.N;
+        f32x4_t ba = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+        if (t_on && p.bias) {
+            if (p.vec_ok) { ba = *(const f32x4_t*)(p.bias + n0 + lv); bg = *(const f32x4_t*)(p.bias + n0 + lg); }
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ba[e] = p.bias[n0 + lv + e]; bg[e] = p.bias[n0 + lg + e]; }
+            }
+        }
+#pragma unroll 2
+        for (int k = 0; k < PASSES; ++k) {
+            const int rl = er + k * EROWS, row = mch + rl;
+            if (!t_on || rl >= ER || row >= p.M) continue;
             const f32x4_t a4 = *(const f32x4_t*)(stage + rl * BN + lv);
             const f32x4_t g4 = *(const f32x4_t*)(stage + rl * BN + lg);
             float v[4];
-            f32x4_t ba = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) {
-                if (p.vec_ok) { ba = *(const f32x4_t*)(p.bias + n0 + lv); bg = *(const f32x4_t*)(p.bias + n0 + lg); }
-                else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { ba[e] = p.bias[n0 + lv + e]; bg[e] = p.bias[n0 + lg + e]; }
-                }
-            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float a_ = a4[e] * p.alpha + ba[e], g_ = g4[e] * p.alpha + bg[e];
