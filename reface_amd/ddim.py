@@ -80,11 +80,11 @@ class DDIMSampler(object):
         unet = self.model.model.diffusion_model
         key = (B, H, W, cfg_on, float(scale), with_noise, unet.compute_dtype, id(unet))
         plan = self._plans.get(key)
-        if plan is not None and plan["eng"] is unet.engine(B * (2 if cfg_on else 1), H, W, uniform_t=True):
+        if plan is not None and plan["eng"] is unet.engine(B * (2 if cfg_on else 1), H, W, uniform_t=True, cfg_pair=cfg_on):
             return plan
         dev = self.model.device
         nb = B * (2 if cfg_on else 1)
-        eng = unet.engine(nb, H, W, uniform_t=True)
+        eng = unet.engine(nb, H, W, uniform_t=True, cfg_pair=cfg_on)
         img = torch.empty((B, 4, H, W), dtype=F32, device=dev)
         z = torch.empty((B, 4, H, W), dtype=F32, device=dev)
         m = torch.empty((B, 1, H, W), dtype=F32, device=dev)

@@ -61,9 +61,13 @@ class UNetEngine:
 
     CPAD = 16      # 9 input channels stored in 16 (multiple of the 16-byte vector for both dtypes)
 
-    def __init__(self, sd, cfg: UNetConfig, B, H, W, dtype, device, uniform_t=False, emb_rows=None):
+    def __init__(self, sd, cfg: UNetConfig, B, H, W, dtype, device, uniform_t=False, emb_rows=None, cfg_pair=False):
         self.cfg, self.B, self.H, self.W, self.dt, self.dev = cfg, B, H, W, dtype, device
         self.uniform_t = uniform_t
+        # cfg_pair: the caller guarantees that samples [0, B/2) and [B/2, B) carry the SAME x and timestep and differ only in
+        # the context (classifier-free guidance, ddim.py:330-341).  Everything upstream of the first cross-attention is then
+        # computed once for B/2 samples -- bit-identical to computing it twice.
+        self.cfg_pair = bool(cfg_pair) and uniform_t and B % 2 == 0
         self.pool = _Pool(device)
         self.sd = {k: v.detach().to(device=device, dtype=F32) for k, v in sd.items()}
         self.plan = unet_plan(cfg)
@@ -183,7 +187,7 @@ class UNetEngine:
         h1 = self.pool.get((B, H, W, cout), self.dt)
         rv = self.emb_vec(p)
         if self.uniform_t:
-            rv = rv.as_strided((B, cout), (0, 1), rv.storage_offset())      # every sample reads row 0
+            rv = rv.as_strided((B, cout), (0, 1), rv.storage_offset())      # every sample reads row 0 (B = this input's batch)
         self.main.append(ops.conv2d(t1, ops.pack_conv_weight(self.sd[f"{p}.in_layers.2.weight"], self.dt), h1,
                                     self.f32(f"{p}.in_layers.2.bias"), rowvec=rv, name=f"{p}.in_layers.2"))
         self.pool.put(t1)
@@ -203,10 +207,13 @@ class UNetEngine:
             self.pool.put(skip)
         return y
 
-    def _st(self, p, x, c, heads, dst):
+    def _st(self, p, x, c, heads, dst, pair=False):
+        """SpatialTransformer (attention.py:218-289).  pair=True: ``x`` holds B/2 samples shared by both CFG halves; the block
+        runs on B/2 samples up to the self-attention and fans out to the full batch where the context enters."""
         B, H, W, _ = x.shape
         M, d = B * H * W, c // heads
         t = f"{p}.transformer_blocks.0"
+        nb = 2 if pair else 1                   # batch fan-out at the cross-attention
         g = self._gn(x, f"{p}.norm", 1e-6, False)
         tok = self.pool.get((M, c), self.dt)
         self.main.append(ops.linear(g.view(M, c), self.w(f"{p}.proj_in.weight").reshape(c, c), tok, self.f32(f"{p}.proj_in.bias"),
@@ -221,29 +228,40 @@ class UNetEngine:
         q3 = qkv.view(B, H * W, 3 * c)
         self.main.append(ops.attention(q3[..., :c], q3[..., c:2 * c], q3[..., 2 * c:], att.view(B, H * W, c), heads=heads,
                                        scale=d ** -0.5, name=f"{t}.attn1"))
-        x1 = self.pool.get((M, c), self.dt)
-        # attn1 out-projection + residual + the (token-independent) cross-attention output
-        self.main.append(ops.linear(att, self.w(f"{t}.attn1.to_out.0.weight"), x1, self.f32(f"{t}.attn1.to_out.0.bias"), residual=tok,
-                                    rowvec=self.ctx_vec(p), rows_per_sample=H * W, name=f"{t}.attn1.to_out"))
+        x1 = self.pool.get((nb * M, c), self.dt)
+        # attn1 out-projection + residual + the (token-independent) cross-attention output; with pair=True one launch per CFG
+        # half: same A and residual, that half's context vectors
+        w_out, b_out, cv = self.w(f"{t}.attn1.to_out.0.weight"), self.f32(f"{t}.attn1.to_out.0.bias"), self.ctx_vec(p)
+        for hf in range(nb):
+            self.main.append(ops.linear(att, w_out, x1[hf * M:(hf + 1) * M], b_out, residual=tok, rowvec=cv[hf * B:(hf + 1) * B],
+                                        rows_per_sample=H * W, name=f"{t}.attn1.to_out"))
         self.pool.put(qkv)
         self.pool.put(tok)
+        if pair:
+            self.pool.put(ln)
+            ln = self.pool.get((nb * M, c), self.dt)
         self.main.append(ops.layernorm(x1, self.f32(f"{t}.norm3.weight"), self.f32(f"{t}.norm3.bias"), ln, name=f"{t}.norm3"))
         wg, bg = ops.pack_geglu(self.sd[f"{t}.ff.net.0.proj.weight"], self.sd[f"{t}.ff.net.0.proj.bias"], self.dt)
-        gg = self.pool.get((M, 4 * c), self.dt)
+        gg = self.pool.get((nb * M, 4 * c), self.dt)
         self.main.append(ops.linear(ln, wg, gg, bg, act=ops.ACT_GEGLU, name=f"{t}.ff.net.0"))
         x2 = ln
         self.main.append(ops.linear(gg, self.w(f"{t}.ff.net.2.weight"), x2, self.f32(f"{t}.ff.net.2.bias"), residual=x1, name=f"{t}.ff.net.2"))
         self.pool.put(gg)
         self.pool.put(x1)
-        y = dst if dst is not None else self.pool.get((B, H, W, c), self.dt)
-        self.main.append(ops.conv2d(x2.view(B, H, W, c), self.w(f"{p}.proj_out.weight").reshape(c, c), y, self.f32(f"{p}.proj_out.bias"),
-                                    ksize=1, pad=(0, 0), residual=x, name=f"{p}.proj_out"))
+        y = dst if dst is not None else self.pool.get((nb * B, H, W, c), self.dt)
+        w_po, b_po = self.w(f"{p}.proj_out.weight").reshape(c, c), self.f32(f"{p}.proj_out.bias")
+        for hf in range(nb):        # the residual x is shared by both halves
+            self.main.append(ops.conv2d(x2.view(nb * B, H, W, c)[hf * B:(hf + 1) * B], w_po, y[hf * B:(hf + 1) * B], b_po,
+                                        ksize=1, pad=(0, 0), residual=x, name=f"{p}.proj_out"))
         self.pool.put(x2)
         return y
 
     def _block(self, prefix, layers, x, dst):
         """TimestepEmbedSequential (openaimodel.py:80-88); the last layer writes into ``dst``."""
         B = self.B
+        pair = False
+        if self.cfg_pair and prefix == "input_blocks.1" and [l[0] for l in layers] == ["res", "st"]:
+            x, pair, B = x[:B // 2], True, B // 2          # both halves of x are identical: work on one
         for j, l in enumerate(layers):
             p = f"{prefix}.{j}"
             last = j == len(layers) - 1
@@ -256,7 +274,7 @@ class UNetEngine:
             elif l[0] == "res":
                 y = self._res(p, x, l[1], l[2], d)
             elif l[0] == "st":
-                y = self._st(p, x, l[1], l[2], d)
+                y = self._st(p, x, l[1], l[2], d, pair=pair)
             elif l[0] == "down":
                 y = d if d is not None else self.pool.get((B, H // 2, W // 2, l[1]), self.dt)
                 self.main.append(ops.conv2d(x, ops.pack_conv_weight(self.sd[f"{p}.op.weight"], self.dt), y, self.f32(f"{p}.op.bias"),
@@ -379,15 +397,16 @@ class UNetModel(nn.Module):
         self.compute_dtype = dtype
         self._engines.clear()
 
-    def engine(self, B, H, W, uniform_t=False, emb_rows=None):
+    def engine(self, B, H, W, uniform_t=False, emb_rows=None, cfg_pair=False):
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("reface_amd.UNetModel runs on the GPU only (HIP kernels; there is no CPU fallback)")
-        key = (B, H, W, self.compute_dtype, uniform_t, emb_rows, weights_version(self))
+        key = (B, H, W, self.compute_dtype, uniform_t, emb_rows, bool(cfg_pair), weights_version(self))
         eng = self._engines.get(key)
         if eng is None:
             self._engines = {k: v for k, v in self._engines.items() if k[-1] == key[-1]}   # drop engines of stale weights
-            eng = UNetEngine(flat_state(self), self.cfg, B, H, W, self.compute_dtype, dev, uniform_t=uniform_t, emb_rows=emb_rows)
+            eng = UNetEngine(flat_state(self), self.cfg, B, H, W, self.compute_dtype, dev, uniform_t=uniform_t, emb_rows=emb_rows,
+                             cfg_pair=cfg_pair)
             self._engines[key] = eng
         return eng
 
