@@ -15,6 +15,7 @@
 #include "common.h"
 
 namespace rf {
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 template <typename T> struct AttnMma;
 template <> struct AttnMma<bf16_t> {
@@ -249,10 +250,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(fmaf(s[qb][kb][r], c2, -mc));
-                    s[qb][kb][r] = e;
-                    if constexpr (!ONES) psum += e;
+                for (int r = 0; r < 16; r += 2) {
+                    // two scores per v_pk_fma_f32 (the softmax is VALU-bound at d = 40: every instruction counts)
+                    const f32x2_t a = __builtin_elementwise_fma(f32x2_t{s[qb][kb][r], s[qb][kb][r + 1]}, f32x2_t{c2, c2}, f32x2_t{-mc, -mc});
+                    const float e0 = __builtin_amdgcn_exp2f(a[0]), e1 = __builtin_amdgcn_exp2f(a[1]);
+                    s[qb][kb][r] = e0;
+                    s[qb][kb][r + 1] = e1;
+                    if constexpr (!ONES) psum += e0 + e1;
                 }
             if constexpr (!ONES) l_run[qb] += psum;
         }

@@ -287,20 +287,28 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         };
         // uniform K state of the NEXT tile to issue: absolute tile index, and for convs (tap, channel chunk inside the tap)
         const int tpt = CONV ? p.Ctot / BK : 1;     // K tiles per tap
+        // korder 1 (channel-chunk-major K): the KH*KW taps of one BK-channel chunk are consecutive tiles, so the ~BM x 128 B of A
+        // that a block touches per chunk stay L2-resident across the taps (tap-major K sweeps all channels between reuses)
         int it = kb0_tiles, ity = 0, itx = 0, ic = 0;
         if (CONV) {
-            const int tap = it / tpt;
-            ic = it - tap * tpt;
+            const int ntap = p.KH * p.KW;
+            const int tap = p.korder ? it % ntap : it / tpt;
+            ic = p.korder ? it / ntap : it - tap * tpt;
             ity = tap / p.KW;
             itx = tap - ity * p.KW;
             set_tap(ity, itx);
         }
         auto next_tile = [&]() {     // advance the issue state by one K tile
             ++it;
-            if (CONV && ++ic == tpt) {
-                ic = 0;
-                if (++itx == p.KW) { itx = 0; ++ity; }
-                set_tap(ity, itx);
+            if (CONV) {
+                if (p.korder) {
+                    if (++itx == p.KW) { itx = 0; if (++ity == p.KH) { ity = 0; ++ic; } }
+                    set_tap(ity, itx);
+                } else if (++ic == tpt) {
+                    ic = 0;
+                    if (++itx == p.KW) { itx = 0; ++ity; }
+                    set_tap(ity, itx);
+                }
             }
         };
         // issue pieces [q0, q1) of the issue-state tile into LDS stage `buf`
@@ -785,7 +793,7 @@ extern "C" int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream) {
         const long long wb = ((long long)(d->N - 1) * p.ldw + d->K) * es;
         // ... and K tiles that never straddle a filter tap (uniform K offset per tile; rows packed as sample:12 | oy:10 | ox:10)
         const int bk = (int)(128 / es);
-        const bool uniform = d->K % bk == 0 && (!conv || (ctot % bk == 0 && d->korder == 0 && d->K == d->KH * d->KW * ctot &&
+        const bool uniform = d->K % bk == 0 && (!conv || (ctot % bk == 0 && d->K == d->KH * d->KW * ctot &&
                                                          d->Hout <= 1024 && d->Wout <= 1024 && d->M / (d->Hout * d->Wout) < 4095));
         p.glds = (d->C1 == 0 && uniform && ab < 0x7fff0000LL && wb < 0x7fff0000LL) ? 1 : 0;
         p.korder = d->korder;

@@ -22,6 +22,8 @@ the reference's ``state_dict`` names.  The arithmetic is a prepared list of kern
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -68,6 +70,7 @@ class UNetEngine:
         # the context (classifier-free guidance, ddim.py:330-341).  Everything upstream of the first cross-attention is then
         # computed once for B/2 samples -- bit-identical to computing it twice.
         self.cfg_pair = bool(cfg_pair) and uniform_t and B % 2 == 0
+        self.korder_on = os.environ.get("REFACE_KORDER", "0") == "1"
         self.pool = _Pool(device)
         self.sd = {k: v.detach().to(device=device, dtype=F32) for k, v in sd.items()}
         self.plan = unet_plan(cfg)
@@ -175,6 +178,12 @@ class UNetEngine:
         return self.ctx_table[:, off:off + c]
 
     # ------------------------------------------------------------------ main graph
+    def _conv3(self, x, wkey, out, bkey, name, **kw):
+        """3x3 conv launch; K order chosen per layer (ops.conv_korder)."""
+        cin = x.shape[3]
+        ko = ops.conv_korder(cin, self.dt) if self.korder_on else 0
+        return ops.conv2d(x, ops.pack_conv_weight(self.sd[wkey], self.dt, korder=ko), out, self.f32(bkey), korder=ko, name=name, **kw)
+
     def _gn(self, x, key, eps, silu):
         out = self.pool.get(tuple(x.shape), self.dt)
         self.main += ops.groupnorm(x, self.f32(key + ".weight"), self.f32(key + ".bias"), out, self.gn_partial, eps=eps,
@@ -188,8 +197,7 @@ class UNetEngine:
         rv = self.emb_vec(p)
         if self.uniform_t:
             rv = rv.as_strided((B, cout), (0, 1), rv.storage_offset())      # every sample reads row 0 (B = this input's batch)
-        self.main.append(ops.conv2d(t1, ops.pack_conv_weight(self.sd[f"{p}.in_layers.2.weight"], self.dt), h1,
-                                    self.f32(f"{p}.in_layers.2.bias"), rowvec=rv, name=f"{p}.in_layers.2"))
+        self.main.append(self._conv3(t1, f"{p}.in_layers.2.weight", h1, f"{p}.in_layers.2.bias", f"{p}.in_layers.2", rowvec=rv))
         self.pool.put(t1)
         t2 = self._gn(h1, f"{p}.out_layers.0", 1e-5, True)
         self.pool.put(h1)
@@ -200,8 +208,7 @@ class UNetEngine:
         else:
             skip = x
         y = dst if dst is not None else self.pool.get((B, H, W, cout), self.dt)
-        self.main.append(ops.conv2d(t2, ops.pack_conv_weight(self.sd[f"{p}.out_layers.3.weight"], self.dt), y,
-                                    self.f32(f"{p}.out_layers.3.bias"), residual=skip, name=f"{p}.out_layers.3"))
+        self.main.append(self._conv3(t2, f"{p}.out_layers.3.weight", y, f"{p}.out_layers.3.bias", f"{p}.out_layers.3", residual=skip))
         self.pool.put(t2)
         if cin != cout:
             self.pool.put(skip)
@@ -277,12 +284,10 @@ class UNetEngine:
                 y = self._st(p, x, l[1], l[2], d, pair=pair)
             elif l[0] == "down":
                 y = d if d is not None else self.pool.get((B, H // 2, W // 2, l[1]), self.dt)
-                self.main.append(ops.conv2d(x, ops.pack_conv_weight(self.sd[f"{p}.op.weight"], self.dt), y, self.f32(f"{p}.op.bias"),
-                                            stride=2, name=f"{p}.op"))
+                self.main.append(self._conv3(x, f"{p}.op.weight", y, f"{p}.op.bias", f"{p}.op", stride=2))
             elif l[0] == "up":
                 y = d if d is not None else self.pool.get((B, 2 * H, 2 * W, l[1]), self.dt)
-                self.main.append(ops.conv2d(x, ops.pack_conv_weight(self.sd[f"{p}.conv.weight"], self.dt), y, self.f32(f"{p}.conv.bias"),
-                                            ups=1, name=f"{p}.conv"))
+                self.main.append(self._conv3(x, f"{p}.conv.weight", y, f"{p}.conv.bias", f"{p}.conv", ups=1))
             else:
                 raise ValueError(l)
             if j > 0 and x is not None:
