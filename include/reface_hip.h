@@ -79,9 +79,20 @@ typedef struct rf_conv_gemm_desc {
     int32_t korder;       /* 0: k = tap*(C0+C1) + c;  1: k = ((c / BK)*KH*KW + tap)*BK + c % BK, BK = 64 (bf16) / 32 (fp32) */
     void* workspace;      /* optional fp32 scratch for split-K (small-M / long-K problems that cannot fill 256 CUs); NULL = never split */
     int64_t workspace_bytes;
+    int32_t gn_rows;      /* > 0: also emit GroupNorm(32) partial sums of `out` (rows per sample = H*W) for up to two consumers, see below */
+    double* gn_part0;     /* consumer 0: [M / gn_rows][gn_nchunks0][32][2] fp64 (sum, sumsq) in the rf_groupnorm_stats layout, or NULL */
+    int32_t gn_cpg0, gn_coff0, gn_slot0, gn_nchunks0;   /* its channels per group, position of out column 0 in its channel space, first chunk slot, chunk slots per sample */
+    double* gn_part1;     /* consumer 1 (e.g. the decoder norm over [h | skip], which groups the same channels differently), or NULL */
+    int32_t gn_cpg1, gn_coff1, gn_slot1, gn_nchunks1;
 } rf_conv_gemm_desc;
 
 int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream);
+
+/* The tile plan rf_conv_gemm would use for `d` (block rows / columns, split-K factor); no launch.  Fused GroupNorm statistics
+ * (gn_rows > 0) need splitk == 1 and gn_rows % bm == 0; a launch then writes (gn_rows / bm) * ceil(N / bn) chunk slots per sample,
+ * slot = gn_slot + (row tile within the sample) * ceil(N / bn) + column tile.  Replaces the separate statistics pass of
+ * nn.GroupNorm (util.py:214-216) over a tensor this GEMM has just produced. */
+int rf_conv_gemm_plan(const rf_conv_gemm_desc* d, int32_t* bm, int32_t* bn, int32_t* splitk);
 
 /*
  * GroupNorm(32 groups) over channels-last [B, HW, C]  (+ optional SiLU), two launches:

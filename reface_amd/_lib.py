@@ -32,6 +32,9 @@ class ConvGemmDesc(C.Structure):
         ("sA", C.c_int64), ("sW", C.c_int64), ("sO", C.c_int64), ("sR", C.c_int64),
         ("act_vec", C.c_void_p), ("korder", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("gn_rows", C.c_int32),
+        ("gn_part0", C.c_void_p), ("gn_cpg0", C.c_int32), ("gn_coff0", C.c_int32), ("gn_slot0", C.c_int32), ("gn_nchunks0", C.c_int32),
+        ("gn_part1", C.c_void_p), ("gn_cpg1", C.c_int32), ("gn_coff1", C.c_int32), ("gn_slot1", C.c_int32), ("gn_nchunks1", C.c_int32),
     ]
 
 
@@ -39,6 +42,7 @@ _SIGS = {
     "rf_last_error": (C.c_char_p, []),
     "rf_version": (C.c_int, []),
     "rf_conv_gemm": (C.c_int, [C.POINTER(ConvGemmDesc), C.c_void_p]),
+    "rf_conv_gemm_plan": (C.c_int, [C.POINTER(ConvGemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rf_groupnorm_stats": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "rf_groupnorm_apply": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

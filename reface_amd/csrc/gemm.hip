@@ -43,6 +43,11 @@ struct GemmParams {
     int vec_ok;      // epilogue may use 16-byte (fp32) / 8-byte (bf16) vector accesses
     int splitk;      // > 1: blockIdx.z owns a K range and writes raw fp32 partial sums to `ws` (epilogue in splitk_reduce_kernel)
     float* ws;       // [splitk][M][N] fp32
+    // fused GroupNorm statistics of `out` (rf_conv_gemm_desc.gn_*): up to two consumers with their own channel grouping
+    int gn_rows;
+    double* gn_part[2];
+    int gn_cpg[2], gn_coff[2], gn_slot[2], gn_nch[2];
+    int* plan;       // host only: {BM, BN, splitk} requested by rf_conv_gemm_plan (no launch)
 };
 
 template <typename T> struct MmaFrag;
@@ -431,6 +436,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
     TO* outp = (TO*)p.out + zb * p.sO;
     const TO* resp = p.residual ? (const TO*)p.residual + zb * p.sR : nullptr;
     const bool partial_out = p.splitk > 1;
+    const bool gn_on = p.gn_rows > 0;          // fused GroupNorm statistics of the values this block writes
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f}, gsq[4] = {0.f, 0.f, 0.f, 0.f};      // this thread's 4 columns, all of its rows
     for (int ch = 0; ch < NCH; ++ch) {
     if (NCH == 1 || wm == ch) {
 #pragma unroll
@@ -525,7 +532,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         constexpr int VPR = BN / 4;
         constexpr int EROWS = NT / VPR;
         constexpr int PASSES = (ER + EROWS - 1) / EROWS;
-        constexpr int U = 4;
+        constexpr int U = sizeof(TO) == 2 ? 4 : 2;      // rows of residual loads in flight (fp32 rows cost 4 registers each)
         const int cs = tid % VPR, er = tid / VPR;
         const int cl = cs * 4, col = n0 + cl;
         const bool t_on = er < EROWS && col < p.N;
@@ -587,6 +594,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                             v[0] += rq[u][0]; v[1] += rq[u][1]; v[2] += rq[u][2]; v[3] += rq[u][3];
                         }
                     }
+                    if (gn_on) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { gsum[e] += v[e]; gsq[e] += v[e] * v[e]; }
+                    }
                     if constexpr (sizeof(TO) == 2) {
                         u32x2_t w; w[0] = pack_bf2(v[0], v[1]); w[1] = pack_bf2(v[2], v[3]);
                         *(u32x2_t*)dst = w;
@@ -599,6 +610,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                         if (col + e < p.N) {
                             float y = v[e];
                             if (resp) y += load_out<TO>(resp + (long long)row * p.ldr + col + e);
+                            if (gn_on) { gsum[e] += y; gsq[e] += y * y; }
                             store_out<TO>(dst + e, y);
                         }
                 }
@@ -606,6 +618,36 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         }
     }
     if (NCH > 1) lds_barrier();
+    }
+    if (gn_on) {
+        // column sums of the tile: [EROWS][BN] per-thread partials -> 32 group sums per consumer -> one chunk slot (fp64)
+        constexpr int VPR = BN / 4, EROWS = NT / VPR;
+        float* const cs = stage;                       // [2][EROWS][BN]
+        if (NCH == 1) lds_barrier();                   // every thread is done with the staged tile
+        const int cs_ = tid % VPR, er = tid / VPR;
+        if (er < EROWS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                cs[er * BN + cs_ * 4 + e] = gsum[e];
+                cs[(EROWS + er) * BN + cs_ * 4 + e] = gsq[e];
+            }
+        }
+        lds_barrier();
+        if (tid < 64) {
+            const int c = tid >> 5, g = tid & 31;
+            if (p.gn_part[c]) {
+                const int cpg = p.gn_cpg[c], base = p.gn_coff[c] + n0;            // consumer channel of local column 0
+                const int lo = max(0, g * cpg - base), hi = min(min(BN, p.N - n0), (g + 1) * cpg - base);
+                double sa = 0.0, sq = 0.0;
+                for (int k = lo; k < hi; ++k)
+#pragma unroll
+                    for (int r = 0; r < EROWS; ++r) { sa += (double)cs[r * BN + k]; sq += (double)cs[(EROWS + r) * BN + k]; }
+                const int b = m0 / p.gn_rows, mt = (m0 - b * p.gn_rows) / BM;
+                double* o = p.gn_part[c] + (((long long)b * p.gn_nch[c] + p.gn_slot[c] + mt * p.tiles_n + tile_n) * 32 + g) * 2;
+                o[0] = sa;
+                o[1] = sq;
+            }
+        }
     }
 }
 
@@ -678,6 +720,16 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     // split-K for launches that cannot fill the chip: each z-slice owns a K range, partial sums go through the caller's workspace
     p.splitk = pick_splitk(d, p, (long long)p.tiles_m * p.tiles_n, sizeof(T) == 2 ? 64 : 32);
     if (p.splitk > 1) p.ws = (float*)d->workspace;
+    if (p.plan) { p.plan[0] = BM; p.plan[1] = BN; p.plan[2] = p.splitk; return 0; }
+    if (p.gn_rows > 0) {
+        RF_CHECK(p.splitk == 1 && p.gn_rows % BM == 0 && p.M % p.gn_rows == 0 && d->batch == 1 && d->act != RF_ACT_GEGLU,
+                 "rf_conv_gemm: fused GroupNorm statistics need splitk == 1 (%d), gn_rows %% %d == 0 (%d), batch 1, no GEGLU -- ask rf_conv_gemm_plan",
+                 p.splitk, BM, p.gn_rows);
+        for (int c = 0; c < 2; ++c)
+            RF_CHECK(!p.gn_part[c] || (p.gn_cpg[c] > 0 && p.gn_slot[c] >= 0 && p.gn_slot[c] + (p.gn_rows / BM) * p.tiles_n <= p.gn_nch[c]),
+                     "rf_conv_gemm: GroupNorm consumer %d: cpg=%d slot=%d needs %d slots of %d", c, p.gn_cpg[c], p.gn_slot[c],
+                     (p.gn_rows / BM) * p.tiles_n, p.gn_nch[c]);
+    }
     dim3 grid(p.tiles_m * p.tiles_n, d->batch, p.splitk), block(WM * WN * 64);
 #define RF_LAUNCH_VARIANT(CONV_, GLDS_)                                                                                         \
     {                                                                                                                            \
@@ -741,7 +793,7 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
 
 }  // namespace rf
 
-extern "C" int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream) {
+static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
     using namespace rf;
     RF_CHECK(d != nullptr, "rf_conv_gemm: null descriptor");
     RF_CHECK(d->dtype == RF_F32 || d->dtype == RF_BF16, "rf_conv_gemm: bad dtype %d", d->dtype);
@@ -776,6 +828,11 @@ extern "C" int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream) {
     p.W = d->W; p.ldw = d->ldw > 0 ? d->ldw : d->K; p.bias = d->bias; p.rowvec = d->rowvec; p.rows_per_sample = d->rows_per_sample; p.ldv = d->ldv;
     p.residual = d->residual; p.ldr = d->ldr; p.act = d->act; p.act_vec = d->act_vec; p.out = d->out; p.ldo = d->ldo; p.alpha = d->alpha;
     p.sA = d->sA; p.sW = d->sW; p.sO = d->sO; p.sR = d->sR;
+    p.gn_rows = (d->gn_part0 || d->gn_part1) ? d->gn_rows : 0;
+    p.gn_part[0] = d->gn_part0; p.gn_cpg[0] = d->gn_cpg0; p.gn_coff[0] = d->gn_coff0; p.gn_slot[0] = d->gn_slot0; p.gn_nch[0] = d->gn_nchunks0;
+    p.gn_part[1] = d->gn_part1; p.gn_cpg[1] = d->gn_cpg1; p.gn_coff[1] = d->gn_coff1; p.gn_slot[1] = d->gn_slot1; p.gn_nch[1] = d->gn_nchunks1;
+    p.plan = plan;
+    RF_CHECK(!(d->gn_part0 || d->gn_part1) || d->gn_rows > 0, "rf_conv_gemm: gn_part set but gn_rows = %d", d->gn_rows);
     {
         const uintptr_t oa = d->out_dtype == RF_F32 ? 16 : 8;
         const int nout = d->act == RF_ACT_GEGLU ? d->N / 2 : d->N;
@@ -807,4 +864,15 @@ extern "C" int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream) {
     }
     if (d->out_dtype == RF_F32) return launch_typed<bf16_t, float>(d, p, conv, st);
     return launch_typed<bf16_t, bf16_t>(d, p, conv, st);
+}
+
+extern "C" int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream) { return conv_gemm_impl(d, stream, nullptr); }
+
+extern "C" int rf_conv_gemm_plan(const rf_conv_gemm_desc* d, int32_t* bm, int32_t* bn, int32_t* splitk) {
+    using namespace rf;
+    RF_CHECK(bm && bn && splitk, "rf_conv_gemm_plan: null output");
+    int plan[3] = {0, 0, 0};
+    const int rc = conv_gemm_impl(d, nullptr, plan);
+    *bm = plan[0]; *bn = plan[1]; *splitk = plan[2];
+    return rc;
 }

@@ -165,6 +165,7 @@ def conv2d(x, W, out, bias=None, *, ksize=3, stride=1, pad=(1, 1), ups=0, x2=Non
 
 
 GN_MAX_CHUNKS = 32
+GN_FUSED_MAX_CHUNKS = 96     # chunk slots per sample a GEMM-fused statistics buffer may have
 
 
 def gn_chunks(B, HW):
@@ -189,6 +190,68 @@ def groupnorm(x, gamma, beta, out, partial, *, eps, silu, name="groupnorm"):
                                         float(eps), int(bool(silu)), code(out.dtype), _p(out), out.stride(2)),
                (x, partial, gamma, beta, out), name + ".apply")
     return [a, b]
+
+
+def gemm_plan(launch):
+    """(block rows, block columns, split-K factor) rf_conv_gemm will use for this prepared launch."""
+    lib = _lib.load()
+    bm, bn, sk = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    _lib.check(lib.rf_conv_gemm_plan(C.byref(launch.keep[0]), C.byref(bm), C.byref(bn), C.byref(sk)), launch.name + ".plan")
+    return bm.value, bn.value, sk.value
+
+
+def fuse_groupnorm_stats(x, producers):
+    """Let the GEMMs that wrote ``x`` [B, H, W, C] also emit its GroupNorm(32) partial sums.
+
+    ``producers``: [(launch, row0, rows, col0, cols)] -- prepared rf_conv_gemm launches that together tile the [B*H*W, C] matrix
+    (column slices of a concat buffer, batch halves).  Returns (partial, nchunks) for groupnorm_apply, or None when some
+    producer cannot do it (split-K plan, tile rows straddling samples, GEGLU, both consumer slots taken, uneven tiling).
+    """
+    B, H, W_, Cc = x.shape
+    HW, M = H * W_, B * H * W_
+    if Cc % 32 or sum(r * c for _, _, r, _, c in producers) != M * Cc:
+        return None
+    plans, slot_of, nslots = [], {}, 0
+    for l, row0, rows, col0, cols in producers:
+        d = l.keep[0]
+        if l.fn.__name__ != "rf_conv_gemm" or d.act == ACT_GEGLU or d.batch != 1 or (d.gn_part0 and d.gn_part1):
+            return None
+        if row0 % HW or rows % HW or d.M != rows or d.N != cols:
+            return None
+        bm, bn, sk = gemm_plan(l)
+        if sk != 1 or HW % bm:
+            return None
+        per_sample = (HW // bm) * ((cols + bn - 1) // bn)
+        key = (col0, cols)
+        if key not in slot_of:                  # batch slices of one column range share the slot numbering
+            slot_of[key] = (nslots, per_sample)
+            nslots += per_sample
+        elif slot_of[key][1] != per_sample:
+            return None
+        plans.append((l, row0, key))
+    if nslots > GN_FUSED_MAX_CHUNKS:
+        return None
+    partial = torch.zeros((B, nslots, 32, 2), dtype=torch.float64, device=x.device)
+    for l, row0, key in plans:
+        d = l.keep[0]
+        part = partial[row0 // HW:]
+        d.gn_rows = HW
+        if not d.gn_part0:
+            d.gn_part0, d.gn_cpg0, d.gn_coff0, d.gn_slot0, d.gn_nchunks0 = part.data_ptr(), Cc // 32, key[0], slot_of[key][0], nslots
+        else:
+            d.gn_part1, d.gn_cpg1, d.gn_coff1, d.gn_slot1, d.gn_nchunks1 = part.data_ptr(), Cc // 32, key[0], slot_of[key][0], nslots
+        l.keep = tuple(l.keep) + (partial,)
+    return partial, nslots
+
+
+def groupnorm_apply(x, gamma, beta, out, partial, nchunks, *, eps, silu, name="groupnorm"):
+    """The normalisation pass alone, on statistics that already sit in ``partial`` (fuse_groupnorm_stats)."""
+    lib = _lib.load()
+    _require_gpu(x, gamma, beta, out, partial)
+    B, H, W_, Cc = x.shape
+    return Launch(lib.rf_groupnorm_apply, (code(x.dtype), _p(x), B, H * W_, Cc, x.stride(2), nchunks, _p(partial), _p(gamma), _p(beta),
+                                           float(eps), int(bool(silu)), code(out.dtype), _p(out), out.stride(2)),
+                  (x, partial, gamma, beta, out), name + ".apply")
 
 
 def layernorm(x, gamma, beta, out, *, eps=1e-5, name="layernorm"):

@@ -39,6 +39,7 @@ class _Pool:
 
     def __init__(self, device):
         self.device, self.free, self.bytes = device, {}, 0
+        self.on_put = None          # called with a tensor when its memory goes back to the free list
 
     def get(self, shape, dtype):
         n = 1
@@ -51,6 +52,8 @@ class _Pool:
         return torch.empty(shape, dtype=dtype, device=self.device)
 
     def put(self, t):
+        if self.on_put is not None:
+            self.on_put(t)
         self.free.setdefault((t.numel(), t.dtype), []).append(t.reshape(-1))
 
 
@@ -71,7 +74,12 @@ class UNetEngine:
         # computed once for B/2 samples -- bit-identical to computing it twice.
         self.cfg_pair = bool(cfg_pair) and uniform_t and B % 2 == 0
         self.korder_on = os.environ.get("REFACE_KORDER", "0") == "1"
+        # GroupNorm statistics come out of the epilogue of the GEMM that produced the tensor wherever its tile plan allows
+        self.gn_fuse = os.environ.get("REFACE_GN_FUSE", "1") == "1"
+        self.gn_fused = 0
+        self.produced = []
         self.pool = _Pool(device)
+        self.pool.on_put = self._forget
         self.sd = {k: v.detach().to(device=device, dtype=F32) for k, v in sd.items()}
         self.plan = unet_plan(cfg)
         nds = len(cfg.channel_mult) - 1
@@ -184,10 +192,53 @@ class UNetEngine:
         ko = ops.conv_korder(cin, self.dt) if self.korder_on else 0
         return ops.conv2d(x, ops.pack_conv_weight(self.sd[wkey], self.dt, korder=ko), out, self.f32(bkey), korder=ko, name=name, **kw)
 
+    def _add(self, launch, out=None):
+        """Append a launch; GEMM outputs are remembered so that a later GroupNorm can ask their producers for its statistics."""
+        self.main.append(launch)
+        if out is not None and out.dim() == 4:
+            es = out.element_size()
+            self.produced.append((out.data_ptr(), out.stride(2) * es, out.shape[0] * out.shape[1] * out.shape[2], out.shape[3] * es, launch))
+        return launch
+
+    def _forget(self, t):
+        """The memory of t is about to be reused: drop the producer records that point into it."""
+        st = t.untyped_storage()
+        lo, hi = st.data_ptr(), st.data_ptr() + st.nbytes()
+        self.produced = [r for r in self.produced if not (lo <= r[0] < hi)]
+
+    def _producers(self, x):
+        """The recorded GEMM launches whose outputs tile x [B, H, W, C] exactly (latest writer of each region), else None."""
+        es, pitch = x.element_size(), x.stride(2) * x.element_size()
+        M, cb, base = x.shape[0] * x.shape[1] * x.shape[2], x.shape[3] * es, x.data_ptr()
+        if not x[0].is_contiguous() and x.stride(1) != x.shape[2] * x.stride(2):
+            return None
+        found = {}
+        for ptr, p2, rows, colbytes, l in self.produced:            # later entries overwrite earlier ones (buffer reuse)
+            off = ptr - base
+            if p2 != pitch or off < 0:
+                continue
+            row0, cb0 = divmod(off, pitch)
+            if row0 + rows <= M and cb0 + colbytes <= cb:
+                found[(row0, cb0)] = (l, row0, rows, cb0 // es, colbytes // es)
+        prods = list(found.values())
+        if not prods or sum(r * c for _, _, r, _, c in prods) != M * x.shape[3]:
+            return None
+        return prods
+
     def _gn(self, x, key, eps, silu):
         out = self.pool.get(tuple(x.shape), self.dt)
-        self.main += ops.groupnorm(x, self.f32(key + ".weight"), self.f32(key + ".bias"), out, self.gn_partial, eps=eps,
-                                   silu=silu, name=key)
+        fused = None
+        if self.gn_fuse:
+            prods = self._producers(x)
+            if prods is not None:
+                fused = ops.fuse_groupnorm_stats(x, prods)
+        if fused is not None:
+            self.main.append(ops.groupnorm_apply(x, self.f32(key + ".weight"), self.f32(key + ".bias"), out, fused[0], fused[1],
+                                                 eps=eps, silu=silu, name=key))
+            self.gn_fused += 1
+        else:
+            self.main += ops.groupnorm(x, self.f32(key + ".weight"), self.f32(key + ".bias"), out, self.gn_partial, eps=eps,
+                                       silu=silu, name=key)
         return out
 
     def _res(self, p, x, cin, cout, dst):
@@ -197,7 +248,7 @@ class UNetEngine:
         rv = self.emb_vec(p)
         if self.uniform_t:
             rv = rv.as_strided((B, cout), (0, 1), rv.storage_offset())      # every sample reads row 0 (B = this input's batch)
-        self.main.append(self._conv3(t1, f"{p}.in_layers.2.weight", h1, f"{p}.in_layers.2.bias", f"{p}.in_layers.2", rowvec=rv))
+        self._add(self._conv3(t1, f"{p}.in_layers.2.weight", h1, f"{p}.in_layers.2.bias", f"{p}.in_layers.2", rowvec=rv), h1)
         self.pool.put(t1)
         t2 = self._gn(h1, f"{p}.out_layers.0", 1e-5, True)
         self.pool.put(h1)
@@ -208,7 +259,7 @@ class UNetEngine:
         else:
             skip = x
         y = dst if dst is not None else self.pool.get((B, H, W, cout), self.dt)
-        self.main.append(self._conv3(t2, f"{p}.out_layers.3.weight", y, f"{p}.out_layers.3.bias", f"{p}.out_layers.3", residual=skip))
+        self._add(self._conv3(t2, f"{p}.out_layers.3.weight", y, f"{p}.out_layers.3.bias", f"{p}.out_layers.3", residual=skip), y)
         self.pool.put(t2)
         if cin != cout:
             self.pool.put(skip)
@@ -258,8 +309,8 @@ class UNetEngine:
         y = dst if dst is not None else self.pool.get((nb * B, H, W, c), self.dt)
         w_po, b_po = self.w(f"{p}.proj_out.weight").reshape(c, c), self.f32(f"{p}.proj_out.bias")
         for hf in range(nb):        # the residual x is shared by both halves
-            self.main.append(ops.conv2d(x2.view(nb * B, H, W, c)[hf * B:(hf + 1) * B], w_po, y[hf * B:(hf + 1) * B], b_po,
-                                        ksize=1, pad=(0, 0), residual=x, name=f"{p}.proj_out"))
+            self._add(ops.conv2d(x2.view(nb * B, H, W, c)[hf * B:(hf + 1) * B], w_po, y[hf * B:(hf + 1) * B], b_po,
+                                 ksize=1, pad=(0, 0), residual=x, name=f"{p}.proj_out"), y[hf * B:(hf + 1) * B])
         self.pool.put(x2)
         return y
 
@@ -276,18 +327,18 @@ class UNetEngine:
             H, W = x.shape[1], x.shape[2]
             if l[0] == "conv":
                 y = d if d is not None else self.pool.get((B, H, W, l[2]), self.dt)
-                self.main.append(ops.conv2d(x, ops.pack_conv_weight(self.sd[f"{p}.weight"], self.dt, cin_pad=self.CPAD), y,
-                                            self.f32(f"{p}.bias"), name=p))
+                self._add(ops.conv2d(x, ops.pack_conv_weight(self.sd[f"{p}.weight"], self.dt, cin_pad=self.CPAD), y,
+                                     self.f32(f"{p}.bias"), name=p), y)
             elif l[0] == "res":
                 y = self._res(p, x, l[1], l[2], d)
             elif l[0] == "st":
                 y = self._st(p, x, l[1], l[2], d, pair=pair)
             elif l[0] == "down":
                 y = d if d is not None else self.pool.get((B, H // 2, W // 2, l[1]), self.dt)
-                self.main.append(self._conv3(x, f"{p}.op.weight", y, f"{p}.op.bias", f"{p}.op", stride=2))
+                self._add(self._conv3(x, f"{p}.op.weight", y, f"{p}.op.bias", f"{p}.op", stride=2), y)
             elif l[0] == "up":
                 y = d if d is not None else self.pool.get((B, 2 * H, 2 * W, l[1]), self.dt)
-                self.main.append(self._conv3(x, f"{p}.conv.weight", y, f"{p}.conv.bias", f"{p}.conv", ups=1))
+                self._add(self._conv3(x, f"{p}.conv.weight", y, f"{p}.conv.bias", f"{p}.conv", ups=1), y)
             else:
                 raise ValueError(l)
             if j > 0 and x is not None:

@@ -168,6 +168,49 @@ def test_groupnorm(dt, Cc, hw, silu, eps):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c0,c1,hw,B", [(320, 0, 32, 2), (640, 320, 32, 2), (1280, 640, 16, 4)])
+def test_groupnorm_stats_fused_into_gemm(dt, c0, c1, hw, B):
+    """GroupNorm whose statistics come out of the producing GEMMs' epilogues (rf_conv_gemm gn_* fields): a concat buffer
+    [h | skip] written by two GEMMs (the skip one also feeds a second consumer with another grouping), vs torch on the stored tensor."""
+    Cc = c0 + c1
+    cat = torch.zeros((B, hw, hw, Cc), dtype=dt, device=DEV)
+    prods = []
+    for i, (off, c) in enumerate(((0, c0), (c0, c1))):
+        if c == 0:
+            continue
+        xin, _ = q(rnd((B, hw, hw, 64), 90 + i), dt)
+        w, _ = q(rnd((c, 64), 92 + i) / 8, dt)
+        bias = rnd((c,), 94 + i).to(DEV)
+        res, _ = q(rnd((B, hw, hw, c), 96 + i), dt)
+        out = cat[..., off:off + c]
+        l = ops.conv2d(xin, w.reshape(c, 64), out, bias, ksize=1, pad=(0, 0), residual=res, name=f"prod{i}")
+        prods.append((l, 0, B * hw * hw, off, c))
+    fused = ops.fuse_groupnorm_stats(cat, prods)
+    bm, bn, sk = ops.gemm_plan(prods[0][0])
+    if sk != 1 or (hw * hw) % bm:
+        assert fused is None
+        pytest.skip(f"plan bm={bm} splitk={sk} cannot fuse at this size")
+    assert fused is not None
+    second = None
+    if c1:      # the skip half alone is a second consumer (different channels per group)
+        second = ops.fuse_groupnorm_stats(cat[..., c0:], [(prods[1][0], 0, B * hw * hw, 0, c1)])
+        assert second is not None
+    ops.run([p_[0] for p_ in prods])
+    g, be = rnd((Cc,), 98) * 0.2 + 1, rnd((Cc,), 99) * 0.2
+    y = torch.empty_like(cat)
+    ops.groupnorm_apply(cat, g.to(DEV), be.to(DEV), y, fused[0], fused[1], eps=1e-5, silu=True)()
+    torch.cuda.synchronize()
+    ref = F.silu(F.group_norm(cat.float().cpu().permute(0, 3, 1, 2), 32, g, be, 1e-5)).permute(0, 2, 3, 1)
+    check(y, ref, dt)
+    if second is not None:
+        y2 = torch.empty((B, hw, hw, c1), dtype=dt, device=DEV)
+        ops.groupnorm_apply(cat[..., c0:], g[:c1].to(DEV), be[:c1].to(DEV), y2, second[0], second[1], eps=1e-5, silu=False)()
+        torch.cuda.synchronize()
+        ref2 = F.group_norm(cat[..., c0:].float().cpu().permute(0, 3, 1, 2), 32, g[:c1], be[:c1], 1e-5).permute(0, 2, 3, 1)
+        check(y2, ref2, dt)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("Cc", [320, 768, 1024, 1280])
 def test_layernorm(dt, Cc):
     M = 131

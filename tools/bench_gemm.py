@@ -101,6 +101,8 @@ lin("ff2 2560->640 @32", Bc * 1024, 640, 2560)
 lin("geglu 1280->10240 @16", Bc * 256, 10240, 1280, ops.ACT_GEGLU)
 lin("ff2 5120->1280 @16", Bc * 256, 1280, 5120)
 lin("skip1x1 2560->1280 @8", Bc * 64, 1280, 2560)
+lin("lin big 5760->320 @64", Bc * 4096, 320, 5760)
+lin("lin big 5760->640 @32", Bc * 1024, 640, 5760)
 lin("proj 640->640 @32", Bc * 1024, 640, 640)
 lin("proj 1280->1280 @16", Bc * 256, 1280, 1280)
 attn("attn d40 N4096", 8, 40, 4096)
