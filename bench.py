@@ -210,6 +210,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         from reface_amd import profiler
         plan = list(sampler._plans.values())[0]
+        log(f"[bench] UNet launches per DDIM step: {len(plan['step'])} (GroupNorm statistics fused into GEMM epilogues: {plan['eng'].gn_fused} of 61)")
         timed = profiler.time_launches(plan["step"], reps=3)
         fam = profiler.summarize(timed)
         step_ms = sum(ms for _, ms in timed)

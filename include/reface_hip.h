@@ -88,8 +88,9 @@ typedef struct rf_conv_gemm_desc {
 
 int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream);
 
-/* The tile plan rf_conv_gemm would use for `d` (block rows / columns, split-K factor); no launch.  Fused GroupNorm statistics
- * (gn_rows > 0) need splitk == 1 and gn_rows % bm == 0; a launch then writes (gn_rows / bm) * ceil(N / bn) chunk slots per sample,
+/* The epilogue tiling rf_conv_gemm would use for `d` -- rows / columns of the block that finishes an output tile (the GEMM tile, or
+ * the tile of the split-K reduce pass when splitk > 1) -- and the split-K factor; no launch.  Fused GroupNorm statistics
+ * (gn_rows > 0) need gn_rows % bm == 0; a launch then writes (gn_rows / bm) * ceil(N / bn) chunk slots per sample,
  * slot = gn_slot + (row tile within the sample) * ceil(N / bn) + column tile.  Replaces the separate statistics pass of
  * nn.GroupNorm (util.py:214-216) over a tensor this GEMM has just produced. */
 int rf_conv_gemm_plan(const rf_conv_gemm_desc* d, int32_t* bm, int32_t* bn, int32_t* splitk);

@@ -651,41 +651,78 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
     }
 }
 
-// split-K second pass: out = act(alpha * sum_z ws[z] + bias + rowvec) + residual   (elementwise, 4 columns per thread)
+// split-K second pass: out = act(alpha * sum_z ws[z] + bias + rowvec) + residual.  One block = SK_ROWS x SK_COLS of the output,
+// thread -> one fixed 4-column segment and every 4th row, so the fused GroupNorm statistics reduce exactly as in the main epilogue
+// (chunk slot = gn_slot + (row tile within the sample) * column tiles + column tile).
+constexpr int SK_ROWS = 32, SK_COLS = 256;
 template <typename TO>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
-    const long long nvec = (long long)p.M * ((p.N + 3) / 4);
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nvec) return;
-    const int nv = (p.N + 3) / 4;
-    const int row = (int)(i / nv), col = (int)(i - (long long)row * nv) * 4;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool vec = (p.N & 3) == 0;
-    for (int z = 0; z < p.splitk; ++z) {
-        const float* src = p.ws + ((long long)z * p.M + row) * p.N + col;
-        if (vec) { const f32x4_t a = *(const f32x4_t*)src; v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3]; }
-        else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (col + e < p.N) v[e] += src[e];
-        }
-    }
+    const int tid = threadIdx.x;
+    const int cl = (tid & 63) * 4, rp = tid >> 6;
+    const int n0 = blockIdx.x * SK_COLS, m0 = blockIdx.y * SK_ROWS;
+    const int col = n0 + cl;
+    const bool vec = (p.N & 3) == 0 && p.vec_ok;
+    const bool gn_on = p.gn_rows > 0;
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f}, gsq[4] = {0.f, 0.f, 0.f, 0.f};
     TO* outp = (TO*)p.out;
     const TO* resp = (const TO*)p.residual;
+    if (col < p.N) {
+        float cadd[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int c = col + e;
-        if (c >= p.N) break;
-        float y = v[e] * p.alpha;
-        if (p.bias) y += p.bias[c];
-        if (p.rowvec) y += p.rowvec[(long long)(row / p.rows_per_sample) * p.ldv + c];
-        if (p.act == RF_ACT_SILU) y = silu_exact(y);
-        else if (p.act == RF_ACT_QUICK_GELU) y = quick_gelu(y);
-        else if (p.act == RF_ACT_GELU) y = gelu_erf(y);
-        else if (p.act == RF_ACT_RELU) y = fmaxf(y, 0.0f);
-        else if (p.act == RF_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
-        else if (p.act == RF_ACT_PRELU) y = y >= 0.0f ? y : y * p.act_vec[c];
-        if (resp) y += load_out<TO>(resp + (long long)row * p.ldr + c);
-        store_out<TO>(outp + (long long)row * p.ldo + c, y);
+        for (int e = 0; e < 4; ++e)
+            if (p.bias && col + e < p.N) cadd[e] = p.bias[col + e];
+#pragma unroll 2
+        for (int k = 0; k < SK_ROWS / 4; ++k) {
+            const int row = m0 + rp + 4 * k;
+            if (row >= p.M) break;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int z = 0; z < p.splitk; ++z) {
+                const float* src = p.ws + ((long long)z * p.M + row) * p.N + col;
+                if (vec) { const f32x4_t a = *(const f32x4_t*)src; v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3]; }
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (col + e < p.N) v[e] += src[e];
+                }
+            }
+            const float* rv = p.rowvec ? p.rowvec + (long long)(row / p.rows_per_sample) * p.ldv : nullptr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = col + e;
+                if (c >= p.N) break;
+                float y = v[e] * p.alpha + cadd[e];
+                if (rv) y += rv[c];
+                if (p.act == RF_ACT_SILU) y = silu_exact(y);
+                else if (p.act == RF_ACT_QUICK_GELU) y = quick_gelu(y);
+                else if (p.act == RF_ACT_GELU) y = gelu_erf(y);
+                else if (p.act == RF_ACT_RELU) y = fmaxf(y, 0.0f);
+                else if (p.act == RF_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
+                else if (p.act == RF_ACT_PRELU) y = y >= 0.0f ? y : y * p.act_vec[c];
+                if (resp) y += load_out<TO>(resp + (long long)row * p.ldr + c);
+                if (gn_on) { gsum[e] += y; gsq[e] += y * y; }
+                store_out<TO>(outp + (long long)row * p.ldo + c, y);
+            }
+        }
+    }
+    if (gn_on) {
+        __shared__ float cs[2][4][SK_COLS];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cs[0][rp][cl + e] = gsum[e]; cs[1][rp][cl + e] = gsq[e]; }
+        __syncthreads();
+        if (tid < 64) {
+            const int c = tid >> 5, g = tid & 31;
+            if (p.gn_part[c]) {
+                const int cpg = p.gn_cpg[c], base = p.gn_coff[c] + n0;
+                const int lo = max(0, g * cpg - base), hi = min(min(SK_COLS, p.N - n0), (g + 1) * cpg - base);
+                double sa = 0.0, sq = 0.0;
+                for (int k = lo; k < hi; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sa += (double)cs[0][r][k]; sq += (double)cs[1][r][k]; }
+                const int b = m0 / p.gn_rows, mt = (m0 - b * p.gn_rows) / SK_ROWS;
+                double* o = p.gn_part[c] + (((long long)b * p.gn_nch[c] + p.gn_slot[c] + mt * (int)gridDim.x + (int)blockIdx.x) * 32 + g) * 2;
+                o[0] = sa;
+                o[1] = sq;
+            }
+        }
     }
 }
 
@@ -720,15 +757,16 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     // split-K for launches that cannot fill the chip: each z-slice owns a K range, partial sums go through the caller's workspace
     p.splitk = pick_splitk(d, p, (long long)p.tiles_m * p.tiles_n, sizeof(T) == 2 ? 64 : 32);
     if (p.splitk > 1) p.ws = (float*)d->workspace;
-    if (p.plan) { p.plan[0] = BM; p.plan[1] = BN; p.plan[2] = p.splitk; return 0; }
+    // statistics tiling: the GEMM tile, or the reduce pass's tile when split-K moves the epilogue there
+    const int st_rows = p.splitk > 1 ? SK_ROWS : BM, st_cols = p.splitk > 1 ? SK_COLS : BN;
+    if (p.plan) { p.plan[0] = st_rows; p.plan[1] = st_cols; p.plan[2] = p.splitk; return 0; }
     if (p.gn_rows > 0) {
-        RF_CHECK(p.splitk == 1 && p.gn_rows % BM == 0 && p.M % p.gn_rows == 0 && d->batch == 1 && d->act != RF_ACT_GEGLU,
-                 "rf_conv_gemm: fused GroupNorm statistics need splitk == 1 (%d), gn_rows %% %d == 0 (%d), batch 1, no GEGLU -- ask rf_conv_gemm_plan",
-                 p.splitk, BM, p.gn_rows);
+        RF_CHECK(p.gn_rows % st_rows == 0 && p.M % p.gn_rows == 0 && d->batch == 1 && d->act != RF_ACT_GEGLU,
+                 "rf_conv_gemm: fused GroupNorm statistics need gn_rows %% %d == 0 (%d), batch 1, no GEGLU -- ask rf_conv_gemm_plan", st_rows, p.gn_rows);
+        const int need = (p.gn_rows / st_rows) * ((p.N + st_cols - 1) / st_cols);
         for (int c = 0; c < 2; ++c)
-            RF_CHECK(!p.gn_part[c] || (p.gn_cpg[c] > 0 && p.gn_slot[c] >= 0 && p.gn_slot[c] + (p.gn_rows / BM) * p.tiles_n <= p.gn_nch[c]),
-                     "rf_conv_gemm: GroupNorm consumer %d: cpg=%d slot=%d needs %d slots of %d", c, p.gn_cpg[c], p.gn_slot[c],
-                     (p.gn_rows / BM) * p.tiles_n, p.gn_nch[c]);
+            RF_CHECK(!p.gn_part[c] || (p.gn_cpg[c] > 0 && p.gn_slot[c] >= 0 && p.gn_slot[c] + need <= p.gn_nch[c]),
+                     "rf_conv_gemm: GroupNorm consumer %d: cpg=%d slot=%d needs %d slots of %d", c, p.gn_cpg[c], p.gn_slot[c], need, p.gn_nch[c]);
     }
     dim3 grid(p.tiles_m * p.tiles_n, d->batch, p.splitk), block(WM * WN * 64);
 #define RF_LAUNCH_VARIANT(CONV_, GLDS_)                                                                                         \
@@ -743,10 +781,8 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     else if (p.glds) RF_LAUNCH_VARIANT(false, true)
     else RF_LAUNCH_VARIANT(false, false)
 #undef RF_LAUNCH_VARIANT
-    if (p.splitk > 1) {
-        const long long nvec = (long long)p.M * ((p.N + 3) / 4);
-        hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, p);
-    }
+    if (p.splitk > 1)
+        hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3((p.N + SK_COLS - 1) / SK_COLS, (p.M + SK_ROWS - 1) / SK_ROWS), dim3(256), 0, st, p);
     RF_LAUNCH_CHECK("rf_conv_gemm");
     return 0;
 }

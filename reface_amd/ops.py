@@ -193,7 +193,7 @@ def groupnorm(x, gamma, beta, out, partial, *, eps, silu, name="groupnorm"):
 
 
 def gemm_plan(launch):
-    """(block rows, block columns, split-K factor) rf_conv_gemm will use for this prepared launch."""
+    """(rows, columns of the block that finishes an output tile, split-K factor) rf_conv_gemm will use for this prepared launch."""
     lib = _lib.load()
     bm, bn, sk = C.c_int32(0), C.c_int32(0), C.c_int32(0)
     _lib.check(lib.rf_conv_gemm_plan(C.byref(launch.keep[0]), C.byref(bm), C.byref(bn), C.byref(sk)), launch.name + ".plan")
@@ -205,7 +205,7 @@ def fuse_groupnorm_stats(x, producers):
 
     ``producers``: [(launch, row0, rows, col0, cols)] -- prepared rf_conv_gemm launches that together tile the [B*H*W, C] matrix
     (column slices of a concat buffer, batch halves).  Returns (partial, nchunks) for groupnorm_apply, or None when some
-    producer cannot do it (split-K plan, tile rows straddling samples, GEGLU, both consumer slots taken, uneven tiling).
+    producer cannot do it (tile rows straddling samples, GEGLU, both consumer slots taken, uneven tiling).
     """
     B, H, W_, Cc = x.shape
     HW, M = H * W_, B * H * W_
@@ -219,7 +219,7 @@ def fuse_groupnorm_stats(x, producers):
         if row0 % HW or rows % HW or d.M != rows or d.N != cols:
             return None
         bm, bn, sk = gemm_plan(l)
-        if sk != 1 or HW % bm:
+        if HW % bm:
             return None
         per_sample = (HW // bm) * ((cols + bn - 1) // bn)
         key = (col0, cols)
