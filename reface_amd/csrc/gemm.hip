@@ -671,35 +671,77 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (p.bias && col + e < p.N) cadd[e] = p.bias[col + e];
-#pragma unroll 2
-        for (int k = 0; k < SK_ROWS / 4; ++k) {
-            const int row = m0 + rp + 4 * k;
-            if (row >= p.M) break;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int z = 0; z < p.splitk; ++z) {
-                const float* src = p.ws + ((long long)z * p.M + row) * p.N + col;
-                if (vec) { const f32x4_t a = *(const f32x4_t*)src; v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3]; }
-                else {
+        constexpr int U = 4;          // rows in flight: the partial-sum loads of U rows are issued together (one row at a time
+                                      // serialises the L2 / HBM latency SK_ROWS / 4 times per thread)
+#pragma unroll 1
+        for (int k0 = 0; k0 < SK_ROWS / 4; k0 += U) {
+            float v[U][4];
+            bool ok[U];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (col + e < p.N) v[e] += src[e];
-                }
+            for (int u = 0; u < U; ++u) {
+                ok[u] = m0 + rp + 4 * (k0 + u) < p.M;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[u][e] = 0.f;
             }
-            const float* rv = p.rowvec ? p.rowvec + (long long)(row / p.rows_per_sample) * p.ldv : nullptr;
+            for (int z = 0; z < p.splitk; ++z) {
+                f32x4_t a[U];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = col + e;
-                if (c >= p.N) break;
-                float y = v[e] * p.alpha + cadd[e];
-                if (rv) y += rv[c];
-                if (p.act == RF_ACT_SILU) y = silu_exact(y);
-                else if (p.act == RF_ACT_QUICK_GELU) y = quick_gelu(y);
-                else if (p.act == RF_ACT_GELU) y = gelu_erf(y);
-                else if (p.act == RF_ACT_RELU) y = fmaxf(y, 0.0f);
-                else if (p.act == RF_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
-                else if (p.act == RF_ACT_PRELU) y = y >= 0.0f ? y : y * p.act_vec[c];
-                if (resp) y += load_out<TO>(resp + (long long)row * p.ldr + c);
-                if (gn_on) { gsum[e] += y; gsq[e] += y * y; }
-                store_out<TO>(outp + (long long)row * p.ldo + c, y);
+                for (int u = 0; u < U; ++u) {
+                    const float* src = p.ws + ((long long)z * p.M + (m0 + rp + 4 * (k0 + u))) * p.N + col;
+                    a[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    if (ok[u]) {
+                        if (vec) a[u] = *(const f32x4_t*)src;
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (col + e < p.N) a[u][e] = src[e];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) { v[u][0] += a[u][0]; v[u][1] += a[u][1]; v[u][2] += a[u][2]; v[u][3] += a[u][3]; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
+                const int row = m0 + rp + 4 * (k0 + u);
+                const float* rv = p.rowvec ? p.rowvec + (long long)(row / p.rows_per_sample) * p.ldv : nullptr;
+                const bool full = vec && col + 3 < p.N;
+                float y4[4] = {0.f, 0.f, 0.f, 0.f}, r4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (resp && full) {
+                    if constexpr (sizeof(TO) == 2) {
+                        const u32x2_t q = *(const u32x2_t*)(resp + (long long)row * p.ldr + col);
+                        r4[0] = as_f32(q[0] << 16); r4[1] = as_f32(q[0] & 0xffff0000u); r4[2] = as_f32(q[1] << 16); r4[3] = as_f32(q[1] & 0xffff0000u);
+                    } else {
+                        const f32x4_t q = *(const f32x4_t*)(resp + (long long)row * p.ldr + col);
+                        r4[0] = q[0]; r4[1] = q[1]; r4[2] = q[2]; r4[3] = q[3];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = col + e;
+                    if (c >= p.N) break;
+                    float y = v[u][e] * p.alpha + cadd[e];
+                    if (rv) y += rv[c];
+                    if (p.act == RF_ACT_SILU) y = silu_exact(y);
+                    else if (p.act == RF_ACT_QUICK_GELU) y = quick_gelu(y);
+                    else if (p.act == RF_ACT_GELU) y = gelu_erf(y);
+                    else if (p.act == RF_ACT_RELU) y = fmaxf(y, 0.0f);
+                    else if (p.act == RF_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
+                    else if (p.act == RF_ACT_PRELU) y = y >= 0.0f ? y : y * p.act_vec[c];
+                    if (resp) y += full ? r4[e] : load_out<TO>(resp + (long long)row * p.ldr + c);
+                    if (gn_on) { gsum[e] += y; gsq[e] += y * y; }
+                    y4[e] = y;
+                    if (!full) store_out<TO>(outp + (long long)row * p.ldo + c, y);
+                }
+                if (full) {
+                    TO* dst = outp + (long long)row * p.ldo + col;
+                    if constexpr (sizeof(TO) == 2) {
+                        u32x2_t w; w[0] = pack_bf2(y4[0], y4[1]); w[1] = pack_bf2(y4[2], y4[3]);
+                        *(u32x2_t*)dst = w;
+                    } else {
+                        *(f32x4_t*)dst = f32x4_t{y4[0], y4[1], y4[2], y4[3]};
+                    }
+                }
             }
         }
     }
