@@ -28,6 +28,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .gnfuse import ProducerTracker
 from .modules import ParamTree, flat_state, weights_version
 from .params import UNetConfig, unet_param_specs, unet_plan
 
@@ -77,9 +78,9 @@ class UNetEngine:
         # GroupNorm statistics come out of the epilogue of the GEMM that produced the tensor wherever its tile plan allows
         self.gn_fuse = os.environ.get("REFACE_GN_FUSE", "1") == "1"
         self.gn_fused = 0
-        self.produced = []
         self.pool = _Pool(device)
-        self.pool.on_put = self._forget
+        self.tracker = ProducerTracker()
+        self.pool.on_put = self.tracker.forget
         self.sd = {k: v.detach().to(device=device, dtype=F32) for k, v in sd.items()}
         self.plan = unet_plan(cfg)
         nds = len(cfg.channel_mult) - 1
@@ -195,41 +196,13 @@ class UNetEngine:
     def _add(self, launch, out=None):
         """Append a launch; GEMM outputs are remembered so that a later GroupNorm can ask their producers for its statistics."""
         self.main.append(launch)
-        if out is not None and out.dim() == 4:
-            es = out.element_size()
-            self.produced.append((out.data_ptr(), out.stride(2) * es, out.shape[0] * out.shape[1] * out.shape[2], out.shape[3] * es, launch))
-        return launch
-
-    def _forget(self, t):
-        """The memory of t is about to be reused: drop the producer records that point into it."""
-        st = t.untyped_storage()
-        lo, hi = st.data_ptr(), st.data_ptr() + st.nbytes()
-        self.produced = [r for r in self.produced if not (lo <= r[0] < hi)]
-
-    def _producers(self, x):
-        """The recorded GEMM launches whose outputs tile x [B, H, W, C] exactly (latest writer of each region), else None."""
-        es, pitch = x.element_size(), x.stride(2) * x.element_size()
-        M, cb, base = x.shape[0] * x.shape[1] * x.shape[2], x.shape[3] * es, x.data_ptr()
-        if not x[0].is_contiguous() and x.stride(1) != x.shape[2] * x.stride(2):
-            return None
-        found = {}
-        for ptr, p2, rows, colbytes, l in self.produced:            # later entries overwrite earlier ones (buffer reuse)
-            off = ptr - base
-            if p2 != pitch or off < 0:
-                continue
-            row0, cb0 = divmod(off, pitch)
-            if row0 + rows <= M and cb0 + colbytes <= cb:
-                found[(row0, cb0)] = (l, row0, rows, cb0 // es, colbytes // es)
-        prods = list(found.values())
-        if not prods or sum(r * c for _, _, r, _, c in prods) != M * x.shape[3]:
-            return None
-        return prods
+        return self.tracker.record(out, launch)
 
     def _gn(self, x, key, eps, silu):
         out = self.pool.get(tuple(x.shape), self.dt)
         fused = None
         if self.gn_fuse:
-            prods = self._producers(x)
+            prods = self.tracker.producers(x)
             if prods is not None:
                 fused = ops.fuse_groupnorm_stats(x, prods)
         if fused is not None:

@@ -11,10 +11,13 @@ graph from ldm/modules/diffusionmodules/model.py:368-568:
 * Downsample (model.py:72-76): asymmetric (0,1,0,1) zero pad + stride-2 conv = pad_t = pad_l = 0.
 * decode: z / scale_factor (ddpm.py:1284) is folded into post_quant_conv's alpha.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from . import ops
+from .gnfuse import ProducerTracker
 from .modules import ParamTree, flat_state, weights_version
 from .params import VAEConfig, vae_param_specs
 from .unet import _Pool
@@ -59,6 +62,10 @@ class _VAEEngine:
     def __init__(self, sd, cfg: VAEConfig, B, H, W, dtype, device, which):
         self.cfg, self.B, self.dt, self.dev = cfg, B, dtype, device
         self.pool = _Pool(device)
+        self.tracker = ProducerTracker()
+        self.pool.on_put = self.tracker.forget
+        self.gn_fuse = os.environ.get("REFACE_GN_FUSE", "1") == "1"
+        self.gn_fused = 0
         self.sd = {k: v.detach().to(device=device, dtype=F32) for k, v in sd.items()}
         self.gn_partial = torch.empty(B * ops.GN_MAX_CHUNKS * 64, dtype=torch.float64, device=device)
         self.launches = []
@@ -73,16 +80,26 @@ class _VAEEngine:
 
     def _gn(self, x, key, silu=True):
         out = self.pool.get(tuple(x.shape), self.dt)
-        self.launches += ops.groupnorm(x, self.f32(key + ".weight"), self.f32(key + ".bias"), out, self.gn_partial, eps=1e-6,
-                                       silu=silu, name=key)
+        fused = None
+        if self.gn_fuse:            # statistics from the epilogue of the GEMM that wrote x, when its tile plan allows
+            prods = self.tracker.producers(x)
+            if prods is not None:
+                fused = ops.fuse_groupnorm_stats(x, prods)
+        if fused is not None:
+            self.launches.append(ops.groupnorm_apply(x, self.f32(key + ".weight"), self.f32(key + ".bias"), out, fused[0], fused[1],
+                                                     eps=1e-6, silu=silu, name=key))
+            self.gn_fused += 1
+        else:
+            self.launches += ops.groupnorm(x, self.f32(key + ".weight"), self.f32(key + ".bias"), out, self.gn_partial, eps=1e-6,
+                                           silu=silu, name=key)
         return out
 
     def _conv3(self, key, x, cout, *, cin_pad=None, stride=1, pad=(1, 1), ups=0, residual=None, out=None):
         B, H, W, _ = x.shape
         Ho, Wo = (2 * H, 2 * W) if ups else ((H // 2, W // 2) if stride == 2 else (H, W))
         y = out if out is not None else self.pool.get((B, Ho, Wo, cout), self.dt)
-        self.launches.append(ops.conv2d(x, ops.pack_conv_weight(self.sd[key + ".weight"], self.dt, cin_pad=cin_pad), y,
-                                        self.f32(key + ".bias"), stride=stride, pad=pad, ups=ups, residual=residual, name=key))
+        self.launches.append(self.tracker.record(y, ops.conv2d(x, ops.pack_conv_weight(self.sd[key + ".weight"], self.dt, cin_pad=cin_pad), y,
+                                                               self.f32(key + ".bias"), stride=stride, pad=pad, ups=ups, residual=residual, name=key)))
         return y
 
     def _res(self, p, x, cin, cout):
@@ -132,8 +149,8 @@ class _VAEEngine:
         self.launches.append(ops.conv_gemm(probs, vt, att, M=N, N=c, K=N, C0=N, ld0=N, Hin=1, Win=N, Hout=1, Wout=N, ldo=c,
                                            bias=self.f32(f"{p}.v.bias"), batch=B, sA=N * N, sW=c * N, sO=N * c, name=f"{p}.pv"))
         y = self.pool.get((B, H, W, c), self.dt)
-        self.launches.append(ops.conv2d(att, self.w(f"{p}.proj_out.weight").reshape(c, c), y, self.f32(f"{p}.proj_out.bias"), ksize=1,
-                                        pad=(0, 0), residual=x, name=f"{p}.proj_out"))
+        self.launches.append(self.tracker.record(y, ops.conv2d(att, self.w(f"{p}.proj_out.weight").reshape(c, c), y, self.f32(f"{p}.proj_out.bias"),
+                                                               ksize=1, pad=(0, 0), residual=x, name=f"{p}.proj_out")))
         for t in (qk, vt, scores, att) + ((probs,) if probs is not scores else ()):
             self.pool.put(t)
         return y

@@ -185,6 +185,9 @@ def test_vae_full_width_blocks_vs_reference_golden(golden_dir):
         eng.sd = {k: v.to(DEV) for k, v in sd.items()}
         eng.gn_partial = torch.empty(B * ops.GN_MAX_CHUNKS * 64, dtype=torch.float64, device=DEV)
         eng.launches = []
+        from reface_amd.gnfuse import ProducerTracker
+        eng.tracker, eng.gn_fuse, eng.gn_fused = ProducerTracker(), True, 0
+        eng.pool.on_put = eng.tracker.forget
         xin = x.permute(0, 2, 3, 1).contiguous().to(DEV)
         y = eng._res(*shape_args[:1], xin, *shape_args[1:]) if kind == "res" else eng._attn(shape_args[0], xin, shape_args[1])
         ops.run(eng.launches)
