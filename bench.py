@@ -129,6 +129,23 @@ def cpu_baseline(cpu_sd, cores):
             "sample": f"B=1: 1 CFG DDIM step (UNet batch 2, latent 64x64) = {t_step:.2f}s scaled x50, + 1 fp32 VAE decode 512x512 = {t_dec:.2f}s"}
 
 
+def pmc_traffic(family):
+    """HBM-side bytes per launch of a kernel family (read + write) from the newest committed PMC pass, or None.
+    The counters cannot be collected inside this process: tools/pmc_traffic.sh runs this same command under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, FETCH_SIZE doubled as the gfx950 note in the
+    microarchitecture guide prescribes) and the summary is committed as profiles/rNN_pmc_hbm_traffic.json."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_hbm_traffic.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f).get(family)
+        return None if d is None else d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch_uncalibrated"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,7 +240,7 @@ def main():
         nb = 2 * B
         unet_alg = F_UNET_64 * nb * (h / 64.0) ** 2 if h == 64 else None
         roof = {"bound": "mfma", "kernel": key, "achieved": dom["tflops_per_s"], "peak": PEAK[args.dtype], "unit": "TFLOP/s",
-                "frac": dom["tflops_per_s"] / PEAK[args.dtype], "traffic": None,
+                "frac": dom["tflops_per_s"] / PEAK[args.dtype], "traffic": pmc_traffic(key),
                 "launches_per_ddim_step": dom["calls"], "avg_launch_us": dom["ms"] / dom["calls"] * 1e3,
                 "alg_flop_per_ddim_step": dom["flops"], "ddim_step_ms_sum_of_kernels": step_ms}
         if unet_alg:

@@ -11,6 +11,8 @@ ResBlock embedding vectors (precomputed for all S timesteps by one GEMM chain) a
 update coefficients.  Cross-attention reduces to a per-sample vector computed once per call.
 """
 import numpy as np
+import os
+
 import torch
 
 from . import ops
@@ -25,7 +27,7 @@ class DDIMSampler(object):
         self.model = model
         self.ddpm_num_timesteps = model.num_timesteps
         self.schedule = schedule
-        self.use_graph = kwargs.get("use_graph", True)
+        self.use_graph = kwargs.get("use_graph", os.environ.get("REFACE_NO_GRAPH", "0") != "1")      # counter collection cannot trace graph replays
         self._plans = {}
 
     def register_buffer(self, name, attr):
