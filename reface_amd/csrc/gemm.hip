@@ -836,7 +836,9 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
         static const int forced_all = [] { const char* e = getenv("RF_GEMM_CFG"); return e ? atoi(e) : -1; }();
         static const int small_k = [] { const char* e = getenv("RF_SMALLK_K"); return e ? atoi(e) : 0; }();          // K <= this ...
         static const int small_cfg = [] { const char* e = getenv("RF_SMALLK_CFG"); return e ? atoi(e) : -1; }();     // ... uses this config
-        const int forced = forced_all >= 0 ? forced_all : (p.K <= small_k ? small_cfg : -1);
+        static const int m_exact = [] { const char* e = getenv("RF_MCFG_M"); return e ? atoi(e) : 0; }();               // M == this ...
+        static const int m_cfg = [] { const char* e = getenv("RF_MCFG_CFG"); return e ? atoi(e) : -1; }();              // ... uses this config
+        const int forced = forced_all >= 0 ? forced_all : (p.M == m_exact ? m_cfg : (p.K <= small_k ? small_cfg : -1));
         const bool g = d->act == RF_ACT_GEGLU;
         switch (forced) {
             case 0: if (!g && p.glds && d->batch == 1) return launch_cfg<T, TO, 4, 2, 2, 5>(d, p, conv, st); break;
