@@ -129,6 +129,40 @@ def cpu_baseline(cpu_sd, cores):
             "sample": f"B=1: 1 CFG DDIM step (UNet batch 2, latent 64x64) = {t_step:.2f}s scaled x50, + 1 fp32 VAE decode 512x512 = {t_dec:.2f}s"}
 
 
+def conditioning_line(vae, B, h, device):
+    """the once-per-image conditioning stage as a separate line -- CLIP ViT-L/14 on the reference and on the
+    (resized) target, ArcFace IR-SE50 on the reference, fp32 KL-VAE encode of the 512x512 masked target -- fp32, batch B."""
+    from reface_amd import params as P
+    from reface_amd.encoders import Backbone, FrozenCLIPEmbedder, target_to_clip_input
+    clip = FrozenCLIPEmbedder()
+    clip.load_state_dict(P.seeded_state_dict(P.clip_param_specs(clip.cfg), 88), strict=True)
+    arc = Backbone(input_size=112, num_layers=50, drop_ratio=0.6, mode="ir_se")
+    arc.load_state_dict(P.seeded_state_dict(P.arcface_param_specs(), 77), strict=True)
+    clip.to(device)
+    arc.to(device)
+    ref = P.seeded_randn((B, 3, 224, 224), 71).to(device)
+    tar = torch.tanh(P.seeded_randn((B, 3, 8 * h, 8 * h), 70)).to(device)
+
+    def stage():
+        z_ref = clip.encode(ref)
+        z_tar = clip.encode(target_to_clip_input(tar))
+        fid = arc.forward_from_clip_image(ref)
+        post = vae.encode(tar)
+        return z_ref, z_tar, fid, post
+
+    stage()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        out = stage()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all() and torch.isfinite(out[3].mean).all()
+    return {"metric": "conditioning images/sec (2x CLIP ViT-L/14 + ArcFace IR-SE50 + fp32 VAE encode 512x512, fp32)", "value": B / dt,
+            "unit": "images/s", "ms_per_batch": dt * 1e3, "batch": B, "algorithmic_gflop_per_image": 1116.7 + 2 * 155.53 + 12.59}
+
+
 def pmc_traffic(family):
     """HBM-side bytes per launch of a kernel family (read + write) from the newest committed PMC pass, or None.
     The counters cannot be collected inside this process: tools/pmc_traffic.sh runs this same command under
@@ -158,6 +192,7 @@ def main():
     ap.add_argument("--scale", type=float, default=3.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-conditioning", action="store_true", help="skip the separate conditioning-stage (encoders) throughput line")
     ap.add_argument("--profile-json", default=None, help="write the per-kernel-family table here")
     args = ap.parse_args()
 
@@ -267,6 +302,12 @@ def main():
             with open(args.profile_json, "w") as f:
                 json.dump({"families": fam, "vae_families": dfam, "step_launches": [row(l, ms) for l, ms in timed],
                            "vae_launches": [row(l, ms) for l, ms in dtimed]}, f, indent=1)
+    if rank == 0 and world == 1 and not args.no_conditioning:
+        try:
+            result["conditioning"] = conditioning_line(vae, B, h, device)
+            log(f"[bench] conditioning stage: {result['conditioning']['value']:.1f} images/s ({result['conditioning']['ms_per_batch']:.1f} ms per batch of {B})")
+        except Exception as e:        # the headline number must not depend on this side line
+            result["conditioning"] = {"error": repr(e)}
     if want_cpu:
         cores = os.cpu_count() or 1
         try:
