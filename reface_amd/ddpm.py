@@ -265,5 +265,13 @@ class LatentDiffusion(nn.Module, _DeviceMixin):
             cond = {key: cond}
         return self.model(x_noisy, t, **cond, return_features=return_features)
 
+    @torch.no_grad()
     def q_sample(self, x_start, t, noise=None):
-        raise NotImplementedError("q_sample (--Start_from_target) is a 'next' row of the scope table (SURVEY.md 8f.4)")
+        """ddpm.py:412-415: sqrt(acp[t]) * x_start + sqrt(1 - acp[t]) * noise, per sample (rf_combine3)."""
+        x = x_start.to(device=self.device, dtype=torch.float32).contiguous()
+        noise = torch.randn_like(x) if noise is None else noise.to(device=self.device, dtype=torch.float32).contiguous()
+        out = torch.empty_like(x)
+        sa, s1 = self.sqrt_alphas_cumprod.detach().cpu(), self.sqrt_one_minus_alphas_cumprod.detach().cpu()
+        for b, tb in enumerate(t.reshape(-1).tolist()):
+            ops.combine3(x[b], noise[b], None, out[b], wa=float(sa[tb]), wb=float(s1[tb]), wc=0.0, den=0.0)()
+        return out

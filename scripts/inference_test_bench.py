@@ -103,8 +103,8 @@ def save_png(arr_chw01, path):
 def main(argv=None):
     opt = build_parser().parse_args(argv)
     print(opt)
-    if opt.plms or opt.laion400m or opt.Guidance:
-        raise NotImplementedError("--plms / --laion400m / --Guidance are outside the REFace DDIM hot path (SURVEY.md section 2)")
+    if opt.laion400m or opt.Guidance:
+        raise NotImplementedError("--laion400m / --Guidance are outside the REFace sampling path (SURVEY.md section 2)")
     torch.manual_seed(opt.seed)
     np.random.seed(opt.seed)
     rank = int(os.environ.get("RANK", "0"))
@@ -126,7 +126,11 @@ def main(argv=None):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
-    sampler = DDIMSampler(model)
+    if opt.plms:                                    # inference_test_bench.py:337-339
+        from ldm.models.diffusion.plms import PLMSSampler
+        sampler = PLMSSampler(model)
+    else:
+        sampler = DDIMSampler(model)
 
     outpath = opt.outdir
     sample_path, result_path, grid_path = (os.path.join(outpath, d) for d in ("samples", "results", "grid"))
@@ -150,8 +154,12 @@ def main(argv=None):
     n_done, t_start = 0, time.time()
     with torch.no_grad(), model.ema_scope():
         for test_batch, prior, test_model_kwargs, segment_id_batch in loader:
-            if opt.Start_from_target:
-                raise NotImplementedError("--Start_from_target is the 'next' row 8f.4 of the scope table")
+            if opt.Start_from_target:                   # inference_test_bench.py:414-435: noised target (or prior) latent as x_T
+                x0_img = prior                          # `use_prior = True` is hard-wired in the reference (:402, :424-429)
+                z0 = model.get_first_stage_encoding(model.encode_first_stage(x0_img.to(device).float()))
+                t0 = int(opt.target_start_noise_t)
+                t_q = torch.randint(t0 - 1, t0, (z0.shape[0],), device="cpu").long()
+                start_code = model.q_sample(x_start=z0, t=t_q, noise=torch.randn_like(z0))
             test_model_kwargs = {n: test_model_kwargs[n].to(device, non_blocking=True) for n in test_model_kwargs}
             B = test_batch.shape[0]
             uc = model.learnable_vector.repeat(B, 1, 1) if opt.scale != 1.0 else None

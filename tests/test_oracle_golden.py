@@ -142,6 +142,25 @@ def test_ddim_eta(golden_dir):
     close(samples, g["samples"], 1e-4)
 
 
+@pytest.mark.parametrize("S", [5, 10])
+def test_plms_small(golden_dir, S):
+    """oracle.ddim.plms_sample vs the reference's PLMSSampler (plms.py) with CFG 3.5."""
+    cfg, sd, plan = _small_unet()
+    eps = lambda x, t, c: unet.unet_forward(sd, plan, x, t, c, cfg.model_channels)
+    x_T, z_inp, mask, c, uc = _ddim_inputs()
+    g = G(golden_dir, f"plms_small_S{S}")
+    samples, inter = ddim.plms_sample(eps, S, x_T, c, uc, z_inp, mask, 3.5)
+    close(samples, g["samples"], 2e-4)
+    close(inter["pred_x0"][-1], g["pred_x0_last"], 2e-4)
+    assert len(inter["x_inter"]) == int(g["n_inter"])
+
+
+def test_q_sample(golden_dir):
+    g = G(golden_dir, "q_sample")
+    x = ddim.q_sample(rnd((2, 4, 16, 16), 35), torch.from_numpy(g["t"]), rnd((2, 4, 16, 16), 36))
+    close(x, g["x"], 1e-6)
+
+
 def test_vae_small(golden_dir):
     cfg = P.VAEConfig(**SMALL_VAE)
     sd = P.seeded_state_dict(P.vae_param_specs(cfg), 55)

@@ -141,6 +141,38 @@ def test_ddim_no_cfg_matches_oracle():
     assert maxerr(got, ref) < 2e-4, maxerr(got, ref)
 
 
+@pytest.mark.parametrize("S", [5, 10])
+def test_plms_vs_reference_golden(golden_dir, S):
+    """PLMSSampler on the HIP engine vs the reference's plms.py (CFG 3.5; improved-Euler first step, Adams-Bashforth after)."""
+    from reface_amd.plms import PLMSSampler
+    unet = make_unet(SMALL_UNET, 7)
+    sampler = PLMSSampler(_LDMStub(unet))
+    x_T, z_inp, mask, c, uc = _ddim_inputs()
+    g = G(golden_dir, f"plms_small_S{S}")
+    samples, inter = sampler.sample(S=S, conditioning=c.to(DEV), batch_size=2, shape=[4, 16, 16], verbose=False,
+                                    unconditional_guidance_scale=3.5, unconditional_conditioning=uc.to(DEV), eta=0.0,
+                                    x_T=x_T.to(DEV), test_model_kwargs={"inpaint_image": z_inp.to(DEV), "inpaint_mask": mask.to(DEV)})
+    assert maxerr(samples, g["samples"]) < 3e-4, maxerr(samples, g["samples"])
+    assert maxerr(inter["pred_x0"][-1], g["pred_x0_last"]) < 3e-4
+    assert len(inter["x_inter"]) == int(g["n_inter"])
+    with pytest.raises(ValueError, match="ddim_eta must be 0 for PLMS"):
+        sampler.sample(S=S, conditioning=c.to(DEV), batch_size=2, shape=[4, 16, 16], verbose=False, eta=0.5, x_T=x_T.to(DEV),
+                       test_model_kwargs={"inpaint_image": z_inp.to(DEV), "inpaint_mask": mask.to(DEV)})
+
+
+def test_q_sample_vs_reference_golden(golden_dir):
+    """LatentDiffusion.q_sample (--Start_from_target, ddpm.py:412-415) through the HIP combine kernel."""
+    import types
+    from reface_amd.ddpm import LatentDiffusion
+    from reface_amd.schedule import ddpm_buffers
+    g = G(golden_dir, "q_sample")
+    b = ddpm_buffers(1000, 0.00085, 0.0120)
+    host = types.SimpleNamespace(device=torch.device(DEV), sqrt_alphas_cumprod=b["sqrt_alphas_cumprod"],
+                                 sqrt_one_minus_alphas_cumprod=b["sqrt_one_minus_alphas_cumprod"])
+    x = LatentDiffusion.q_sample(host, rnd((2, 4, 16, 16), 35).to(DEV), torch.from_numpy(g["t"]), rnd((2, 4, 16, 16), 36).to(DEV))
+    assert maxerr(x, g["x"]) < 1e-6, maxerr(x, g["x"])
+
+
 def make_vae(cfg_kwargs, seed):
     from reface_amd.vae import AutoencoderKL
     dd = dict(cfg_kwargs)

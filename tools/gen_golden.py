@@ -194,6 +194,38 @@ def gen_ddim():
     save("ddim_small_S5_eta5", samples=samples, noises=noises, seed=7, scale=3.5)
 
 
+def gen_plms():
+    """PLMSSampler (plms.py) with CFG on the reduced-width UNet, and LatentDiffusion.q_sample (ddpm.py:412-415)."""
+    from ldm.models.diffusion.plms import PLMSSampler
+    PLMSSampler.register_buffer = lambda self, n, a: setattr(self, n, a)
+    cfg = P.UNetConfig(**SMALL_UNET)
+    m, _ = _ref_unet(cfg, 7)
+    ldm = _StubLDM(m)
+    sampler = PLMSSampler(ldm)
+    B, h = 2, 16
+    x_T = rnd((B, 4, h, h), 30)
+    z_inp = rnd((B, 4, h, h), 31)
+    mask = (rnd((B, 1, h, h), 32) > 0).float()
+    c = rnd((B, 1, 768), 33)
+    uc = rnd((1, 1, 768), 34).repeat(B, 1, 1)
+    for S in (5, 10):
+        samples, inter = sampler.sample(S=S, conditioning=c, batch_size=B, shape=[4, h, h], verbose=False,
+                                        unconditional_guidance_scale=3.5, unconditional_conditioning=uc, eta=0.0, x_T=x_T,
+                                        test_model_kwargs={"inpaint_image": z_inp, "inpaint_mask": mask})
+        save(f"plms_small_S{S}", samples=samples, pred_x0_last=inter["pred_x0"][-1], n_inter=len(inter["x_inter"]), seed=7, scale=3.5)
+    # q_sample through the reference DDPM buffers (register_schedule, fp32)
+    from ldm.models.diffusion.ddpm import DDPM
+    from reface_amd.schedule import ddpm_buffers
+    bufs = ddpm_buffers(1000, 0.00085, 0.0120)
+    host = type("H", (), {})()
+    host.sqrt_alphas_cumprod = bufs["sqrt_alphas_cumprod"]
+    host.sqrt_one_minus_alphas_cumprod = bufs["sqrt_one_minus_alphas_cumprod"]
+    z = rnd((B, 4, h, h), 35)
+    noise = rnd((B, 4, h, h), 36)
+    t = torch.tensor([999, 417])
+    save("q_sample", x=DDPM.q_sample(host, z, t, noise), t=t)
+
+
 SMALL_VAE = dict(ch=32, ch_mult=(1, 2, 4, 4), num_res_blocks=2, in_channels=3, out_ch=3, z_channels=4,
                  embed_dim=4, double_z=True, attn_resolutions=(), resolution=256)
 
@@ -393,7 +425,7 @@ def gen_e2e():
          z_inpaint=z_inpaint, mask64=mask64, samples=samples, x_dec=x_dec, u8=u8)
 
 
-GROUPS = dict(schedule=gen_schedule, unet_ops=gen_unet_ops, unet_small=gen_unet_small, unet_full=gen_unet_full,
+GROUPS = dict(plms=gen_plms, schedule=gen_schedule, unet_ops=gen_unet_ops, unet_small=gen_unet_small, unet_full=gen_unet_full,
               ddim=gen_ddim, vae=gen_vae, arcface=gen_arcface, clip=gen_clip, e2e=gen_e2e)
 
 if __name__ == "__main__":

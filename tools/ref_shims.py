@@ -136,3 +136,12 @@ def install():
     lp.LPIPS = LPIPS
 
     sys.path.insert(0, "/root/reference")
+    # The reference's `ldm` has no __init__.py (namespace package); this repository ships a regular `ldm` package (the drop-in
+    # import-path shim), which would win the lookup as soon as the repo root is on sys.path.  Pin `ldm` to the reference tree.
+    if "ldm" in sys.modules and not getattr(sys.modules["ldm"], "_reference_pinned", False):
+        raise RuntimeError("`ldm` was imported before tools/ref_shims.install(): it would not be the reference's")
+    import types
+    ldm = types.ModuleType("ldm")
+    ldm.__path__ = ["/root/reference/ldm"]
+    ldm._reference_pinned = True
+    sys.modules["ldm"] = ldm
