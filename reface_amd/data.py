@@ -1,8 +1,14 @@
 """Input contract of the test-bench datasets (ldm/data/test_bench_dataset.py:368): each item is
 ``(target[3,H,W] in [-1,1], prior, {inpaint_image, inpaint_mask, ref_imgs}, id_str)``.
 
-``SyntheticPairs`` produces seeded items of that contract (no dataset is reachable offline); the real
-CelebA / FFHQ / FF++ folder readers are a "next" row of the scope table."""
+``SyntheticPairs`` produces seeded items of that contract (no dataset is reachable offline).  ``CelebAdataset`` reads the
+CelebAMask-HQ folder layout the reference's test split uses (test_bench_dataset.py:130-222, 253-370), with PIL + numpy only:
+the reference goes through cv2 / albumentations for the 224x224 resize of the source face (cv2 INTER_LINEAR), which are not in
+this image -- PIL's bilinear filter stands in, so that one resize is "parity unpinned" (the tensors' shapes, ranges, mask
+semantics and normalisations are the reference's)."""
+import os
+
+import numpy as np
 import torch
 from torch.utils.data import Dataset
 
@@ -26,6 +32,80 @@ class SyntheticPairs(Dataset):
         ref = seeded_randn((1, 3, 224, 224), self.seed * 100003 + 3 * i + 1)      # CLIP-normalised reference (dataset adds a dim)
         inpaint = target * self.mask
         return target, target.clone(), {"inpaint_image": inpaint, "inpaint_mask": self.mask.clone(), "ref_imgs": ref}, f"{i:012d}"
+
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def _to_tensor(img):
+    """torchvision ToTensor: HWC uint8 -> CHW float in [0, 1] (an 'L' image gives one channel)."""
+    a = np.asarray(img, dtype=np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    return torch.from_numpy(a.transpose(2, 0, 1).copy()).float() / 255.0
+
+
+def _normalize(t, mean, std):
+    m = torch.tensor(mean, dtype=torch.float32).view(-1, 1, 1)
+    s = torch.tensor(std, dtype=torch.float32).view(-1, 1, 1)
+    return (t - m) / s
+
+
+class CelebAdataset(Dataset):
+    """Test split of CelebAMask-HQ as the REFace test bench reads it (ids 28000-28999 are targets, 29000-29999 sources; pair i is
+    (target i, source i)).  Item = (target [3,512,512] in [-1,1], prior, {inpaint_image, inpaint_mask (1 = keep), ref_imgs
+    [1,3,224,224] CLIP-normalised source face x its face mask}, 12-digit id) -- test_bench_dataset.py:262-370.
+
+    ``remove_mask_tar`` / ``preserve_mask_src`` are the segmentation labels (1 skin, 2 nose, ... 17 neck) that are cut out of the
+    target / kept in the source; ``gray_outer_mask=False`` selects the `__getitem_black__` variant (full source image, one label
+    list ``preserve_mask_src`` for both)."""
+
+    def __init__(self, state="test", dataset_dir="dataset/FaceData/CelebAMask-HQ", gray_outer_mask=True, remove_mask_tar=None,
+                 preserve_mask_src=None, preserve_mask=None, fraction=1.0, first_target=28000, n_targets=1000, first_source=29000,
+                 **_ignored):
+        if state != "test":
+            raise NotImplementedError("only the test split is on the inference path (train / validation splits feed main.py)")
+        from PIL import Image
+        self.Image = Image
+        self.gray_outer_mask = bool(gray_outer_mask)
+        if preserve_mask is not None:
+            remove_mask_tar = preserve_mask_src = preserve_mask
+        self.remove_tar = list(remove_mask_tar if remove_mask_tar is not None else [1, 2, 4, 5, 8, 9, 6, 7, 10, 11, 12, 17])
+        self.preserve_src = list(preserve_mask_src if preserve_mask_src is not None else [1, 2, 4, 5, 8, 9, 6, 7, 10, 11, 12, 13, 17])
+        j = os.path.join
+        ids_t = range(first_target, first_target + n_targets)
+        ids_s = range(first_source, first_source + n_targets)
+        self.imgs = sorted(j(dataset_dir, "CelebA-HQ-img", f"{i}.jpg") for i in ids_t)
+        self.labels = sorted(j(dataset_dir, "CelebA-HQ-mask/Overall_mask", f"{i}.png") for i in ids_t)
+        self.ref_imgs = sorted(j(dataset_dir, "CelebA-HQ-img", f"{i}.jpg") for i in ids_s)
+        self.ref_labels = sorted(j(dataset_dir, "CelebA-HQ-mask/Overall_mask", f"{i}.png") for i in ids_s)
+        n = int(len(self.imgs) * fraction)
+        self.imgs, self.labels, self.ref_imgs, self.ref_labels = self.imgs[:n], self.labels[:n], self.ref_imgs[:n], self.ref_labels[:n]
+
+    def __len__(self):
+        return len(self.imgs)
+
+    def _label_mask(self, path, keep):
+        lab = np.array(self.Image.open(path).convert("L"))
+        return self.Image.fromarray(np.where(np.isin(lab, keep), 255, 0).astype(np.uint8)).convert("L")
+
+    def __getitem__(self, index):
+        Image = self.Image
+        img_p = Image.open(self.imgs[index]).convert("RGB").resize((512, 512))                 # PIL default filter, as the reference
+        image_tensor = _normalize(_to_tensor(img_p), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
+        tar_labels = self.remove_tar if self.gray_outer_mask else self.preserve_src
+        mask_tensor = 1.0 - _to_tensor(self._label_mask(self.labels[index], tar_labels))     # 1 = keep, 0 = region to generate
+        ref = Image.open(self.ref_imgs[index]).convert("RGB").resize((224, 224), Image.BILINEAR)   # A.Resize(224, 224): cv2 linear
+        ref_tensor = _normalize(_to_tensor(ref), CLIP_MEAN, CLIP_STD)
+        if self.gray_outer_mask:
+            ref_mask = _to_tensor(self._label_mask(self.ref_labels[index], self.preserve_src))
+            # T.Resize((224, 224)) on a tensor: bilinear, no antialias (torchvision <= 0.14)
+            ref_mask = torch.nn.functional.interpolate(ref_mask[None], size=(224, 224), mode="bilinear", align_corners=False)[0]
+            ref_tensor = ref_tensor * ref_mask
+        inpaint_tensor = image_tensor * mask_tensor
+        return image_tensor, image_tensor, {"inpaint_image": inpaint_tensor, "inpaint_mask": mask_tensor,
+                                            "ref_imgs": ref_tensor.unsqueeze(0)}, str(index).zfill(12)
 
 
 def shard_indices(n, rank, world):

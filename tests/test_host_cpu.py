@@ -219,3 +219,41 @@ def test_multiprocess_sharding_gloo(tmp_path):
                         "--master-port", "29533", str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "GLOO_OK 7 4" in r.stdout
+
+
+def test_celeba_reader_contract(tmp_path):
+    """CelebAdataset on a synthetic CelebAMask-HQ tree: tensor contract of test_bench_dataset.py:262-370 (shapes, ranges,
+    mask semantics: target mask 1 = keep outside the removed labels, source face x its preserved-label mask, CLIP normalisation)."""
+    from PIL import Image
+    from reface_amd.data import CLIP_MEAN, CLIP_STD, CelebAdataset
+    root = tmp_path / "CelebAMask-HQ"
+    (root / "CelebA-HQ-img").mkdir(parents=True)
+    (root / "CelebA-HQ-mask" / "Overall_mask").mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    for i in (28000, 28001, 29000, 29001):
+        Image.fromarray(rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)).save(root / "CelebA-HQ-img" / f"{i}.jpg")
+        lab = np.zeros((512, 512), np.uint8)
+        lab[128:384, 160:352] = 1                 # skin
+        lab[200:260, 230:280] = 2                 # nose
+        lab[0:100, :] = 13                        # hair: kept in the source, not removed from the target
+        Image.fromarray(lab).save(root / "CelebA-HQ-mask" / "Overall_mask" / f"{i}.png")
+    ds = CelebAdataset(state="test", dataset_dir=str(root), gray_outer_mask=True, n_targets=2,
+                       remove_mask_tar=[1, 2, 4, 5, 8, 9, 6, 7, 10, 11, 12, 17], preserve_mask_src=[1, 2, 4, 5, 8, 9, 6, 7, 10, 11, 12, 13, 17])
+    assert len(ds) == 2
+    tar, prior, kw, sid = ds[1]
+    assert sid == "000000000001" and tar.shape == (3, 512, 512) and prior.shape == (3, 512, 512)
+    assert -1.0 <= float(tar.min()) and float(tar.max()) <= 1.0
+    m = kw["inpaint_mask"]
+    assert m.shape == (1, 512, 512) and set(np.unique(m.numpy()).tolist()) == {0.0, 1.0}
+    assert m[0, 256, 256] == 0 and m[0, 50, 50] == 1 and m[0, 450, 50] == 1          # face removed, hair / background kept
+    assert torch.equal(kw["inpaint_image"], tar * m)
+    ref = kw["ref_imgs"]
+    assert ref.shape == (1, 3, 224, 224)
+    zero = torch.tensor([(0 - mu) / sd for mu, sd in zip(CLIP_MEAN, CLIP_STD)]).view(3, 1, 1)
+    assert torch.all(ref[0][:, 200:, :20] == 0)                                     # outside the preserved labels: multiplied by 0
+    assert (ref[0][:, 100:150, 90:130] != 0).any() and float(ref.abs().max()) < 3.0
+    black = CelebAdataset(state="test", dataset_dir=str(root), gray_outer_mask=False, n_targets=2, preserve_mask_src=[1, 2])
+    _, _, kb, _ = black[0]
+    assert (kb["ref_imgs"][0][:, 200:, :20] != 0).any()                             # full source image in the black-mask variant
+    with pytest.raises(NotImplementedError):
+        CelebAdataset(state="train", dataset_dir=str(root))
