@@ -104,6 +104,9 @@ int rf_conv_gemm_plan(const rf_conv_gemm_desc* d, int32_t* bm, int32_t* bn, int3
  * model.py:33-39; openaimodel.py:201-203,225-227,832-834).
  */
 int rf_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, int ldx, int nchunks, double* partial, void* stream);
+/* [B][nchunks][32][2] -> [B][1][32][2] in a fixed summation order: compacts the many chunk slots that GEMM-fused statistics produce
+ * on large images (one slot per output tile) so that rf_groupnorm_apply reads one slot per sample. */
+int rf_groupnorm_finalize(const double* partial_in, int B, int nchunks, double* partial_out, void* stream);
 int rf_groupnorm_apply(int dtype, const void* x, int B, int HW, int C, int ldx, int nchunks, const double* partial,
                        const float* gamma, const float* beta, float eps, int silu, int out_dtype, void* out, int ldo, void* stream);
 

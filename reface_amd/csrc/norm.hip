@@ -304,6 +304,34 @@ extern "C" int rf_groupnorm_stats(int dtype, const void* x, int B, int HW, int C
     return 0;
 }
 
+// sum the chunk partials of every (sample, group) in a fixed order: [B][nchunks][32][2] -> [B][1][32][2]
+__global__ __launch_bounds__(GN_THREADS) void gn_finalize_kernel(const double* __restrict__ in, int nchunks, double* __restrict__ out) {
+    const int b = blockIdx.x, g = threadIdx.x & 31, part = threadIdx.x >> 5;
+    __shared__ double red[GN_THREADS][2];
+    double a = 0.0, q = 0.0;
+    for (int c = part; c < nchunks; c += GN_THREADS / 32) {
+        const double* pp = in + (((long long)b * nchunks + c) * 32 + g) * 2;
+        a += pp[0];
+        q += pp[1];
+    }
+    red[threadIdx.x][0] = a;
+    red[threadIdx.x][1] = q;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double sa = 0.0, sq = 0.0;
+        for (int k = 0; k < GN_THREADS / 32; ++k) { sa += red[threadIdx.x + 32 * k][0]; sq += red[threadIdx.x + 32 * k][1]; }
+        out[((long long)b * 32 + threadIdx.x) * 2] = sa;
+        out[((long long)b * 32 + threadIdx.x) * 2 + 1] = sq;
+    }
+}
+
+extern "C" int rf_groupnorm_finalize(const double* partial_in, int B, int nchunks, double* partial_out, void* stream) {
+    RF_CHECK(partial_in && partial_out && B > 0 && nchunks >= 1, "rf_groupnorm_finalize: bad arguments");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(GN_THREADS), 0, (hipStream_t)stream, partial_in, nchunks, partial_out);
+    RF_LAUNCH_CHECK("rf_groupnorm_finalize");
+    return 0;
+}
+
 extern "C" int rf_groupnorm_apply(int dtype, const void* x, int B, int HW, int C, int ldx, int nchunks, const double* partial,
                                   const float* gamma, const float* beta, float eps, int silu, int out_dtype, void* out, int ldo, void* stream) {
     if (gn_check("rf_groupnorm_apply", dtype, C, ldx, nchunks)) return 1;

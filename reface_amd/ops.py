@@ -165,7 +165,8 @@ def conv2d(x, W, out, bias=None, *, ksize=3, stride=1, pad=(1, 1), ups=0, x2=Non
 
 
 GN_MAX_CHUNKS = 32
-GN_FUSED_MAX_CHUNKS = 96     # chunk slots per sample a GEMM-fused statistics buffer may have
+GN_FUSED_MAX_CHUNKS = 96     # chunk slots per sample rf_groupnorm_apply re-reduces itself; above that a finalize pass compacts them
+GN_FUSED_MAX_SLOTS = 1 << 16
 
 
 def gn_chunks(B, HW):
@@ -204,7 +205,8 @@ def fuse_groupnorm_stats(x, producers):
     """Let the GEMMs that wrote ``x`` [B, H, W, C] also emit its GroupNorm(32) partial sums.
 
     ``producers``: [(launch, row0, rows, col0, cols)] -- prepared rf_conv_gemm launches that together tile the [B*H*W, C] matrix
-    (column slices of a concat buffer, batch halves).  Returns (partial, nchunks) for groupnorm_apply, or None when some
+    (column slices of a concat buffer, batch halves).  Returns (partial, nchunks, extra launches to run before the apply) for
+    groupnorm_apply, or None when some
     producer cannot do it (tile rows straddling samples, GEGLU, both consumer slots taken, uneven tiling).
     """
     B, H, W_, Cc = x.shape
@@ -229,7 +231,7 @@ def fuse_groupnorm_stats(x, producers):
         elif slot_of[key][1] != per_sample:
             return None
         plans.append((l, row0, key))
-    if nslots > GN_FUSED_MAX_CHUNKS:
+    if nslots > GN_FUSED_MAX_SLOTS:
         return None
     partial = torch.zeros((B, nslots, 32, 2), dtype=torch.float64, device=x.device)
     for l, row0, key in plans:
@@ -241,7 +243,12 @@ def fuse_groupnorm_stats(x, producers):
         else:
             d.gn_part1, d.gn_cpg1, d.gn_coff1, d.gn_slot1, d.gn_nchunks1 = part.data_ptr(), Cc // 32, key[0], slot_of[key][0], nslots
         l.keep = tuple(l.keep) + (partial,)
-    return partial, nslots
+    if nslots > GN_FUSED_MAX_CHUNKS:        # many tiles per sample (large images): compact to one slot per sample first
+        lib = _lib.load()
+        compact = torch.zeros((B, 1, 32, 2), dtype=torch.float64, device=x.device)
+        fin = Launch(lib.rf_groupnorm_finalize, (_p(partial), B, nslots, _p(compact)), (partial, compact), "groupnorm.finalize")
+        return compact, 1, [fin]
+    return partial, nslots, []
 
 
 def groupnorm_apply(x, gamma, beta, out, partial, nchunks, *, eps, silu, name="groupnorm"):

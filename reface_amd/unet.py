@@ -206,6 +206,7 @@ class UNetEngine:
             if prods is not None:
                 fused = ops.fuse_groupnorm_stats(x, prods)
         if fused is not None:
+            self.main += fused[2]
             self.main.append(ops.groupnorm_apply(x, self.f32(key + ".weight"), self.f32(key + ".bias"), out, fused[0], fused[1],
                                                  eps=eps, silu=silu, name=key))
             self.gn_fused += 1

@@ -86,6 +86,7 @@ class _VAEEngine:
             if prods is not None:
                 fused = ops.fuse_groupnorm_stats(x, prods)
         if fused is not None:
+            self.launches += fused[2]
             self.launches.append(ops.groupnorm_apply(x, self.f32(key + ".weight"), self.f32(key + ".bias"), out, fused[0], fused[1],
                                                      eps=1e-6, silu=silu, name=key))
             self.gn_fused += 1

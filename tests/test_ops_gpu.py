@@ -168,7 +168,7 @@ def test_groupnorm(dt, Cc, hw, silu, eps):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("c0,c1,hw,B,kin", [(320, 0, 32, 2, 64), (640, 320, 32, 2, 64), (1280, 640, 16, 4, 64), (1280, 640, 16, 4, 2048), (1280, 1280, 8, 4, 2048)])
+@pytest.mark.parametrize("c0,c1,hw,B,kin", [(320, 0, 32, 2, 64), (640, 320, 32, 2, 64), (1280, 640, 16, 4, 64), (1280, 640, 16, 4, 2048), (1280, 1280, 8, 4, 2048), (128, 0, 128, 2, 64)])
 def test_groupnorm_stats_fused_into_gemm(dt, c0, c1, hw, B, kin):
     """GroupNorm whose statistics come out of the producing GEMMs' epilogues (rf_conv_gemm gn_* fields): a concat buffer
     [h | skip] written by two GEMMs (the skip one also feeds a second consumer with another grouping), vs torch on the stored tensor."""
@@ -196,6 +196,7 @@ def test_groupnorm_stats_fused_into_gemm(dt, c0, c1, hw, B, kin):
         second = ops.fuse_groupnorm_stats(cat[..., c0:], [(prods[1][0], 0, B * hw * hw, 0, c1)])
         assert second is not None
     ops.run([p_[0] for p_ in prods])
+    ops.run(fused[2])
     g, be = rnd((Cc,), 98) * 0.2 + 1, rnd((Cc,), 99) * 0.2
     y = torch.empty_like(cat)
     ops.groupnorm_apply(cat, g.to(DEV), be.to(DEV), y, fused[0], fused[1], eps=1e-5, silu=True)()
@@ -203,6 +204,7 @@ def test_groupnorm_stats_fused_into_gemm(dt, c0, c1, hw, B, kin):
     ref = F.silu(F.group_norm(cat.float().cpu().permute(0, 3, 1, 2), 32, g, be, 1e-5)).permute(0, 2, 3, 1)
     check(y, ref, dt)
     if second is not None:
+        ops.run(second[2])
         y2 = torch.empty((B, hw, hw, c1), dtype=dt, device=DEV)
         ops.groupnorm_apply(cat[..., c0:], g[:c1].to(DEV), be[:c1].to(DEV), y2, second[0], second[1], eps=1e-5, silu=False)()
         torch.cuda.synchronize()
