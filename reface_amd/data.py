@@ -60,6 +60,8 @@ class CelebAdataset(Dataset):
     ``remove_mask_tar`` / ``preserve_mask_src`` are the segmentation labels (1 skin, 2 nose, ... 17 neck) that are cut out of the
     target / kept in the source; ``gray_outer_mask=False`` selects the `__getitem_black__` variant (full source image, one label
     list ``preserve_mask_src`` for both)."""
+    IMG_DIR, IMG_FMT = "CelebA-HQ-img", "{}.jpg"
+    MASK_DIR, MASK_FMT = "CelebA-HQ-mask/Overall_mask", "{}.png"
 
     def __init__(self, state="test", dataset_dir="dataset/FaceData/CelebAMask-HQ", gray_outer_mask=True, remove_mask_tar=None,
                  preserve_mask_src=None, preserve_mask=None, fraction=1.0, first_target=28000, n_targets=1000, first_source=29000,
@@ -76,10 +78,10 @@ class CelebAdataset(Dataset):
         j = os.path.join
         ids_t = range(first_target, first_target + n_targets)
         ids_s = range(first_source, first_source + n_targets)
-        self.imgs = sorted(j(dataset_dir, "CelebA-HQ-img", f"{i}.jpg") for i in ids_t)
-        self.labels = sorted(j(dataset_dir, "CelebA-HQ-mask/Overall_mask", f"{i}.png") for i in ids_t)
-        self.ref_imgs = sorted(j(dataset_dir, "CelebA-HQ-img", f"{i}.jpg") for i in ids_s)
-        self.ref_labels = sorted(j(dataset_dir, "CelebA-HQ-mask/Overall_mask", f"{i}.png") for i in ids_s)
+        self.imgs = sorted(j(dataset_dir, self.IMG_DIR, self.IMG_FMT.format(i)) for i in ids_t)
+        self.labels = sorted(j(dataset_dir, self.MASK_DIR, self.MASK_FMT.format(i)) for i in ids_t)
+        self.ref_imgs = sorted(j(dataset_dir, self.IMG_DIR, self.IMG_FMT.format(i)) for i in ids_s)
+        self.ref_labels = sorted(j(dataset_dir, self.MASK_DIR, self.MASK_FMT.format(i)) for i in ids_s)
         n = int(len(self.imgs) * fraction)
         self.imgs, self.labels, self.ref_imgs, self.ref_labels = self.imgs[:n], self.labels[:n], self.ref_imgs[:n], self.ref_labels[:n]
 
@@ -106,6 +108,20 @@ class CelebAdataset(Dataset):
         inpaint_tensor = image_tensor * mask_tensor
         return image_tensor, image_tensor, {"inpaint_image": inpaint_tensor, "inpaint_mask": mask_tensor,
                                             "ref_imgs": ref_tensor.unsqueeze(0)}, str(index).zfill(12)
+
+
+class FFHQdataset(CelebAdataset):
+    """FFHQ test split (test_bench_dataset.py:456-700): ``images512/%05d.png`` + ``BiSeNet_mask/%05d.png``, targets 68000-68999,
+    sources 69000-69999, label lists ``remove_mask_tar_FFHQ`` / ``preserve_mask_src_FFHQ``; same item contract as CelebA."""
+    IMG_DIR, IMG_FMT = "images512", "{:05d}.png"
+    MASK_DIR, MASK_FMT = "BiSeNet_mask", "{:05d}.png"
+
+    def __init__(self, state="test", dataset_dir="dataset/FaceData/FFHQ", remove_mask_tar_FFHQ=None, preserve_mask_src_FFHQ=None,
+                 first_target=68000, first_source=69000, **kw):
+        kw.pop("remove_mask_tar", None)
+        kw.pop("preserve_mask_src", None)
+        super().__init__(state=state, dataset_dir=dataset_dir, remove_mask_tar=remove_mask_tar_FFHQ, preserve_mask_src=preserve_mask_src_FFHQ,
+                         first_target=first_target, first_source=first_source, **kw)
 
 
 def shard_indices(n, rank, world):

@@ -142,8 +142,8 @@ def main(argv=None):
         from reface_amd.data import SyntheticPairs, shard_indices
         full = SyntheticPairs(n=opt.n_items, image_size=opt.H, seed=opt.seed)
         test_dataset = torch.utils.data.Subset(full, shard_indices(len(full), rank, world))
-    elif opt.dataset == "CelebA":                    # inference_test_bench.py:374-377: data.params.test.params of the config
-        from reface_amd.data import CelebAdataset, shard_indices
+    elif opt.dataset in ("CelebA", "FFHQ"):          # inference_test_bench.py:374-381: data.params.test.params of the config
+        from reface_amd.data import CelebAdataset, FFHQdataset, shard_indices
         test_args = {}
         try:
             test_args = dict(config.data.params.test.params)
@@ -152,11 +152,11 @@ def main(argv=None):
         if opt.dataset_dir is not None and "dataset_dir" not in test_args:
             test_args["dataset_dir"] = opt.dataset_dir
         test_args.setdefault("state", "test")
-        full = CelebAdataset(**test_args)
+        full = (CelebAdataset if opt.dataset == "CelebA" else FFHQdataset)(**test_args)
         test_dataset = torch.utils.data.Subset(full, shard_indices(len(full), rank, world))
     else:
-        raise NotImplementedError(f"--dataset {opt.dataset}: the FFHQ / FF++ folder readers (ldm/data/test_bench_dataset.py:470-839) "
-                                  "are part of the 'next' row 8f.1; CelebA and synthetic are available")
+        raise NotImplementedError(f"--dataset {opt.dataset}: the FF++ folder reader (ldm/data/test_bench_dataset.py:700-839) "
+                                  "is part of the 'next' row 8f.1; CelebA, FFHQ and synthetic are available")
     loader = torch.utils.data.DataLoader(test_dataset, batch_size=batch_size, num_workers=0, shuffle=False, drop_last=False)
 
     start_code = None

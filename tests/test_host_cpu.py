@@ -257,3 +257,22 @@ def test_celeba_reader_contract(tmp_path):
     assert (kb["ref_imgs"][0][:, 200:, :20] != 0).any()                             # full source image in the black-mask variant
     with pytest.raises(NotImplementedError):
         CelebAdataset(state="train", dataset_dir=str(root))
+
+
+def test_ffhq_reader_layout(tmp_path):
+    """FFHQdataset: images512/%05d.png + BiSeNet_mask/%05d.png, ids 68000.. / 69000.., *_FFHQ label lists; contract as CelebA."""
+    from PIL import Image
+    from reface_amd.data import FFHQdataset
+    root = tmp_path / "FFHQ"
+    (root / "images512").mkdir(parents=True)
+    (root / "BiSeNet_mask").mkdir(parents=True)
+    rng = np.random.default_rng(1)
+    for i in (68000, 69000):
+        Image.fromarray(rng.integers(0, 256, (512, 512, 3), dtype=np.uint8)).save(root / "images512" / f"{i:05d}.png")
+        lab = np.zeros((512, 512), np.uint8)
+        lab[100:400, 100:400] = 1
+        Image.fromarray(lab).save(root / "BiSeNet_mask" / f"{i:05d}.png")
+    ds = FFHQdataset(state="test", dataset_dir=str(root), gray_outer_mask=True, n_targets=1, remove_mask_tar_FFHQ=[1], preserve_mask_src_FFHQ=[1])
+    tar, _, kw, sid = ds[0]
+    assert len(ds) == 1 and sid == "000000000000" and tar.shape == (3, 512, 512)
+    assert kw["inpaint_mask"][0, 250, 250] == 0 and kw["inpaint_mask"][0, 10, 10] == 1 and kw["ref_imgs"].shape == (1, 3, 224, 224)
