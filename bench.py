@@ -129,14 +129,14 @@ def cpu_baseline(cpu_sd, cores):
             "sample": f"B=1: 1 CFG DDIM step (UNet batch 2, latent 64x64) = {t_step:.2f}s scaled x50, + 1 fp32 VAE decode 512x512 = {t_dec:.2f}s"}
 
 
-def conditioning_line(vae, B, h, device):
+def conditioning_line(vae, B, h, device, enc_dtype=torch.float32):
     """the once-per-image conditioning stage as a separate line -- CLIP ViT-L/14 on the reference and on the
     (resized) target, ArcFace IR-SE50 on the reference, fp32 KL-VAE encode of the 512x512 masked target -- fp32, batch B."""
     from reface_amd import params as P
     from reface_amd.encoders import Backbone, FrozenCLIPEmbedder, target_to_clip_input
-    clip = FrozenCLIPEmbedder()
+    clip = FrozenCLIPEmbedder(compute_dtype=enc_dtype)
     clip.load_state_dict(P.seeded_state_dict(P.clip_param_specs(clip.cfg), 88), strict=True)
-    arc = Backbone(input_size=112, num_layers=50, drop_ratio=0.6, mode="ir_se")
+    arc = Backbone(input_size=112, num_layers=50, drop_ratio=0.6, mode="ir_se", compute_dtype=enc_dtype)
     arc.load_state_dict(P.seeded_state_dict(P.arcface_param_specs(), 77), strict=True)
     clip.to(device)
     arc.to(device)
@@ -159,7 +159,8 @@ def conditioning_line(vae, B, h, device):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all() and torch.isfinite(out[3].mean).all()
-    return {"metric": "conditioning images/sec (2x CLIP ViT-L/14 + ArcFace IR-SE50 + fp32 VAE encode 512x512, fp32)", "value": B / dt,
+    tag = "fp32" if enc_dtype == torch.float32 else "bf16 towers"
+    return {"metric": f"conditioning images/sec (2x CLIP ViT-L/14 + ArcFace IR-SE50 [{tag}] + fp32 VAE encode 512x512)", "value": B / dt,
             "unit": "images/s", "ms_per_batch": dt * 1e3, "batch": B, "algorithmic_gflop_per_image": 1116.7 + 2 * 155.53 + 12.59}
 
 
@@ -306,6 +307,9 @@ def main():
         try:
             result["conditioning"] = conditioning_line(vae, B, h, device)
             log(f"[bench] conditioning stage: {result['conditioning']['value']:.1f} images/s ({result['conditioning']['ms_per_batch']:.1f} ms per batch of {B})")
+            if dtype == torch.bfloat16:         # what the CLI's --precision bf16 runs: bf16 towers, fp32 VAE encode
+                result["conditioning_bf16_towers"] = conditioning_line(vae, B, h, device, torch.bfloat16)
+                log(f"[bench] conditioning stage, bf16 towers: {result['conditioning_bf16_towers']['value']:.1f} images/s")
         except Exception as e:        # the headline number must not depend on this side line
             result["conditioning"] = {"error": repr(e)}
     if want_cpu:

@@ -120,7 +120,7 @@ def main(argv=None):
     device = torch.device("cuda")
     model = model.to(device)
     if opt.precision in ("autocast", "bf16"):
-        model.set_compute_dtype(torch.bfloat16)
+        model.set_compute_dtype(torch.bfloat16, encoders=True)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
