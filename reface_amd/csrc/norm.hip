@@ -113,6 +113,28 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
 
     __shared__ float mean_s[32], rstd_s[32];
     __shared__ double red[GN_THREADS][2];
+    // Everything that does not depend on the statistics is fetched first -- affine parameters and this thread's first pixel --
+    // so that the small low-resolution launches pay ONE global-memory latency, not three in a row (partials -> gamma/beta -> x)
+    const int ppc = (HW + achunks - 1) / achunks;
+    const int p0 = blockIdx.x * ppc, p1 = min(HW, p0 + ppc);
+    float gm[GN_SLOTS][VEC], bt[GN_SLOTS][VEC];
+    u32x4_t raw0[GN_SLOTS];
+#pragma unroll
+    for (int q = 0; q < GN_SLOTS; ++q) {
+        const int v = tv + q * TV;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { gm[q][e] = 0.f; bt[q][e] = 0.f; }
+        raw0[q] = u32x4_t{0u, 0u, 0u, 0u};
+        if (v < nvec) {
+#pragma unroll
+            for (int e = 0; e < VEC; e += 4) {
+                const f32x4_t g4 = *(const f32x4_t*)(gamma + v * VEC + e), b4 = *(const f32x4_t*)(beta + v * VEC + e);
+                gm[q][e] = g4[0]; gm[q][e + 1] = g4[1]; gm[q][e + 2] = g4[2]; gm[q][e + 3] = g4[3];
+                bt[q][e] = b4[0]; bt[q][e + 1] = b4[1]; bt[q][e + 2] = b4[2]; bt[q][e + 3] = b4[3];
+            }
+            if (pl < PL && p0 + pl < p1) raw0[q] = *(const u32x4_t*)(x + ((long long)b * HW + p0 + pl) * ldx + v * VEC);
+        }
+    }
     {   // reduce the per-chunk partials of sample b: thread -> (group, part)
         const int g = threadIdx.x & 31, part = threadIdx.x >> 5;
         double a = 0.0, q = 0.0;
@@ -145,15 +167,13 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
             sc[q][e] = sh[q][e] = 0.f;
             if (v < nvec) {
                 const int c = v * VEC + e, g = c / cpg;
-                const float a = rstd_s[g] * gamma[c];
+                const float a = rstd_s[g] * gm[q][e];
                 sc[q][e] = a;
-                sh[q][e] = beta[c] - mean_s[g] * a;
+                sh[q][e] = bt[q][e] - mean_s[g] * a;
             }
         }
     }
     if (pl >= PL) return;
-    const int ppc = (HW + achunks - 1) / achunks;
-    const int p0 = blockIdx.x * ppc, p1 = min(HW, p0 + ppc);
     for (int p = p0 + pl; p < p1; p += PL) {
         const T* row = x + ((long long)b * HW + p) * ldx;
         TO* orow = out + ((long long)b * HW + p) * ldo;
@@ -162,7 +182,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
             const int v = tv + q * TV;
             if (v < nvec) {
                 float f[VEC];
-                unpack16<T>(*(const u32x4_t*)(row + v * VEC), f);
+                unpack16<T>(p == p0 + pl ? raw0[q] : *(const u32x4_t*)(row + v * VEC), f);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     float y = f[e] * sc[q][e] + sh[q][e];
@@ -201,7 +221,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     for (int q = 0; q < LN_MAXV; ++q) {
         const int v = lane + q * 64;
         if (v < nvec) {
-            unpack16<T>(*(const u32x4_t*)(xr + v * VEC), f[q]);
+            const u32x4_t raw = *(const u32x4_t*)(xr + v * VEC);
+            unpack16<T>(raw, f[q]);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) sum += f[q][e];
         }
@@ -225,8 +246,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
             float y[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                const int c = v * VEC + e;
-                y[e] = (f[q][e] - mean) * rstd * gamma[c] + beta[c];
+                y[e] = (f[q][e] - mean) * rstd * gamma[v * VEC + e] + beta[v * VEC + e];
             }
             if constexpr (sizeof(TO) == sizeof(T)) {
                 *(u32x4_t*)(orow + v * VEC) = pack16<TO>(y);
@@ -336,6 +356,7 @@ extern "C" int rf_groupnorm_apply(int dtype, const void* x, int B, int HW, int C
                                   const float* gamma, const float* beta, float eps, int silu, int out_dtype, void* out, int ldo, void* stream) {
     if (gn_check("rf_groupnorm_apply", dtype, C, ldx, nchunks)) return 1;
     RF_CHECK(x && partial && gamma && beta && out && B > 0 && HW > 0, "rf_groupnorm_apply: bad arguments");
+    RF_CHECK((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "rf_groupnorm_apply: gamma / beta must be 16-byte aligned");
     RF_CHECK(out_dtype == RF_F32 || out_dtype == RF_BF16, "rf_groupnorm_apply: bad out_dtype");
     RF_CHECK(ldo % 8 == 0, "rf_groupnorm_apply: ldo=%d must be a multiple of 8", ldo);
     // blocks of >= ~16 pixels, about 4 blocks per CU in total
@@ -361,6 +382,7 @@ extern "C" int rf_layernorm(int dtype, const void* x, int M, int C, int ldx, con
     RF_CHECK(dtype == RF_F32 || dtype == RF_BF16, "rf_layernorm: bad dtype %d", dtype);
     RF_CHECK(out_dtype == RF_F32 || out_dtype == RF_BF16, "rf_layernorm: bad out_dtype");
     RF_CHECK(x && gamma && beta && out && M > 0, "rf_layernorm: bad arguments");
+    RF_CHECK((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "rf_layernorm: gamma / beta must be 16-byte aligned");
     RF_CHECK(C % vec == 0 && ldx % vec == 0 && ldo % 8 == 0 && C / vec <= 64 * LN_MAXV, "rf_layernorm: C=%d ldx=%d ldo=%d unsupported", C, ldx, ldo);
     dim3 grid((M + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
