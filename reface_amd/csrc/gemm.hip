@@ -683,6 +683,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[u][e] = 0.f;
             }
+            // residual and per-sample vector of the U rows: issued with (not after) the partial-sum loads
+            typedef typename std::conditional<sizeof(TO) == 2, u32x2_t, f32x4_t>::type resv_t;
+            const bool full = vec && col + 3 < p.N;
+            resv_t rq[U];
+            f32x4_t rv4[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int row = m0 + rp + 4 * (k0 + u);
+                rv4[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (ok[u] && full) {
+                    if (resp) rq[u] = *(const resv_t*)(resp + (long long)row * p.ldr + col);
+                    if (p.rowvec) rv4[u] = *(const f32x4_t*)(p.rowvec + (long long)(row / p.rows_per_sample) * p.ldv + col);
+                }
+            }
             for (int z = 0; z < p.splitk; ++z) {
                 f32x4_t a[U];
 #pragma unroll
@@ -704,23 +718,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
             for (int u = 0; u < U; ++u) {
                 if (!ok[u]) continue;
                 const int row = m0 + rp + 4 * (k0 + u);
-                const float* rv = p.rowvec ? p.rowvec + (long long)(row / p.rows_per_sample) * p.ldv : nullptr;
-                const bool full = vec && col + 3 < p.N;
+                const float* rv = (p.rowvec && !full) ? p.rowvec + (long long)(row / p.rows_per_sample) * p.ldv : nullptr;
                 float y4[4] = {0.f, 0.f, 0.f, 0.f}, r4[4] = {0.f, 0.f, 0.f, 0.f};
                 if (resp && full) {
                     if constexpr (sizeof(TO) == 2) {
-                        const u32x2_t q = *(const u32x2_t*)(resp + (long long)row * p.ldr + col);
-                        r4[0] = as_f32(q[0] << 16); r4[1] = as_f32(q[0] & 0xffff0000u); r4[2] = as_f32(q[1] << 16); r4[3] = as_f32(q[1] & 0xffff0000u);
+                        r4[0] = as_f32(rq[u][0] << 16); r4[1] = as_f32(rq[u][0] & 0xffff0000u); r4[2] = as_f32(rq[u][1] << 16); r4[3] = as_f32(rq[u][1] & 0xffff0000u);
                     } else {
-                        const f32x4_t q = *(const f32x4_t*)(resp + (long long)row * p.ldr + col);
-                        r4[0] = q[0]; r4[1] = q[1]; r4[2] = q[2]; r4[3] = q[3];
+                        r4[0] = rq[u][0]; r4[1] = rq[u][1]; r4[2] = rq[u][2]; r4[3] = rq[u][3];
                     }
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int c = col + e;
                     if (c >= p.N) break;
-                    float y = v[u][e] * p.alpha + cadd[e];
+                    float y = v[u][e] * p.alpha + cadd[e] + rv4[u][e];
                     if (rv) y += rv[c];
                     if (p.act == RF_ACT_SILU) y = silu_exact(y);
                     else if (p.act == RF_ACT_QUICK_GELU) y = quick_gelu(y);
