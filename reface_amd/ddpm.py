@@ -189,13 +189,15 @@ class LatentDiffusion(nn.Module, _DeviceMixin):
 
     def set_compute_dtype(self, dtype, encoders=False):
         """Storage/MFMA dtype of the UNet (torch.float32 = exact-fp32 parity mode, torch.bfloat16 = throughput mode).
-        ``encoders=True`` also switches the CLIP ViT-L/14 and ArcFace towers (2.8x faster conditioning stage; the conditioning vector
-        then deviates ~1 % from fp32 -- throughput mode only, the VAE stays fp32)."""
+        ``encoders=True`` also switches the CLIP ViT-L/14 / ArcFace towers and the VAE *encoder* (conditioning stage 4x faster; the
+        conditioning vector and the inpaint latent then deviate ~1 % from fp32 -- throughput mode only; the VAE decode stays fp32)."""
         self.model.diffusion_model.set_compute_dtype(dtype)
         if encoders:
             for m in (getattr(self, "cond_stage_model", None), getattr(getattr(self, "face_ID_model", None), "facenet", None)):
                 if m is not None and hasattr(m, "compute_dtype"):
                     m.compute_dtype = dtype
+            if hasattr(self, "first_stage_model"):
+                self.first_stage_model.encode_dtype = dtype        # the masked-target latent feeds a UNet of this dtype anyway
 
     # ------------------------------------------------------------------ conditioning (ddpm.py:859-1045, 1068-1099)
     def get_learned_conditioning(self, c):

@@ -274,11 +274,13 @@ class AutoencoderKL(nn.Module):
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("reface_amd.AutoencoderKL runs on the GPU only (HIP kernels; there is no CPU fallback)")
-        key = (which, B, H, W, self.compute_dtype, weights_version(self))
+        # the encoder may run in its own dtype (throughput mode: bf16 encode of the masked target, fp32 decode of the result)
+        dt = (getattr(self, "encode_dtype", None) or self.compute_dtype) if which == "enc" else self.compute_dtype
+        key = (which, B, H, W, dt, weights_version(self))
         eng = self._engines.get(key)
         if eng is None:
             self._engines = {k: v for k, v in self._engines.items() if k[-1] == key[-1]}
-            eng = _VAEEngine(flat_state(self), self.cfg, B, H, W, self.compute_dtype, dev, which)
+            eng = _VAEEngine(flat_state(self), self.cfg, B, H, W, dt, dev, which)
             self._engines[key] = eng
         return eng
 

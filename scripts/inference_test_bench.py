@@ -8,7 +8,8 @@ Differences, all at the edges of the scope table:
   * ``--dataset synthetic`` (seeded items of the dataset tensor contract) is available because no dataset is
     reachable offline; CelebA / FFHQ / FF++ folder readers are the "next" row 8f.1;
   * ``--ckpt none`` runs on seeded random weights (no checkpoint is reachable offline);
-  * ``--precision bf16`` selects the bf16 MFMA UNet (``full`` = exact-fp32 MFMA; ``autocast`` maps to bf16);
+  * ``--precision bf16`` selects the throughput mode: bf16 MFMA UNet, CLIP / ArcFace towers and VAE encoder, fp32 VAE decode
+    (``full`` = exact-fp32 MFMA everywhere, the parity mode; ``autocast`` maps to bf16);
   * one process per GPU under torch.distributed.run shards the pairs ``rank::world`` (weights broadcast once).
 """
 import argparse

@@ -139,12 +139,13 @@ def test_cli_synthetic_run(tmp_path):
 
 
 def test_cli_plms_start_from_target(tmp_path):
-    """The 'next' rows 8f.4: --plms and --Start_from_target through the same CLI (3 items, 5 steps, seeded weights)."""
+    """The 'next' rows 8f.4: --plms and --Start_from_target through the same CLI, in throughput mode (--precision bf16: bf16 UNet,
+    CLIP / ArcFace towers and VAE encoder; fp32 VAE decode)."""
     import json
     out = tmp_path / "out"
     cmd = [sys.executable, os.path.join(ROOT, "scripts", "inference_test_bench.py"), "--outdir", str(out), "--config",
            os.path.join(ROOT, "tests", "configs", "reface_small.yaml"), "--ckpt", "none", "--dataset", "synthetic", "--n_items", "2",
-           "--n_samples", "2", "--ddim_steps", "5", "--scale", "3.5", "--H", "256", "--W", "256", "--plms", "--Start_from_target",
+           "--n_samples", "2", "--ddim_steps", "5", "--scale", "3.5", "--H", "256", "--W", "256", "--plms", "--Start_from_target", "--precision", "bf16",
            "--target_start_noise_t", "800", "--clip_vision_config", json.dumps(SMALL_CLIP)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
