@@ -871,8 +871,13 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
         const long long nt = n320 ? N / 320 : (n256 ? N / 256 : 0);
         if (nt > 0) {
             if (mt256 * nt >= 192) return n320 ? launch_cfg<T, TO, 4, 2, 2, 5>(d, p, conv, st) : launch_cfg<T, TO, 4, 2, 2, 4>(d, p, conv, st);
-            if (mt128 * nt * pick_splitk(d, p, mt128 * nt, bk) >= 192)
+            if (mt128 * nt * pick_splitk(d, p, mt128 * nt, bk) >= 192) {
+                // K up to ~90 tiles: two co-resident 4-wave 128x160 blocks per CU (each other's prologue / epilogue cover) beat one
+                // 8-wave 128x320 block in situ (sweep: -1.2 % per batch at 6000, worse again from 11520); RF_SHORTK overrides
+                static const int shortk = [] { const char* e = getenv("RF_SHORTK"); return e ? atoi(e) : 6000; }();
+                if (n320 && p.K <= shortk && mt128 * (N / 160) >= 256) return launch_cfg<T, TO, 4, 1, 1, 5>(d, p, conv, st);
                 return n320 ? launch_cfg<T, TO, 4, 2, 1, 5>(d, p, conv, st) : launch_cfg<T, TO, 4, 2, 1, 4>(d, p, conv, st);
+            }
         }
     }
     if (d->act == RF_ACT_GEGLU) return launch_cfg<T, TO, 2, 2, 2, 2>(d, p, conv, st);
