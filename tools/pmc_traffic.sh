@@ -4,7 +4,7 @@
 tag=$1
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  REFACE_NO_GRAPH=1 rocprofv3 --pmc $c --output-format csv -d gpurun_out/${tag}_pmc_$c -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > gpurun_out/${tag}_pmc_$c.log 2>&1
+  REFACE_NO_GRAPH=1 rocprofv3 --pmc $c --output-format csv -d gpurun_out/${tag}_pmc_$c -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-conditioning > gpurun_out/${tag}_pmc_$c.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, json, re
