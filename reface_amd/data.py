@@ -62,6 +62,7 @@ class CelebAdataset(Dataset):
     list ``preserve_mask_src`` for both)."""
     IMG_DIR, IMG_FMT = "CelebA-HQ-img", "{}.jpg"
     MASK_DIR, MASK_FMT = "CelebA-HQ-mask/Overall_mask", "{}.png"
+    REF_IMG_DIR = REF_MASK_DIR = None          # sources in other folders than the targets (FF++)
 
     def __init__(self, state="test", dataset_dir="dataset/FaceData/CelebAMask-HQ", gray_outer_mask=True, remove_mask_tar=None,
                  preserve_mask_src=None, preserve_mask=None, fraction=1.0, first_target=28000, n_targets=1000, first_source=29000,
@@ -80,8 +81,8 @@ class CelebAdataset(Dataset):
         ids_s = range(first_source, first_source + n_targets)
         self.imgs = sorted(j(dataset_dir, self.IMG_DIR, self.IMG_FMT.format(i)) for i in ids_t)
         self.labels = sorted(j(dataset_dir, self.MASK_DIR, self.MASK_FMT.format(i)) for i in ids_t)
-        self.ref_imgs = sorted(j(dataset_dir, self.IMG_DIR, self.IMG_FMT.format(i)) for i in ids_s)
-        self.ref_labels = sorted(j(dataset_dir, self.MASK_DIR, self.MASK_FMT.format(i)) for i in ids_s)
+        self.ref_imgs = sorted(j(dataset_dir, self.REF_IMG_DIR or self.IMG_DIR, self.IMG_FMT.format(i)) for i in ids_s)
+        self.ref_labels = sorted(j(dataset_dir, self.REF_MASK_DIR or self.MASK_DIR, self.MASK_FMT.format(i)) for i in ids_s)
         n = int(len(self.imgs) * fraction)
         self.imgs, self.labels, self.ref_imgs, self.ref_labels = self.imgs[:n], self.labels[:n], self.ref_imgs[:n], self.ref_labels[:n]
 
@@ -122,6 +123,17 @@ class FFHQdataset(CelebAdataset):
         kw.pop("preserve_mask_src", None)
         super().__init__(state=state, dataset_dir=dataset_dir, remove_mask_tar=remove_mask_tar_FFHQ, preserve_mask_src=preserve_mask_src_FFHQ,
                          first_target=first_target, first_source=first_source, **kw)
+
+
+class FFdataset(FFHQdataset):
+    """FaceForensics++ test split (test_bench_dataset.py:640-839): targets ``Val_target/%04d.png`` + ``target_mask`` (0-499),
+    sources ``Val/%04d.png`` + ``src_mask`` (500-999), the *_FFHQ label lists; same item contract."""
+    IMG_DIR, IMG_FMT = "Val_target", "{:04d}.png"
+    MASK_DIR, MASK_FMT = "target_mask", "{:04d}.png"
+    REF_IMG_DIR, REF_MASK_DIR = "Val", "src_mask"
+
+    def __init__(self, state="test", dataset_dir="dataset/FaceData/FF++", first_target=0, first_source=500, n_targets=500, **kw):
+        super().__init__(state=state, dataset_dir=dataset_dir, first_target=first_target, first_source=first_source, n_targets=n_targets, **kw)
 
 
 def shard_indices(n, rank, world):

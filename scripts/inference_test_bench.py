@@ -143,8 +143,8 @@ def main(argv=None):
         from reface_amd.data import SyntheticPairs, shard_indices
         full = SyntheticPairs(n=opt.n_items, image_size=opt.H, seed=opt.seed)
         test_dataset = torch.utils.data.Subset(full, shard_indices(len(full), rank, world))
-    elif opt.dataset in ("CelebA", "FFHQ"):          # inference_test_bench.py:374-381: data.params.test.params of the config
-        from reface_amd.data import CelebAdataset, FFHQdataset, shard_indices
+    elif opt.dataset in ("CelebA", "FFHQ", "FF++"):          # inference_test_bench.py:374-381: data.params.test.params of the config
+        from reface_amd.data import CelebAdataset, FFdataset, FFHQdataset, shard_indices
         test_args = {}
         try:
             test_args = dict(config.data.params.test.params)
@@ -153,11 +153,12 @@ def main(argv=None):
         if opt.dataset_dir is not None and "dataset_dir" not in test_args:
             test_args["dataset_dir"] = opt.dataset_dir
         test_args.setdefault("state", "test")
-        full = (CelebAdataset if opt.dataset == "CelebA" else FFHQdataset)(**test_args)
+        if opt.dataset == "FF++" and opt.dataset_dir is not None:       # inference_test_bench.py:383: the flag overrides the config
+            test_args["dataset_dir"] = opt.dataset_dir
+        full = {"CelebA": CelebAdataset, "FFHQ": FFHQdataset, "FF++": FFdataset}[opt.dataset](**test_args)
         test_dataset = torch.utils.data.Subset(full, shard_indices(len(full), rank, world))
     else:
-        raise NotImplementedError(f"--dataset {opt.dataset}: the FF++ folder reader (ldm/data/test_bench_dataset.py:700-839) "
-                                  "is part of the 'next' row 8f.1; CelebA, FFHQ and synthetic are available")
+        raise NotImplementedError(f"--dataset {opt.dataset}: CelebA, FFHQ, FF++ and synthetic are available")
     loader = torch.utils.data.DataLoader(test_dataset, batch_size=batch_size, num_workers=0, shuffle=False, drop_last=False)
 
     start_code = None

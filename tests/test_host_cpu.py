@@ -276,3 +276,23 @@ def test_ffhq_reader_layout(tmp_path):
     tar, _, kw, sid = ds[0]
     assert len(ds) == 1 and sid == "000000000000" and tar.shape == (3, 512, 512)
     assert kw["inpaint_mask"][0, 250, 250] == 0 and kw["inpaint_mask"][0, 10, 10] == 1 and kw["ref_imgs"].shape == (1, 3, 224, 224)
+
+
+def test_ffpp_reader_layout(tmp_path):
+    """FFdataset: Val_target / target_mask (0..) targets, Val / src_mask (500..) sources."""
+    from PIL import Image
+    from reface_amd.data import FFdataset
+    root = tmp_path / "FF"
+    for dname in ("Val_target", "target_mask", "Val", "src_mask"):
+        (root / dname).mkdir(parents=True)
+    rng = np.random.default_rng(2)
+    lab = np.zeros((512, 512), np.uint8)
+    lab[100:400, 100:400] = 1
+    Image.fromarray(rng.integers(0, 256, (512, 512, 3), dtype=np.uint8)).save(root / "Val_target" / "0000.png")
+    Image.fromarray(lab).save(root / "target_mask" / "0000.png")
+    Image.fromarray(rng.integers(0, 256, (300, 300, 3), dtype=np.uint8)).save(root / "Val" / "0500.png")
+    Image.fromarray(lab).save(root / "src_mask" / "0500.png")
+    ds = FFdataset(state="test", dataset_dir=str(root), gray_outer_mask=True, n_targets=1, remove_mask_tar_FFHQ=[1], preserve_mask_src_FFHQ=[1])
+    tar, _, kw, sid = ds[0]
+    assert len(ds) == 1 and sid == "000000000000" and tar.shape == (3, 512, 512) and kw["ref_imgs"].shape == (1, 3, 224, 224)
+    assert kw["inpaint_mask"][0, 250, 250] == 0 and kw["inpaint_mask"][0, 10, 10] == 1
