@@ -204,22 +204,29 @@ class LatentDiffusion(nn.Module, _DeviceMixin):
         return self.cond_stage_model.encode(c)
 
     @torch.no_grad()
+    def detect_landmarks(self, x):
+        """Host half of get_landmarks (ddpm.py:1068-1096): dlib HOG detector + 68-point predictor per image on the CPU -> [B, 136]
+        float tensor; zeros where no face is found or dlib is unavailable.  Touches no GPU state, so the CLI runs it for batch i+1
+        on a worker thread while the GPU samples batch i."""
+        lm = []
+        if self.detector is not None and x is not None:
+            img = (255.0 * ((x + 1.0) / 2.0).permute(0, 2, 3, 1).cpu().numpy()).astype(np.uint8)
+            for i in range(len(img)):
+                faces = self.detector(img[i], 1)
+                if len(faces) == 0:
+                    lm.append(np.zeros((1, 136), dtype=np.float32))
+                    continue
+                shape = self.predictor(img[i], faces[0])
+                lm.append(np.array([[p.x, p.y] for p in shape.parts()]).reshape(1, 136))
+        else:
+            lm = [np.zeros((1, 136), dtype=np.float32) for _ in range(x.shape[0])]
+        return torch.tensor(np.concatenate(lm, axis=0)).float()
+
     def get_landmarks(self, x, landmarks136=None):
-        """Host-side dlib landmarks -> landmark_proj_out.  ``landmarks136`` ([B,136]) bypasses dlib."""
+        """Host-side dlib landmarks -> landmark_proj_out.  ``landmarks136`` ([B,136], e.g. a prefetched detect_landmarks result)
+        bypasses the detection."""
         if landmarks136 is None:
-            lm = []
-            if self.detector is not None and x is not None:
-                img = (255.0 * ((x + 1.0) / 2.0).permute(0, 2, 3, 1).cpu().numpy()).astype(np.uint8)
-                for i in range(len(img)):
-                    faces = self.detector(img[i], 1)
-                    if len(faces) == 0:
-                        lm.append(np.zeros((1, 136), dtype=np.float32))
-                        continue
-                    shape = self.predictor(img[i], faces[0])
-                    lm.append(np.array([[p.x, p.y] for p in shape.parts()]).reshape(1, 136))
-            else:
-                lm = [np.zeros((1, 136), dtype=np.float32) for _ in range(x.shape[0])]
-            landmarks136 = torch.tensor(np.concatenate(lm, axis=0)).float()
+            landmarks136 = self.detect_landmarks(x)
         landmarks136 = landmarks136.to(self.device)
         if self.Landmark_loss_weight > 0 and not self.Landmark_cond:
             return landmarks136

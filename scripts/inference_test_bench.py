@@ -166,8 +166,36 @@ def main(argv=None):
         start_code = torch.randn([opt.n_samples, opt.C, opt.H // opt.f, opt.W // opt.f], device=device)
 
     n_done, t_start = 0, time.time()
+    def with_landmark_prefetch(batches):
+        """Yield (batch, landmarks136 or None): the dlib landmarks of batch i+1 are detected on a worker thread while the GPU works
+        on batch i -- the only serial CPU stage inside the reference's batch loop (ddpm.py:1068-1099)."""
+        if not model.Landmark_cond:
+            for bt in batches:
+                yield bt, None
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            it = iter(batches)
+            try:
+                cur = next(it)
+            except StopIteration:
+                return
+            fut = pool.submit(model.detect_landmarks, cur[0])
+            while True:
+                try:
+                    nxt = next(it)
+                except StopIteration:
+                    nxt = None
+                lm = fut.result()
+                if nxt is not None:
+                    fut = pool.submit(model.detect_landmarks, nxt[0])
+                yield cur, lm
+                if nxt is None:
+                    return
+                cur = nxt
+
     with torch.no_grad(), model.ema_scope():
-        for test_batch, prior, test_model_kwargs, segment_id_batch in loader:
+        for (test_batch, prior, test_model_kwargs, segment_id_batch), lm136 in with_landmark_prefetch(loader):
             if opt.Start_from_target:                   # inference_test_bench.py:414-435: noised target (or prior) latent as x_T
                 x0_img = prior                          # `use_prior = True` is hard-wired in the reference (:402, :424-429)
                 z0 = model.get_first_stage_encoding(model.encode_first_stage(x0_img.to(device).float()))
@@ -177,7 +205,7 @@ def main(argv=None):
             test_model_kwargs = {n: test_model_kwargs[n].to(device, non_blocking=True) for n in test_model_kwargs}
             B = test_batch.shape[0]
             uc = model.learnable_vector.repeat(B, 1, 1) if opt.scale != 1.0 else None
-            landmarks = model.get_landmarks(test_batch) if model.Landmark_cond else None
+            landmarks = model.get_landmarks(test_batch, landmarks136=lm136) if model.Landmark_cond else None
             c = model.conditioning_with_feat(test_model_kwargs["ref_imgs"].squeeze(1).to(torch.float32), landmarks=landmarks,
                                              tar=test_batch.to("cuda").to(torch.float32)).float()
             if len(c.shape) == 2:

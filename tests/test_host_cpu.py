@@ -296,3 +296,32 @@ def test_ffpp_reader_layout(tmp_path):
     tar, _, kw, sid = ds[0]
     assert len(ds) == 1 and sid == "000000000000" and tar.shape == (3, 512, 512) and kw["ref_imgs"].shape == (1, 3, 224, 224)
     assert kw["inpaint_mask"][0, 250, 250] == 0 and kw["inpaint_mask"][0, 10, 10] == 1
+
+
+def test_detect_landmarks_host_half():
+    """LatentDiffusion.detect_landmarks: the dlib half of get_landmarks (ddpm.py:1068-1096) with a stand-in detector / predictor --
+    68 (x, y) points flattened per image, zeros where no face is found, no GPU involved."""
+    import types
+    from reface_amd.ddpm import LatentDiffusion
+
+    class Pt:
+        def __init__(self, x, y):
+            self.x, self.y = x, y
+
+    calls = []
+
+    def detector(img, upsample):
+        calls.append((img.shape, img.dtype, upsample))
+        return [object()] if img.mean() > 100 else []
+
+    def predictor(img, face):
+        return types.SimpleNamespace(parts=lambda: [Pt(i, 2 * i) for i in range(68)])
+
+    host = types.SimpleNamespace(detector=detector, predictor=predictor)
+    x = torch.stack([torch.full((3, 32, 32), 0.9), torch.full((3, 32, 32), -0.9)])
+    lm = LatentDiffusion.detect_landmarks(host, x)
+    assert lm.shape == (2, 136) and lm.dtype == torch.float32
+    assert lm[0, :4].tolist() == [0.0, 0.0, 1.0, 2.0] and lm[0, -2:].tolist() == [67.0, 134.0] and float(lm[1].abs().sum()) == 0.0
+    assert calls[0] == ((32, 32, 3), np.uint8, 1)
+    host.detector = None
+    assert float(LatentDiffusion.detect_landmarks(host, x).abs().sum()) == 0.0
