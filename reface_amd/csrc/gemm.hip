@@ -266,6 +266,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             const int n = n0 + r0 + j * RPP;
             offs[AV + j] = n < p.N ? n * p.ldw * (int)sizeof(T) + lane_k : OOB;
         }
+        // the W pieces of the first tile go out before the A row descriptors (two integer divisions per row) are computed
+        if (nk > 0) {
+#pragma unroll
+            for (int j = 0; j < BV; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(ldsB + wave_u * 1024 + j * (RPP * 128)), 16,
+                                                         offs[AV + j], kb0_tiles * 128, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
             const int m = m0 + r0 + i * RPP;
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         using std::integral_constant;
         if (nk > 0) {
             // prologue: tile 0 lands, its first fragments are fetched, the issue state points at tile 1
-            issue_pieces(0, 0, NP);
+            issue_pieces(0, 0, AV);               // (its W pieces are already in flight)
             if (nk > 1) {
                 next_tile();
                 issue_pieces(1, 0, NP);
