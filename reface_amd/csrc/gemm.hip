@@ -601,13 +601,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                             v[0] += rq[u][0]; v[1] += rq[u][1]; v[2] += rq[u][2]; v[3] += rq[u][3];
                         }
                     }
+                    if constexpr (sizeof(TO) == 2) {
+                        u32x2_t w; w[0] = pack_bf2(v[0], v[1]); w[1] = pack_bf2(v[2], v[3]);
+                        *(u32x2_t*)dst = w;
+                        if (gn_on) {      // statistics of the values AS STORED (what the apply pass and the unfused statistics pass read)
+                            v[0] = as_f32(w[0] << 16); v[1] = as_f32(w[0] & 0xffff0000u); v[2] = as_f32(w[1] << 16); v[3] = as_f32(w[1] & 0xffff0000u);
+                        }
+                    }
                     if (gn_on) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { gsum[e] += v[e]; gsq[e] += v[e] * v[e]; }
                     }
                     if constexpr (sizeof(TO) == 2) {
-                        u32x2_t w; w[0] = pack_bf2(v[0], v[1]); w[1] = pack_bf2(v[2], v[3]);
-                        *(u32x2_t*)dst = w;
                     } else {
                         *(f32x4_t*)dst = f32x4_t{v[0], v[1], v[2], v[3]};
                     }
@@ -617,8 +622,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                         if (col + e < p.N) {
                             float y = v[e];
                             if (resp) y += load_out<TO>(resp + (long long)row * p.ldr + col + e);
-                            if (gn_on) { gsum[e] += y; gsq[e] += y * y; }
                             store_out<TO>(dst + e, y);
+                            if (gn_on) {
+                                float ys = y;
+                                if constexpr (sizeof(TO) == 2) ys = bf2f(f2bf(y));
+                                gsum[e] += ys; gsq[e] += ys * ys;
+                            }
                         }
                 }
             }
@@ -747,7 +756,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
                     else if (p.act == RF_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
                     else if (p.act == RF_ACT_PRELU) y = y >= 0.0f ? y : y * p.act_vec[c];
                     if (resp) y += full ? r4[e] : load_out<TO>(resp + (long long)row * p.ldr + c);
-                    if (gn_on) { gsum[e] += y; gsq[e] += y * y; }
+                    if (gn_on) {          // statistics of the value as stored
+                        float ys = y;
+                        if constexpr (sizeof(TO) == 2) ys = bf2f(f2bf(y));
+                        gsum[e] += ys; gsq[e] += ys * ys;
+                    }
                     y4[e] = y;
                     if (!full) store_out<TO>(outp + (long long)row * p.ldo + c, y);
                 }

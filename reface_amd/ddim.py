@@ -5,10 +5,11 @@ shape=..., conditioning=..., unconditional_guidance_scale=..., unconditional_con
 eta=..., x_T=..., test_model_kwargs={'inpaint_image', 'inpaint_mask'}) -> (samples, intermediates)``.
 
 MI355X design: the step body [pack 9-channel input (x2 for CFG) -> UNet -> CFG + DDIM update] is a
-fixed launch list captured once into a HIP graph and replayed S times.  Everything that depends on
-the step index lives in two small device buffers refreshed before each replay: the per-timestep
-ResBlock embedding vectors (precomputed for all S timesteps by one GEMM chain) and five fp32
-update coefficients.  Cross-attention reduces to a per-sample vector computed once per call.
+fixed launch list; the whole S-step loop is unrolled into ONE HIP graph (REFACE_GRAPH_STEPS caps the steps
+per graph; 1 = one replay per step).  Everything that depends on the step index lives in two small device tables the
+unrolled steps index by position: the per-timestep ResBlock embedding vectors (precomputed for all S
+timesteps by one GEMM chain) and five fp32 update coefficients per step -- so a sample() call is
+three small copies and one graph replay.  Cross-attention reduces to a per-sample vector computed once per call.
 """
 import numpy as np
 import os
@@ -78,7 +79,7 @@ class DDIMSampler(object):
 
     # ------------------------------------------------------------------------------------------
     def _plan(self, B, H, W, cfg_on, scale, with_noise):
-        """Build (once per shape) the engine, the S-independent step launch list and its graph."""
+        """Build (once per shape) the engine and the S-independent step launch list."""
         unet = self.model.model.diffusion_model
         key = (B, H, W, cfg_on, float(scale), with_noise, unet.compute_dtype, id(unet))
         plan = self._plans.get(key)
@@ -96,9 +97,55 @@ class DDIMSampler(object):
         step = [ops.ddim_pack_input(img, z, m, eng.x_in, dup=2 if cfg_on else 1)]
         step += eng.main
         step.append(ops.ddim_update(eng.eps, img, px0, noise, coef, cfg=cfg_on, scale=scale))
-        plan = dict(eng=eng, img=img, z=z, m=m, px0=px0, noise=noise, coef=coef, step=step, graph=None)
+        plan = dict(eng=eng, img=img, z=z, m=m, px0=px0, noise=noise, coef=coef, step=step, graphs={}, cfg_on=cfg_on, scale=scale,
+                    x_start=torch.empty_like(img), warm=False)
         self._plans = {key: plan}
         return plan
+
+    @staticmethod
+    def _chunk(S, flagged, want):
+        """DDIM steps per captured graph: the largest divisor of S that is <= `want` -- provided every step whose state the
+        caller wants back (intermediates) is either inside a single whole-loop graph or at a chunk end; else 1."""
+        c = max(d for d in range(1, S + 1) if S % d == 0 and d <= max(1, want))
+        if c == S or all((i + 1) % c == 0 for i in flagged):
+            return c
+        return 1
+
+    def _capture(self, plan, c, flagged_local):
+        """One HIP graph of `c` unrolled DDIM steps.  Step j of the chunk reads row j of the chunk's timestep-embedding table
+        and coefficient block (and its own noise slab when eta > 0): the per-step pointers are patched into the prepared
+        descriptors while the launches are recorded (kernel parameters are copied at capture time)."""
+        eng, dev = plan["eng"], self.model.device
+        B, _, H, W = plan["img"].shape
+        E = eng.E
+        g = dict(tab=torch.zeros((c, E), dtype=F32, device=dev), coef=torch.zeros((c, 8), dtype=F32, device=dev),
+                 noise=(torch.zeros((c,) + tuple(plan["img"].shape), dtype=F32, device=dev) if plan["noise"] is not None else None),
+                 inter_x=[torch.empty_like(plan["img"]) for _ in flagged_local], inter_p=[torch.empty_like(plan["img"]) for _ in flagged_local])
+        lo = eng.emb_table.data_ptr()
+        hi = lo + eng.emb_table.numel() * 4
+        patch = [(l.keep[0], l.keep[0].rowvec) for l in eng.main
+                 if l.fn.__name__ == "rf_conv_gemm" and l.keep[0].rowvec and lo <= l.keep[0].rowvec < hi]
+        updates = [ops.ddim_update(eng.eps, plan["img"], plan["px0"], None if g["noise"] is None else g["noise"][j], g["coef"][j],
+                                   cfg=plan["cfg_on"], scale=plan["scale"]) for j in range(c)]
+        pack = plan["step"][0]
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph):
+                for j in range(c):
+                    for d, orig in patch:
+                        d.rowvec = g["tab"].data_ptr() + j * E * 4 + (orig - lo)
+                    pack()
+                    ops.run(eng.main)
+                    updates[j]()
+                    if j in flagged_local:
+                        k = flagged_local.index(j)
+                        g["inter_x"][k].copy_(plan["img"])
+                        g["inter_p"][k].copy_(plan["px0"])
+        finally:
+            for d, orig in patch:
+                d.rowvec = orig
+        g["graph"], g["keep"] = graph, updates
+        return g
 
     @torch.no_grad()
     def ddim_sampling(self, cond, shape, x_T=None, callback=None, img_callback=None, log_every_t=100,
@@ -116,14 +163,16 @@ class DDIMSampler(object):
             raise Exception("kwargs must contain either 'test_model_kwargs' or 'rest' key")
         cfg_on = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.)
         timesteps = self.ddim_timesteps
-        total_steps = timesteps.shape[0]
+        S = total_steps = timesteps.shape[0]
         time_range = np.flip(timesteps)
         sig_host = np.asarray(self.ddim_sigmas, dtype=np.float64)
         with_noise = bool((sig_host != 0).any())
 
         plan = self._plan(B, H, W, cfg_on, unconditional_guidance_scale, with_noise)
-        eng, img = plan["eng"], plan["img"]
-        img.copy_(torch.randn(shape, device=dev) if x_T is None else x_T.to(device=dev, dtype=F32))
+        eng, img, x_start = plan["eng"], plan["img"], plan["x_start"]
+        # the start noise is drawn ONCE (ddim.py:213: one torch.randn per call), whatever the graph mode does afterwards
+        x_start.copy_(torch.randn(shape, device=dev) if x_T is None else x_T.to(device=dev, dtype=F32))
+        img.copy_(x_start)
         plan["z"].copy_(z_inpaint.to(device=dev, dtype=F32))
         plan["m"].copy_(mask.to(device=dev, dtype=F32))
         c = cond.to(device=dev, dtype=F32)
@@ -131,42 +180,74 @@ class DDIMSampler(object):
 
         # all S timestep-embedding rows in one shot (timesteps are data-independent)
         t_all = torch.tensor(np.ascontiguousarray(time_range), dtype=F32, device=dev)
-        table = torch.empty((total_steps, eng.E), dtype=F32, device=dev)
+        table = torch.empty((S, eng.E), dtype=F32, device=dev)
         ops.run(eng.make_emb_launches(t_all, table))
         coefs = torch.flip(self.ddim_coefs, dims=[0]).contiguous().to(dev)      # row i <-> index S-1-i
-        coefs = torch.cat([coefs, torch.zeros((total_steps, 3), dtype=F32, device=dev)], dim=1).contiguous()
+        coefs = torch.cat([coefs, torch.zeros((S, 3), dtype=F32, device=dev)], dim=1).contiguous()
+        if with_noise:
+            noise_all = x_noise.to(device=dev, dtype=F32) if x_noise is not None else torch.randn((S,) + tuple(shape), device=dev)
 
-        if self.use_graph and plan["graph"] is None:
-            stream = torch.cuda.Stream()
-            stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(stream):
-                ops.run(plan["step"])            # warm-up outside capture (module load, attribute calls)
-                img.copy_(torch.randn(shape, device=dev) if x_T is None else x_T.to(device=dev, dtype=F32))
-            torch.cuda.current_stream().wait_stream(stream)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                ops.run(plan["step"])
-            plan["graph"] = g
-            img.copy_(torch.randn(shape, device=dev) if x_T is None else x_T.to(device=dev, dtype=F32))
+        flagged = [i for i in range(S) if (S - i - 1) % log_every_t == 0 or i == 0]       # ddim.py:247 (index == total_steps - 1 <=> i == 0)
+        per_step_host = bool(callback or img_callback)
+        c_steps = 1
+        if self.use_graph and not per_step_host:
+            c_steps = self._chunk(S, flagged, int(os.environ.get("REFACE_GRAPH_STEPS", "1000")))
+        g = None
+        if self.use_graph:
+            if not plan["warm"]:
+                # one eager step outside capture (module load, function attributes), on real coefficients; state restored after
+                eng.emb_table.copy_(table[0:1])
+                plan["coef"].copy_(coefs[0])
+                stream = torch.cuda.Stream()
+                stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(stream):
+                    ops.run(plan["step"])
+                torch.cuda.current_stream().wait_stream(stream)
+                img.copy_(x_start)
+                plan["warm"] = True
+            fl_local = [i for i in flagged if i < c_steps] if c_steps == S else []
+            gkey = (c_steps, tuple(fl_local))
+            g = plan["graphs"].get(gkey)
+            if g is None:
+                g = self._capture(plan, c_steps, fl_local)
+                plan["graphs"] = {gkey: g}
+                img.copy_(x_start)
 
         intermediates = {"x_inter": [img.clone()], "pred_x0": [img.clone()]}
         if verbose:
             print(f"Running DDIM Sampling with {total_steps} timesteps")
-        for i in range(total_steps):
-            index = total_steps - i - 1
-            eng.emb_table.copy_(table[i:i + 1])
-            plan["coef"].copy_(coefs[i])
-            if with_noise:
-                plan["noise"].copy_(x_noise[i].to(dev) if x_noise is not None else torch.randn(shape, device=dev))
-            if plan["graph"] is not None:
-                plan["graph"].replay()
-            else:
+        if g is not None:
+            for r in range(S // c_steps):
+                i0, i1 = r * c_steps, (r + 1) * c_steps
+                g["tab"].copy_(table[i0:i1])
+                g["coef"].copy_(coefs[i0:i1])
+                if with_noise:
+                    g["noise"].copy_(noise_all[i0:i1])
+                g["graph"].replay()
+                for i in range(i0, i1):
+                    if callback:
+                        callback(i)
+                    if img_callback:
+                        img_callback(plan["px0"], i)
+                if c_steps == S:
+                    for k in range(len(g["inter_x"])):
+                        intermediates["x_inter"].append(g["inter_x"][k].clone())
+                        intermediates["pred_x0"].append(g["inter_p"][k].clone())
+                elif (i1 - 1) in flagged:
+                    intermediates["x_inter"].append(img.clone())
+                    intermediates["pred_x0"].append(plan["px0"].clone())
+        else:
+            for i in range(S):
+                eng.emb_table.copy_(table[i:i + 1])
+                plan["coef"].copy_(coefs[i])
+                if with_noise:
+                    plan["noise"].copy_(noise_all[i])
                 ops.run(plan["step"])
-            if callback:
-                callback(i)
-            if img_callback:
-                img_callback(plan["px0"], i)
-            if index % log_every_t == 0 or index == total_steps - 1:
-                intermediates["x_inter"].append(img.clone())
-                intermediates["pred_x0"].append(plan["px0"].clone())
+                if callback:
+                    callback(i)
+                if img_callback:
+                    img_callback(plan["px0"], i)
+                if i in flagged:
+                    intermediates["x_inter"].append(img.clone())
+                    intermediates["pred_x0"].append(plan["px0"].clone())
         return img.clone(), intermediates

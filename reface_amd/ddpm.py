@@ -15,6 +15,8 @@ All tensor arithmetic runs in the HIP engines of reface_amd.unet / vae / encoder
 from contextlib import contextmanager
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -146,6 +148,12 @@ class LatentDiffusion(nn.Module, _DeviceMixin):
             from .encoders import IDLoss
             self.ID_proj_out = Linear(512, 768)
             self.face_ID_model = IDLoss(multiscale=False)
+            # ddpm.py:101 of the reference: the ArcFace weights come from other_params.arcface_path BEFORE any checkpoint is applied
+            self.arcface_path = cfg_get(op, "arcface_path", None) if op is not None else None
+            self._arcface_loaded = False
+            if self.arcface_path and os.path.exists(str(self.arcface_path)):
+                self.face_ID_model.facenet.load_state_dict(torch.load(str(self.arcface_path), map_location="cpu"), strict=True)
+                self._arcface_loaded = True
         self.detector = self.predictor = None
         if self.Landmark_cond or self.Landmark_loss_weight > 0:
             try:                                     # dlib is host-side and optional (ddpm.py:706-708)
@@ -179,8 +187,27 @@ class LatentDiffusion(nn.Module, _DeviceMixin):
         if ckpt_path is not None:
             sd = torch.load(ckpt_path, map_location="cpu")
             sd = sd.get("state_dict", sd)
-            self.load_state_dict({k: v for k, v in sd.items() if not any(k.startswith(i) for i in ignore_keys)}, strict=False)
+            missing, _ = self.load_state_dict({k: v for k, v in sd.items() if not any(k.startswith(i) for i in ignore_keys)}, strict=False)
+            self.check_engine_weights(missing)
             self.restarted_from_ckpt = True
+
+    def check_engine_weights(self, missing):
+        """``strict=False`` tolerates a pruned checkpoint in the reference because its CLIP comes from ``CLIPModel.from_pretrained``
+        and its ArcFace from ``other_params.arcface_path`` before the checkpoint is applied (ddpm.py:101, modules.py:230).  Here
+        every parameter is zero until loaded, so a tensor the HIP engines read but the checkpoint lacks would silently stay zero:
+        that is an error.  Keys the inference path never reads (text tower, training-only heads) may be absent."""
+        from . import params as P
+        need = set()
+        need.update("model.diffusion_model." + k for k in P.unet_param_specs(self.model.diffusion_model.cfg))
+        need.update("first_stage_model." + k for k in P.vae_param_specs(self.first_stage_model.cfg))
+        need.update("cond_stage_model." + k for k in P.clip_param_specs(self.cond_stage_model.cfg))
+        if hasattr(self, "face_ID_model") and not getattr(self, "_arcface_loaded", False):
+            need.update("face_ID_model.facenet." + k for k in P.arcface_param_specs())
+        need.update(k for k in P.cond_head_specs() if k in dict(self.named_parameters()))
+        lost = sorted(need.intersection(missing))
+        if lost:
+            raise RuntimeError(f"checkpoint lacks {len(lost)} tensors the inference engines read (they would stay zero): "
+                               + ", ".join(lost[:6]) + (" ..." if len(lost) > 6 else ""))
 
     # ------------------------------------------------------------------ plumbing
     @contextmanager

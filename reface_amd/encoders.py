@@ -46,7 +46,9 @@ class _ArcFaceEngine:
         self.pool = _Pool(device)
         self.sd = {k: v.detach().to(device=device, dtype=F32) for k, v in sd.items() if v.dtype.is_floating_point}
         self.launches = []
-        self._build()
+        self.ws = ops.new_workspace(device)
+        with ops.workspace_scope(self.ws):
+            self._build()
         self.sd = None
 
     def _conv(self, x, wkey, cout, *, stride=1, ksize=3, bn=None, prelu=None, cin_pad=None):
@@ -188,7 +190,9 @@ class _CLIPEngine:
         self.cfg, self.B, self.dt, self.dev = cfg, B, dtype, device
         self.sd = {k: v.detach().to(device=device, dtype=F32) for k, v in sd.items()}
         self.launches = []
-        self._build()
+        self.ws = ops.new_workspace(device)
+        with ops.workspace_scope(self.ws):
+            self._build()
         self.sd = None
 
     def w(self, k):

@@ -97,13 +97,36 @@ class Launch:
 
 _WORKSPACES = {}
 SPLITK_WORKSPACE_BYTES = 96 << 20
+_SCOPE = []          # innermost engine workspace (workspace_scope)
+
+
+class workspace_scope:
+    """Launches prepared inside the scope use `ws` as their split-K scratch.  Each engine (UNet, VAE encoder / decoder, CLIP,
+    ArcFace) owns one: launch lists of different engines may then run concurrently on different streams without sharing
+    partial-sum memory; inside one engine the launches are serialised on a stream."""
+
+    def __init__(self, ws):
+        self.ws = ws
+
+    def __enter__(self):
+        _SCOPE.append(self.ws)
+        return self.ws
+
+    def __exit__(self, *a):
+        _SCOPE.pop()
+
+
+def new_workspace(device, nbytes=SPLITK_WORKSPACE_BYTES):
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
 
 
 def _default_workspace(device):
-    """One fp32 split-K scratch buffer per device, shared by every launch (launches on a stream are serialised)."""
+    """Split-K scratch of launches prepared outside any engine: one fp32 buffer per device -- single-stream use only."""
+    if _SCOPE:
+        return _SCOPE[-1]
     ws = _WORKSPACES.get(device)
     if ws is None:
-        ws = torch.empty(SPLITK_WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+        ws = new_workspace(device)
         _WORKSPACES[device] = ws
     return ws
 

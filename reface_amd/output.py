@@ -1,0 +1,124 @@
+"""On-disk outputs of the test-bench CLI, byte-compatible with scripts/inference_test_bench.py:500-553 of the reference.
+
+Per image id the reference writes
+  results/<id>.png           255 * clamp((x_dec + 1) / 2, 0, 1), truncated to uint8                      (:493-495, :536-538)
+  grid/grid-<id>.png         torchvision.utils.make_grid([GT, inpaint, ref, result]) (nrow 8, padding 2, pad value 0)   (:518-531)
+  samples/<id>_mask.png      255 * (mask + 1) / 2 of the FULL-resolution {0, 1} keep-mask, grey -> RGB (0 -> 127)        (:540-543)
+  samples/<id>_GT.png        255 * (target + 1) / 2                                                      (:544-546)
+  samples/<id>_inpaint.png   255 * (masked target + 1) / 2                                               (:547-549)
+  samples/<id>_ref.png       CLIP-un-normalised reference, bilinearly resized 224 -> 512 (no clamp)      (:523-525, :550-552)
+All float -> uint8 conversions are numpy ``astype(np.uint8)`` of float32 arrays, exactly as the reference does them (truncation;
+out-of-range values of the un-clamped panels wrap the same way on the same platform).
+
+Host-side code (PIL PNG encoding).  ``OutputWriter`` runs the encodes on a worker thread so the GPU launch thread never waits
+for zlib (the reference encodes inline, inference_test_bench.py:531-552).
+"""
+import os
+import queue
+import threading
+
+import numpy as np
+
+CLIP_STD = np.array([0.26862954, 0.26130258, 0.27577711], dtype=np.float32).reshape(3, 1, 1)
+CLIP_MEAN = np.array([0.48145466, 0.4578275, 0.40821073], dtype=np.float32).reshape(3, 1, 1)
+
+
+def un_norm(x):
+    """inference_test_bench.py:500-501 (float32 arithmetic, as torch does it)."""
+    return (np.asarray(x, dtype=np.float32) + np.float32(1.0)) / np.float32(2.0)
+
+
+def un_norm_clip(x):
+    """inference_test_bench.py:502-514: x * std + mean per channel, [3, H, W] float32."""
+    return np.asarray(x, dtype=np.float32) * CLIP_STD + CLIP_MEAN
+
+
+def make_grid(panels, nrow=8, padding=2, pad_value=0.0):
+    """torchvision.utils.make_grid for a list of [3, H, W] float32 panels (normalize=False): panels left to right, `nrow` per
+    row, `padding` pixels of `pad_value` between panels and around the border -> [3, ymaps*(H+p)+p, xmaps*(W+p)+p]."""
+    n = len(panels)
+    _, H, W = panels[0].shape
+    xmaps = min(nrow, n)
+    ymaps = (n + xmaps - 1) // xmaps
+    hh, ww = H + padding, W + padding
+    grid = np.full((3, hh * ymaps + padding, ww * xmaps + padding), pad_value, dtype=np.float32)
+    k = 0
+    for y in range(ymaps):
+        for x in range(xmaps):
+            if k >= n:
+                break
+            grid[:, y * hh + padding:y * hh + padding + H, x * ww + padding:x * ww + padding + W] = panels[k]
+            k += 1
+    return grid
+
+
+def to_u8_hwc(chw):
+    """255. * rearrange(x, 'c h w -> h w c') -> astype(uint8): the reference's conversion (truncation)."""
+    return (np.float32(255.0) * np.transpose(np.asarray(chw, dtype=np.float32), (1, 2, 0))).astype(np.uint8)
+
+
+def compose(result01, target, inpaint_image, inpaint_mask, ref512, skip_grid=False):
+    """uint8 HWC arrays of one image's output files.
+
+    result01 [3,H,W] in [0,1]; target / inpaint_image [3,H,W] in [-1,1]; inpaint_mask [1,H,W] in {0,1} (full resolution);
+    ref512 [3,H,W]: the CLIP-normalised reference already resized to the image size."""
+    gt, inp, ref = un_norm(target), un_norm(inpaint_image), un_norm_clip(ref512)
+    out = {
+        "result": to_u8_hwc(result01),
+        "mask": np.repeat(to_u8_hwc(un_norm(inpaint_mask)), 3, axis=2),      # cv2.COLOR_GRAY2RGB replicates the channel
+        "GT": to_u8_hwc(gt),
+        "inpaint": to_u8_hwc(inp),
+        "ref": to_u8_hwc(ref),
+    }
+    if not skip_grid:
+        # the reference builds (and saves) the grid for every image even under --skip_grid (:518-531); the flag is honoured here
+        out["grid"] = to_u8_hwc(make_grid([gt, inp, ref, np.asarray(result01, dtype=np.float32)]))
+    return out
+
+
+def paths(outdir, sid):
+    s, r, g = (os.path.join(outdir, d) for d in ("samples", "results", "grid"))
+    return {"result": os.path.join(r, sid + ".png"), "grid": os.path.join(g, "grid-" + sid + ".png"),
+            "mask": os.path.join(s, sid + "_mask.png"), "GT": os.path.join(s, sid + "_GT.png"),
+            "inpaint": os.path.join(s, sid + "_inpaint.png"), "ref": os.path.join(s, sid + "_ref.png")}
+
+
+class OutputWriter:
+    """PNG encoding off the launch thread: ``submit`` takes host arrays of one batch and returns at once; ``close`` drains."""
+
+    def __init__(self, outdir, skip_grid=False, depth=4):
+        self.outdir, self.skip_grid = outdir, skip_grid
+        self.q = queue.Queue(maxsize=depth)
+        self.err = None
+        self.n = 0
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def _run(self):
+        from PIL import Image
+        while True:
+            job = self.q.get()
+            if job is None:
+                return
+            try:
+                ids, res, tgt, inp, msk, ref = job
+                for i, sid in enumerate(ids):
+                    arrs = compose(res[i], tgt[i], inp[i], msk[i], ref[i], skip_grid=self.skip_grid)
+                    p = paths(self.outdir, sid)
+                    for k, a in arrs.items():
+                        Image.fromarray(a).save(p[k])
+                    self.n += 1
+            except Exception as e:          # surfaced on the next submit / close
+                self.err = e
+
+    def submit(self, ids, result01, target, inpaint_image, inpaint_mask, ref512):
+        if self.err is not None:
+            raise self.err
+        self.q.put((list(ids), result01, target, inpaint_image, inpaint_mask, ref512))
+
+    def close(self):
+        self.q.put(None)
+        self.t.join()
+        if self.err is not None:
+            raise self.err
+        return self.n

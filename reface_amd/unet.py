@@ -89,10 +89,12 @@ class UNetEngine:
         self.x_in = torch.zeros((B, H, W, self.CPAD), dtype=dtype, device=device)
         self.eps = torch.empty((B, H, W, 4), dtype=F32, device=device)
         self.gn_partial = torch.empty(B * ops.GN_MAX_CHUNKS * 64, dtype=torch.float64, device=device)
-        self._build_emb(emb_rows if emb_rows is not None else (1 if uniform_t else B))
-        self._build_ctx()
-        self.main = []
-        self._build_main()
+        self.ws = ops.new_workspace(device)          # this engine's own split-K scratch (ops.workspace_scope)
+        with ops.workspace_scope(self.ws):
+            self._build_emb(emb_rows if emb_rows is not None else (1 if uniform_t else B))
+            self._build_ctx()
+            self.main = []
+            self._build_main()
         self.sd = None      # packed copies are held by the launches
 
     # ------------------------------------------------------------------ weights
@@ -143,11 +145,12 @@ class UNetEngine:
         h = torch.empty((n, td), dtype=F32, device=dev)
         emb = torch.empty((n, td), dtype=F32, device=dev)
         semb = torch.empty((n, td), dtype=F32, device=dev)
-        return [ops.timestep_embedding(t_f32, self.freqs, temb),
-                ops.linear(temb, w0, h, b0, act=ops.ACT_SILU, name="time_embed.0"),
-                ops.linear(h, w2, emb, b2, name="time_embed.2"),
-                ops.silu_f32(emb, semb),
-                ops.linear(semb, wcat, table, bcat, name="emb_layers")]
+        with ops.workspace_scope(self.ws):
+            return [ops.timestep_embedding(t_f32, self.freqs, temb),
+                    ops.linear(temb, w0, h, b0, act=ops.ACT_SILU, name="time_embed.0"),
+                    ops.linear(h, w2, emb, b2, name="time_embed.2"),
+                    ops.silu_f32(emb, semb),
+                    ops.linear(semb, wcat, table, bcat, name="emb_layers")]
 
     def emb_vec(self, p):
         off, cout = self.emb_off[p]

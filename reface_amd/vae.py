@@ -69,7 +69,9 @@ class _VAEEngine:
         self.sd = {k: v.detach().to(device=device, dtype=F32) for k, v in sd.items()}
         self.gn_partial = torch.empty(B * ops.GN_MAX_CHUNKS * 64, dtype=torch.float64, device=device)
         self.launches = []
-        (self._build_decoder if which == "dec" else self._build_encoder)(H, W)
+        self.ws = ops.new_workspace(device)          # own split-K scratch: the decode may run on another stream than the sampler
+        with ops.workspace_scope(self.ws):
+            (self._build_decoder if which == "dec" else self._build_encoder)(H, W)
         self.sd = None
 
     def w(self, key):
@@ -268,7 +270,10 @@ class AutoencoderKL(nn.Module):
         self._engines = {}
         if ckpt_path is not None:
             sd = torch.load(ckpt_path, map_location="cpu")["state_dict"]
-            self.load_state_dict({k: v for k, v in sd.items() if not any(k.startswith(i) for i in ignore_keys)}, strict=False)
+            missing, _ = self.load_state_dict({k: v for k, v in sd.items() if not any(k.startswith(i) for i in ignore_keys)}, strict=False)
+            lost = sorted(set(vae_param_specs(self.cfg)).intersection(missing))
+            if lost:            # parameters are zero until loaded: a tensor the engine reads must come from the checkpoint
+                raise RuntimeError(f"VAE checkpoint {ckpt_path} lacks {len(lost)} tensors the engine reads: {', '.join(lost[:6])}")
 
     def _engine(self, which, B, H, W):
         dev = next(self.parameters()).device

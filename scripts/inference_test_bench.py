@@ -2,7 +2,8 @@
 """Test-bench CLI of REFace on the MI355X-native engines.
 
 Same flags, loop and on-disk outputs as the reference's scripts/inference_test_bench.py:145-566:
-  <outdir>/results/<id>.png, <outdir>/grid/grid-<id>.png, <outdir>/samples/<id>_{mask,GT,inpaint,ref}.png
+  <outdir>/results/<id>.png, <outdir>/grid/grid-<id>.png (4-panel make_grid: GT, inpaint, ref, result),
+  <outdir>/samples/<id>_{mask,GT,inpaint,ref}.png  -- composed by reface_amd/output.py, byte-compatible with :500-553
 Differences, all at the edges of the scope table:
   * no module-import network access (the reference loads an HF safety checker it never calls);
   * ``--dataset synthetic`` (seeded items of the dataset tensor contract) is available because no dataset is
@@ -64,6 +65,7 @@ def build_parser():
     # additions (not in the reference)
     p.add_argument("--n_items", type=int, default=8, help="number of synthetic pairs (--dataset synthetic)")
     p.add_argument("--clip_vision_config", type=str, default=None, help="JSON dict overriding the CLIP ViT dims (tests)")
+    p.add_argument("--num_workers", type=int, default=4, help="DataLoader workers of the folder readers (reference: 4)")
     return p
 
 
@@ -78,6 +80,7 @@ def load_model_from_config(config, ckpt, verbose=False):
         m, u = model.load_state_dict(pl_sd["state_dict"], strict=False)
         if verbose:
             print("missing keys:", m, "\nunexpected keys:", u)
+        model.check_engine_weights(m)            # a tensor the engines read but the checkpoint lacks is an error, not zeros
     else:
         from reface_amd import params as P
         sd = {}
@@ -93,12 +96,6 @@ def load_model_from_config(config, ckpt, verbose=False):
     model.cuda()
     model.eval()
     return model
-
-
-def save_png(arr_chw01, path):
-    from PIL import Image
-    img = (255.0 * arr_chw01.transpose(1, 2, 0)).astype(np.uint8)          # truncation, as inference_test_bench.py:536-537
-    Image.fromarray(img).save(path)
 
 
 def main(argv=None):
@@ -124,9 +121,9 @@ def main(argv=None):
         model.set_compute_dtype(torch.bfloat16, encoders=True)
     if world > 1:
         import torch.distributed as dist
+        from reface_amd.multigpu import broadcast_module
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
-        for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, 0)
+        broadcast_module(model, 0)                  # a few flat RCCL broadcasts (one buffer per dtype), not one per tensor
     if opt.plms:                                    # inference_test_bench.py:337-339
         from ldm.models.diffusion.plms import PLMSSampler
         sampler = PLMSSampler(model)
@@ -159,13 +156,21 @@ def main(argv=None):
         test_dataset = torch.utils.data.Subset(full, shard_indices(len(full), rank, world))
     else:
         raise NotImplementedError(f"--dataset {opt.dataset}: CelebA, FFHQ, FF++ and synthetic are available")
-    loader = torch.utils.data.DataLoader(test_dataset, batch_size=batch_size, num_workers=0, shuffle=False, drop_last=False)
+    # inference_test_bench.py:386-391: 4 worker processes, pinned host memory (the PIL decode / resize of batch i+1 overlaps batch i)
+    nw = 0 if opt.dataset == "synthetic" else opt.num_workers
+    loader = torch.utils.data.DataLoader(test_dataset, batch_size=batch_size, num_workers=nw, pin_memory=True, shuffle=False,
+                                         drop_last=False, persistent_workers=False)
 
     start_code = None
     if opt.fixed_code:
         start_code = torch.randn([opt.n_samples, opt.C, opt.H // opt.f, opt.W // opt.f], device=device)
 
-    n_done, t_start = 0, time.time()
+    n_done, n_batches, t_start = 0, 0, time.time()
+    host = [None, None]
+    writer = None
+    if not opt.skip_save:
+        from reface_amd.output import OutputWriter
+        writer = OutputWriter(outpath, skip_grid=opt.skip_grid)      # PNG encodes run on a worker thread
     def with_landmark_prefetch(batches):
         """Yield (batch, landmarks136 or None): the dlib landmarks of batch i+1 are detected on a worker thread while the GPU works
         on batch i -- the only serial CPU stage inside the reference's batch loop (ddpm.py:1068-1099)."""
@@ -223,22 +228,30 @@ def main(argv=None):
                                              unconditional_guidance_scale=opt.scale, unconditional_conditioning=uc, eta=opt.ddim_eta,
                                              x_T=x_T, log_every_t=100, test_model_kwargs=test_model_kwargs)
             x_dec = model.decode_first_stage(samples_ddim)
+            slot = host[n_batches % 2]                  # double-buffered pinned host staging: D2H of batch i overlaps batch i+1
+            if slot is None or slot[0].shape[0] < B:
+                slot = host[n_batches % 2] = (torch.empty(x_dec.shape, dtype=torch.float32).pin_memory(), torch.cuda.Event())
+            else:
+                slot[1].synchronize()                   # the copy that last used this slot has landed (two batches ago)
             x_img = torch.empty_like(x_dec)
             ops.to_image(x_dec, x_img)()
-            x_np = x_img.cpu().numpy()
+            slot[0][:B].copy_(x_img, non_blocking=True)
             n_done += B
+            n_batches += 1
             if not opt.skip_save:
-                un = lambda t: np.clip((t.cpu().numpy() + 1.0) / 2.0, 0.0, 1.0)
-                gt, inp = un(test_batch), un(inpaint_image)
-                for i in range(B):
-                    sid = segment_id_batch[i]
-                    save_png(x_np[i], os.path.join(result_path, sid + ".png"))
-                    save_png(np.repeat(inpaint_mask[i].cpu().numpy(), 3, 0), os.path.join(sample_path, sid + "_mask.png"))
-                    save_png(gt[i], os.path.join(sample_path, sid + "_GT.png"))
-                    save_png(inp[i], os.path.join(sample_path, sid + "_inpaint.png"))
-                    if not opt.skip_grid:
-                        grid = np.concatenate([inp[i], gt[i], x_np[i]], axis=2)
-                        save_png(grid, os.path.join(grid_path, "grid-" + sid + ".png"))
+                # reference panel of the grid / <id>_ref.png: 224 -> image size, bilinear (torchvision Resize on a tensor, :523)
+                ref = test_model_kwargs["ref_imgs"].squeeze(1).float().contiguous()
+                ref_big = torch.empty((B, 3, opt.H, opt.W), dtype=torch.float32, device=device)
+                ops.bilinear_resize(ref, ref_big)()
+                ref_np = ref_big.cpu().numpy()
+                slot[1].record()
+                slot[1].synchronize()
+                writer.submit(list(segment_id_batch), slot[0][:B].numpy().copy(), test_batch.float().numpy(), inpaint_image.cpu().numpy(),
+                              inpaint_mask.float().cpu().numpy(), ref_np)
+            else:
+                slot[1].record()
+    if writer is not None:
+        writer.close()
     torch.cuda.synchronize()
     dt = time.time() - t_start
     print(f"Your samples are ready and waiting for you here: \n{outpath} \n ({n_done} images on rank {rank} in {dt:.1f}s)\nEnjoy.")

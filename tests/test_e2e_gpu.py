@@ -119,6 +119,19 @@ def test_whole_chain_vs_reference_golden(golden_dir):
     ops.to_image(x_dec, img)()
     u8 = (255.0 * img.permute(0, 2, 3, 1).cpu().numpy()).astype(np.uint8)
     assert (np.abs(u8.astype(int) - g["u8"].astype(int)) <= 1).all() and (u8 != g["u8"]).mean() < 2e-3
+    # the on-disk output tree (inference_test_bench.py:500-552) of item 0 against what the reference's own save block wrote
+    from reface_amd import output as O
+    gp = G(golden_dir, "e2e_png")
+    ref_big = torch.empty((B, 3, H, H), dtype=torch.float32, device=DEV)
+    ops.bilinear_resize(ref.to(DEV).contiguous(), ref_big)()
+    o = O.compose(img[0].cpu().numpy(), target[0].numpy(), inpaint_image[0].numpy(), inpaint_mask[0].numpy(), ref_big[0].cpu().numpy())
+    assert np.array_equal(o["mask"], gp["mask"])
+    panel = lambda k: gp["grid"][2:2 + H, 2 + k * (H + 2):2 + k * (H + 2) + H]
+    assert np.array_equal(o["GT"], panel(0)) and np.array_equal(o["inpaint"], panel(1))
+    assert np.array_equal(o["ref"], panel(2)), np.abs(o["ref"].astype(int) - panel(2).astype(int)).max()      # rf_bilinear_resize is exact
+    assert (np.abs(o["result"].astype(int) - panel(3).astype(int)) <= 1).all()
+    d = np.abs(o["grid"].astype(int) - gp["grid"].astype(int))
+    assert d.max() <= 1 and (d[:, :2 + 3 * (H + 2)] == 0).all()                # everything left of the result panel is byte-exact
 
 
 def test_cli_synthetic_run(tmp_path):
@@ -132,10 +145,19 @@ def test_cli_synthetic_run(tmp_path):
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     res = sorted(os.listdir(out / "results"))
     assert res == ["000000000000.png", "000000000001.png", "000000000002.png"]
-    assert len(os.listdir(out / "grid")) == 3 and len(os.listdir(out / "samples")) == 9
+    assert len(os.listdir(out / "grid")) == 3
+    assert sorted(os.listdir(out / "samples")) == sorted(f"{i:012d}_{k}.png" for i in range(3) for k in ("mask", "GT", "inpaint", "ref"))
     from PIL import Image
     im = np.asarray(Image.open(out / "results" / res[0]))
     assert im.shape == (256, 256, 3) and im.std() > 1.0
+    grid = np.asarray(Image.open(out / "grid" / ("grid-" + res[0])))
+    assert grid.shape == (260, 4 * 258 + 2, 3)                                  # make_grid of 4 panels, padding 2
+    for k, nm in enumerate(("_GT", "_inpaint", "_ref")):
+        pn = np.asarray(Image.open(out / "samples" / (res[0][:-4] + nm + ".png")))
+        assert np.array_equal(grid[2:258, 2 + k * 258:2 + k * 258 + 256], pn), nm
+    assert np.array_equal(grid[2:258, 2 + 3 * 258:2 + 3 * 258 + 256], im)
+    mk = np.asarray(Image.open(out / "samples" / (res[0][:-4] + "_mask.png")))
+    assert set(np.unique(mk)) == {127, 255}                                     # 255 * (mask + 1) / 2
 
 
 def test_cli_plms_start_from_target(tmp_path):

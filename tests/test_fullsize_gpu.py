@@ -1,0 +1,311 @@
+"""Full-size GPU parity: the kernel instantiations the benchmark actually runs, against the CPU oracle / plain PyTorch.
+
+Tile selection in rf_conv_gemm is size-driven (8-wave 256x320 / 256x256 / 128x320 / 128x256 and the two-blocks-per-CU
+128x160 configurations need >= 192 tiles), rf_attention switches to two query blocks per wave from 512 blocks and the GroupNorm
+statistics go through rf_groupnorm_finalize above 96 chunk slots -- so the small-shape tests of test_ops_gpu.py /
+test_pipeline_gpu.py never reach the code that owns the profile.  These tests run BASELINE configs[1] / configs[3] sizes:
+
+  * full-width (859.5 M-parameter) UNet, one CFG pair at 64x64 and 96x96 latents, fp32 engine vs oracle.unet.unet_forward
+    (openaimodel.py:860-907) -- and the bf16 engine (the benchmark's instantiations) against the same oracle output;
+  * full-width fp32 KL-VAE decode of a 512x512 / 768x768 image vs oracle.vae.decode_first_stage (model.py:535-568);
+  * rf_attention at (B*heads, d, N) = (128, 40, 4096) and (64, 40, 9216) vs PyTorch (attention.py:206-220);
+  * rf_conv_gemm at the benchmark's top GEMM shapes vs F.conv2d / F.linear on the bf16-rounded operands, with the tile
+    configuration asserted through rf_conv_gemm_plan;
+  * full-width fp32 5-step CFG DDIM at 64x64 + decode vs the oracle (|d| < 1e-3 per pixel, the north-star gate).
+"""
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from reface_amd import ops
+from reface_amd import params as P
+from reface_amd.params import seeded_randn as rnd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FULL = dict(in_channels=9, model_channels=320, out_channels=4, num_res_blocks=2, attention_resolutions=(4, 2, 1),
+            channel_mult=(1, 2, 4, 4), num_heads=8, context_dim=768)
+
+
+@pytest.fixture(scope="module")
+def full_unet():
+    from reface_amd.unet import UNetModel
+    m = UNetModel(image_size=32, use_spatial_transformer=True, transformer_depth=1, use_checkpoint=True, legacy=False, **FULL)
+    sd = P.seeded_state_dict(P.unet_param_specs(m.cfg), 1234)
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV).eval(), sd
+
+
+@pytest.fixture(scope="module")
+def full_vae():
+    from reface_amd.vae import AutoencoderKL
+    vae = AutoencoderKL(ddconfig=dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
+                                      ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0),
+                        lossconfig={"target": "torch.nn.Identity"}, embed_dim=4)
+    sd = P.seeded_state_dict(P.vae_param_specs(vae.cfg), 55)
+    vae.load_state_dict(sd, strict=True)
+    return vae.to(DEV).eval(), sd
+
+
+def _oracle_threads():
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+
+
+# ------------------------------------------------------------------------------------------------ UNet at 64x64 / 96x96
+@pytest.mark.parametrize("hw", [64, 96])
+def test_unet_full_width_full_size_vs_oracle(full_unet, hw):
+    """One CFG pair (batch 2: same x and t, different context) of the full-width UNet at the configured latent size."""
+    from oracle import unet as ounet
+    m, sd = full_unet
+    plan = P.unet_plan(m.cfg)
+    x1 = rnd((1, 9, hw, hw), 400 + hw)
+    x = torch.cat([x1, x1])
+    t = torch.full((2,), 481, dtype=torch.long)
+    ctx = rnd((2, 1, 768), 401)
+    _oracle_threads()
+    with torch.no_grad():
+        ref = ounet.unet_forward(sd, plan, x, t, ctx)
+    scale = ref.abs().max().item()
+    # (1) exact-fp32 engine, generic entry point (no CFG sharing): the parity gate
+    m.set_compute_dtype(torch.float32)
+    y = m(x.to(DEV), t.to(DEV), context=ctx.to(DEV)).cpu()
+    e32 = (y - ref).abs().max().item()
+    assert e32 < 2e-4 * max(1.0, scale), (e32, scale)
+    # (2) the sampler's engine (uniform timestep, CFG-shared stem, statistics from GEMM epilogues), fp32 and bf16
+    for dt, lim in ((torch.float32, 2e-4), (torch.bfloat16, 0.05)):
+        m.set_compute_dtype(dt)
+        eng = m.engine(2, hw, hw, uniform_t=True, cfg_pair=True)
+        ops.nchw_to_nhwc(x.to(DEV), eng.x_in)()
+        eng.set_context(ctx.to(DEV))
+        eng.set_timesteps(t[:1].to(DEV))
+        eng.run()
+        out = torch.empty((2, 4, hw, hw), dtype=torch.float32, device=DEV)
+        ops.nhwc_to_nchw(eng.eps, out)()
+        torch.cuda.synchronize()
+        out = out.cpu()
+        assert torch.isfinite(out).all()
+        if dt == torch.float32:
+            e = (out - ref).abs().max().item()
+            assert e < lim * max(1.0, scale), (dt, e, scale)
+        else:                                   # bf16: relative L2 of the whole eps tensor + a max-norm bound, stated
+            rel = ((out - ref).norm() / ref.norm()).item()
+            emax = (out - ref).abs().max().item()
+            assert rel < lim and emax < 0.25 * scale, (dt, rel, emax, scale)
+        m._engines.clear()
+        del eng
+        torch.cuda.empty_cache()
+    m.set_compute_dtype(torch.float32)
+
+
+def test_unet_bf16_batch16_cfg_matches_oracle_rows(full_unet):
+    """The benchmark's exact engine shape (B = 8 images -> CFG batch 16 at 64x64, bf16): tile selection depends on M, so the
+    M = 65536 / 16384 / 4096 / 1024 instantiations (256x320, 256x256, 128x320, 128x160 two-per-CU, split-K) are the ones run here.
+    Sample 0 / sample 8 (one CFG pair) must match the oracle's result for that pair; the other pairs use different x."""
+    from oracle import unet as ounet
+    m, sd = full_unet
+    plan = P.unet_plan(m.cfg)
+    hw, B = 64, 8
+    xs = rnd((B, 9, hw, hw), 410)
+    x = torch.cat([xs, xs])
+    ctx = rnd((2 * B, 1, 768), 411)
+    t = torch.full((2,), 741, dtype=torch.long)
+    _oracle_threads()
+    with torch.no_grad():
+        ref = ounet.unet_forward(sd, plan, torch.cat([xs[:1], xs[:1]]), t, torch.cat([ctx[:1], ctx[B:B + 1]]))
+    m.set_compute_dtype(torch.bfloat16)
+    eng = m.engine(2 * B, hw, hw, uniform_t=True, cfg_pair=True)
+    ops.nchw_to_nhwc(x.to(DEV), eng.x_in)()
+    eng.set_context(ctx.to(DEV))
+    eng.set_timesteps(t[:1].to(DEV))
+    eng.run()
+    out = torch.empty((2 * B, 4, hw, hw), dtype=torch.float32, device=DEV)
+    ops.nhwc_to_nchw(eng.eps, out)()
+    torch.cuda.synchronize()
+    out = out.cpu()
+    got = torch.stack([out[0], out[B]])
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert torch.isfinite(out).all() and rel < 0.05, rel
+    # the plan really is the big-tile one
+    tiles = set()
+    for l in eng.main:
+        if l.fn.__name__ == "rf_conv_gemm":
+            tiles.add(ops.gemm_plan(l)[:2])
+    assert (256, 320) in tiles and (256, 256) in tiles, tiles
+    m._engines.clear()
+    m.set_compute_dtype(torch.float32)
+    del eng
+    torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------ VAE decode at 512 / 768
+@pytest.mark.parametrize("h", [64, 96])
+def test_vae_decode_full_size_vs_oracle(full_vae, h):
+    from oracle import vae as ovae
+    vae, sd = full_vae
+    z = rnd((1, 4, h, h), 420 + h)
+    _oracle_threads()
+    with torch.no_grad():
+        ref = ovae.decode_first_stage(sd, vae.cfg, z)
+    got = vae.decode(z.to(DEV), inv_scale=1.0 / 0.18215).cpu()
+    torch.cuda.synchronize()
+    e = (got - ref).abs().max().item()
+    assert got.shape == ref.shape == (1, 3, 8 * h, 8 * h)
+    assert e < 1e-3, e          # north-star gate: |d| < 1e-3 per pixel with the fp32 decode
+    if h == 64:                 # the benchmark's batch (B = 8): sample 3 of a batch must equal the single-sample result
+        zb = rnd((8, 4, h, h), 431)
+        zb[3] = z[0]
+        gb = vae.decode(zb.to(DEV), inv_scale=1.0 / 0.18215)[3].cpu()
+        assert (gb - ref[0]).abs().max().item() < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("BH,d,N", [(128, 40, 4096), (64, 40, 9216), (128, 80, 1024), (128, 160, 256)])
+def test_attention_bench_shapes(dt, BH, d, N):
+    """(batch*heads, head dim, tokens) of the benchmark's self-attention launches: 16 x 8 heads at 64x64 / 32x32 / 16x16 and the
+    96x96 latent of configs[3] (8 x 8 heads, N = 9216).  bf16 d = 40 with >= 512 blocks takes the two-query-blocks-per-wave kernel."""
+    heads = 8
+    B = BH // heads
+    C_ = heads * d
+    qkv = rnd((B, N, 3 * C_), 440) * 0.7
+    qkv[..., :C_] *= 6.0                     # peaky softmax (logit std ~ 3): the output is O(0.5), not an average of everything
+    qkv = qkv.to(dt)
+    qkv_d = qkv.to(DEV)
+    out = torch.empty((B, N, C_), dtype=dt, device=DEV)
+    ops.attention(qkv_d[..., :C_], qkv_d[..., C_:2 * C_], qkv_d[..., 2 * C_:], out, heads=heads, scale=d ** -0.5)()
+    torch.cuda.synchronize()
+    # reference on the GPU in fp32 through PyTorch's plain ops, one head at a time (fp32 scores of N = 9216 are 340 MB per head)
+    qf = qkv_d.float()
+    worst, num, den = 0.0, 0.0, 0.0
+    for b in sorted({0, B // 2, B - 1}):             # three batch elements, all heads
+        q_, k_, v_ = (qf[b, :, i * C_:(i + 1) * C_].reshape(N, heads, d).permute(1, 0, 2) for i in range(3))
+        for h0 in range(heads):
+            s = (q_[h0] @ k_[h0].T) * (d ** -0.5)
+            ref = torch.softmax(s, dim=-1) @ v_[h0]
+            got = out[b, :, h0 * d:(h0 + 1) * d].float()
+            worst = max(worst, (got - ref).abs().max().item())
+            num += ((got - ref) ** 2).sum().item()
+            den += (ref ** 2).sum().item()
+            del s
+    rel = math.sqrt(num / den)
+    assert torch.isfinite(out.float()).all()
+    if dt == torch.float32:
+        assert worst < 2e-5 and rel < 1e-5, (worst, rel)
+    else:                                            # bf16 P and V (2^-9 relative rounding each), fp32 accumulation
+        assert worst < 2e-2 and rel < 6e-3, (worst, rel)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM at the benchmark's shapes
+# (name, M, N, K, kind, expected (tile rows, tile cols) of the block that finishes an output tile, splitk > 1?)
+BENCH_GEMMS = [
+    ("ob.8.2.conv 3x3 @64 C640->640", 65536, 640, 5760, "conv3", (256, 320), False),
+    ("ob.9.0.in_layers.2 3x3 @64 C960->320", 65536, 320, 8640, "conv3", (256, 320), False),
+    ("ib.2.0.in_layers.2 3x3 @64 C320", 65536, 320, 2880, "conv3", (256, 320), False),
+    ("ob.5.2.conv 3x3 @32 C1280", 16384, 1280, 11520, "conv3", (256, 320), False),
+    ("ib.5.0.in_layers.2 3x3 @32 C640", 16384, 640, 5760, "conv3", None, False),
+    ("ob.3.0.in_layers.2 3x3 @16 C2560->1280", 4096, 1280, 23040, "conv3", None, False),
+    ("ib.10 3x3 @8 C1280", 1024, 1280, 11520, "conv3", None, True),
+    ("ff.net.0 GEGLU @64", 65536, 2560, 320, "geglu", (256, 256), False),
+    ("ff.net.0 GEGLU @32", 16384, 5120, 640, "geglu", (256, 256), False),
+    ("ff.net.2 @64", 65536, 320, 1280, "linear_res", (256, 320), False),
+    ("attn1.qkv @64", 65536, 960, 320, "linear", (256, 320), False),
+    ("attn1.qkv @16", 4096, 3840, 1280, "linear", None, False),
+    ("proj_out @64", 65536, 320, 320, "linear_res", (256, 320), False),
+]
+
+
+@pytest.mark.parametrize("case", BENCH_GEMMS, ids=[c[0] for c in BENCH_GEMMS])
+def test_conv_gemm_bench_shapes_bf16(case):
+    name, M, N, K, kind, want_tile, want_split = case
+    dt = torch.bfloat16
+    if kind == "conv3":
+        Cin = K // 9
+        hw = {65536: 64, 16384: 32, 4096: 16, 1024: 8}[M]
+        B = M // (hw * hw)
+        x = (rnd((B, hw, hw, Cin), 450) * 0.5).to(dt)
+        w = (rnd((N, Cin, 3, 3), 451) / math.sqrt(K)).to(dt)
+        b = rnd((N,), 452)
+        rv = rnd((B, N), 453)
+        out = torch.empty((B, hw, hw, N), dtype=dt, device=DEV)
+        l = ops.conv2d(x.to(DEV), ops.pack_conv_weight(w.float(), dt).to(DEV), out, b.to(DEV), rowvec=rv.to(DEV))
+        l()
+        torch.cuda.synchronize()
+        # reference: im2col + fp32 matmul on the GPU (plain PyTorch ops) over the same bf16-rounded operands
+        cols = F.unfold(x.to(DEV).float().permute(0, 3, 1, 2), 3, padding=1)            # [B, Cin*9, hw*hw], k = c*9 + tap
+        ref = torch.einsum("bkl,nk->bln", cols, w.to(DEV).float().reshape(N, Cin * 9)) + b.to(DEV) + rv.to(DEV)[:, None, :]
+        del cols
+        ref = ref.reshape(B, hw, hw, N)
+        got = out.float()
+    else:
+        x = (rnd((M, K), 454) * 0.5).to(dt)
+        b = rnd((N,), 456)
+        if kind == "geglu":
+            w = (rnd((N, K), 455) / math.sqrt(K)).to(dt)
+            wp, bp = ops.pack_geglu(w.float(), b, dt)
+            out = torch.empty((M, N // 2), dtype=dt, device=DEV)
+            l = ops.linear(x.to(DEV), wp.to(DEV), out, bp.to(DEV), act=ops.ACT_GEGLU)
+            l()
+            h = F.linear(x.to(DEV).float(), w.to(DEV).float(), b.to(DEV))
+            a, g = h.chunk(2, -1)
+            ref = a * F.gelu(g)
+        else:
+            w = (rnd((N, K), 455) / math.sqrt(K)).to(dt)
+            res = rnd((M, N), 457).to(dt).to(DEV) if kind == "linear_res" else None
+            out = torch.empty((M, N), dtype=dt, device=DEV)
+            l = ops.linear(x.to(DEV), w.to(DEV), out, b.to(DEV), residual=res)
+            l()
+            ref = F.linear(x.to(DEV).float(), w.to(DEV).float(), b.to(DEV))
+            if res is not None:
+                ref = ref + res.float()
+        torch.cuda.synchronize()
+        got = out.float()
+    bm, bn, sk = ops.gemm_plan(l)
+    if want_tile is not None:
+        assert (bm, bn) == want_tile and sk == 1, (name, bm, bn, sk)
+    if want_split:
+        assert sk > 1, (name, sk)
+    err = (got - ref).abs()
+    lim = 2e-2 + 1e-2 * ref.abs()          # bf16 output rounding (2^-9 relative) + fp32 accumulation-order noise
+    assert torch.isfinite(got).all() and (err <= lim).all(), (name, err.max().item(), ref.abs().max().item())
+    # a row-mapping bug would move whole rows: the per-row mean error must be rounding-sized everywhere
+    assert err.reshape(-1, got.shape[-1]).mean(dim=1).max().item() < 4e-3 * max(1.0, ref.abs().mean().item() * 4), name
+
+
+# ------------------------------------------------------------------------------------------------ 5-step CFG DDIM + decode, full width
+@pytest.mark.slow
+def test_full_width_ddim5_decode_vs_oracle(full_unet, full_vae):
+    """Full-width fp32: 5 CFG DDIM steps at 64x64 (B = 1) + fp32 VAE decode vs the oracle: |d| < 1e-3 per pixel."""
+    import types
+    from oracle import ddim as oddim, unet as ounet, vae as ovae
+    from reface_amd.ddim import DDIMSampler
+    from reface_amd.schedule import ddpm_buffers
+    m, usd = full_unet
+    vae, vsd = full_vae
+    m.set_compute_dtype(torch.float32)
+    b = ddpm_buffers(1000, 0.00085, 0.0120)
+    ldm = types.SimpleNamespace(num_timesteps=1000, betas=b["betas"], alphas_cumprod=b["alphas_cumprod"],
+                                alphas_cumprod_prev=b["alphas_cumprod_prev"], device=torch.device(DEV),
+                                model=types.SimpleNamespace(diffusion_model=m))
+    B, h, S = 1, 64, 5
+    x_T, z_inp = rnd((B, 4, h, h), 460), rnd((B, 4, h, h), 461)
+    mask = (rnd((B, 1, h, h), 462) > 0).float()
+    z_inp = z_inp * mask
+    c, uc = rnd((B, 1, 768), 463), rnd((1, 1, 768), 464).repeat(B, 1, 1)
+    got, _ = DDIMSampler(ldm).sample(S=S, conditioning=c.to(DEV), batch_size=B, shape=[4, h, h], verbose=False,
+                                    unconditional_guidance_scale=3.5, unconditional_conditioning=uc.to(DEV), eta=0.0, x_T=x_T.to(DEV),
+                                    test_model_kwargs={"inpaint_image": z_inp.to(DEV), "inpaint_mask": mask.to(DEV)})
+    img = vae.decode(got, inv_scale=1.0 / 0.18215)
+    torch.cuda.synchronize()
+    plan = P.unet_plan(m.cfg)
+    _oracle_threads()
+    with torch.no_grad():
+        ref, _ = oddim.sample(lambda x, t, cc: ounet.unet_forward(usd, plan, x, t, cc), S, x_T, c, uc, z_inp, mask, 3.5)
+        ref_img = ovae.decode_first_stage(vsd, vae.cfg, ref)
+    e_lat = (got.cpu() - ref).abs().max().item()
+    e_img = (img.cpu() - ref_img).abs().max().item()
+    assert e_lat < 1e-3 and e_img < 1e-3, (e_lat, e_img)
+    m._engines.clear()
+    torch.cuda.empty_cache()

@@ -185,33 +185,41 @@ def test_synthetic_dataset_contract_and_sharding():
 _WORKER = r"""
 import os, sys, time, torch, torch.distributed as dist
 sys.path.insert(0, %r)
-from reface_amd.data import SyntheticPairs, shard_indices
+from reface_amd.data import SyntheticPairs
+from reface_amd.multigpu import broadcast_module, broadcast_tensors, max_over_ranks, shard_indices
 from reface_amd import params as P
+from reface_amd.vae import AutoencoderKL
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-# (1) weights: rank 0 generates, one flat broadcast per module (bench.py build_models)
-specs = P.vae_param_specs(P.VAEConfig(ch=32))
-sd = P.seeded_state_dict(specs, 55) if rank == 0 else {k: torch.zeros(v) for k, v in specs.items()}
-flat = torch.cat([t.reshape(-1) for t in sd.values()])
-dist.broadcast(flat, 0)
-ref = torch.cat([t.reshape(-1) for t in P.seeded_state_dict(specs, 55).values()])
-assert torch.equal(flat, ref)
-# (2) pairs shard r::world with no data-path collective; per-rank seeds differ
+# (1) weights: rank 0 holds them, the OTHER ranks start from zeros; bench.py / the CLI call exactly this function
+vae = AutoencoderKL(ddconfig=dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
+                                  num_res_blocks=2, attn_resolutions=[], dropout=0.0), lossconfig={}, embed_dim=4)
+ref = P.seeded_state_dict(P.vae_param_specs(vae.cfg), 55)
+if rank == 0:
+    vae.load_state_dict(ref, strict=True)
+ncall = broadcast_module(vae, 0)
+got = vae.state_dict()
+assert all(torch.equal(got[k], ref[k]) for k in ref), "broadcast mismatch"
+assert ncall <= 2, ncall                      # flat buffers, not one collective per tensor (there are > 100 tensors)
+# mixed dtypes / small chunks exercise the packing
+ts = [torch.full((5,), float(rank)), torch.full((3, 2), rank, dtype=torch.int64), torch.full((7,), float(rank) + 1)]
+n2 = broadcast_tensors(ts, 0, chunk_bytes=32)
+assert all(float(t.double().sum()) == s for t, s in zip(ts, (0.0, 0.0, 7.0))) and n2 == 3
+# (2) pairs shard r::world with no data-path collective
 ds = SyntheticPairs(n=7, image_size=32, seed=42)
 mine = shard_indices(len(ds), rank, world)
-got = torch.tensor([float(ds[i][0].sum()) for i in mine])
 # (3) timing: barrier, max over ranks
 dist.barrier(); t0 = time.perf_counter(); time.sleep(0.05 * (rank + 1)); dist.barrier()
-el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-dist.all_reduce(el, op=dist.ReduceOp.MAX)
+el = max_over_ranks(time.perf_counter() - t0)
 cnt = torch.tensor([len(mine)]); dist.all_reduce(cnt)
-assert int(cnt) == 7 and float(el) >= 0.05 * world - 1e-3
+assert int(cnt) == 7 and el >= 0.05 * world - 1e-3
 if rank == 0: print("GLOO_OK", int(cnt), len(mine))
 dist.destroy_process_group()
 """
 
 
 def test_multiprocess_sharding_gloo(tmp_path):
+    """world_size-2 gloo run of the functions bench.py and the CLI use for the N > 1 path (reface_amd/multigpu.py)."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER % ROOT)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="1")
@@ -219,6 +227,62 @@ def test_multiprocess_sharding_gloo(tmp_path):
                         "--master-port", "29533", str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "GLOO_OK 7 4" in r.stdout
+
+
+def test_bench_spawns_its_own_ranks(monkeypatch):
+    """`bench.py --gpus N` without a launcher starts torch.distributed.run as a CHILD process (never re-execs itself) with
+    the driver's rendezvous conventions and forwards its own flags."""
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # configs: the metric label follows the workload
+    assert bench.CONFIGS["c3"]["latent"] == 96 and bench.CONFIGS["c3"]["batch"] == 4 and bench.CONFIGS["c4"]["dtype"] == "fp8"
+
+
+def test_output_tree_composition():
+    """reface_amd/output.py: the reference's file set (inference_test_bench.py:500-553) -- 4-panel make_grid with 2-pixel padding,
+    mask as 255*(m+1)/2 (0 -> 127), truncating float -> uint8 conversion, un-clamped CLIP-un-normalised reference panel."""
+    from reface_amd import output as O
+    rng = np.random.default_rng(0)
+    H = 16
+    res = rng.random((3, H, H), dtype=np.float32)
+    tgt = np.tanh(rng.standard_normal((3, H, H))).astype(np.float32)
+    msk = (rng.random((1, H, H)) > 0.5).astype(np.float32)
+    ref = rng.standard_normal((3, H, H)).astype(np.float32)
+    o = O.compose(res, tgt, tgt * msk, msk, ref)
+    assert set(o) == {"result", "mask", "GT", "inpaint", "ref", "grid"}
+    assert o["grid"].shape == (H + 4, 4 * (H + 2) + 2, 3) and o["grid"].dtype == np.uint8
+    assert set(np.unique(o["mask"])) <= {127, 255} and o["mask"].shape == (H, H, 3)
+    assert np.array_equal(o["result"], (255.0 * res.transpose(1, 2, 0)).astype(np.uint8))
+    for k, name in enumerate(("GT", "inpaint", "ref", "result")):          # panels in the reference's order, padding 2, pad value 0
+        x0 = 2 + k * (H + 2)
+        assert np.array_equal(o["grid"][2:2 + H, x0:x0 + H], o[name]), name
+    assert (o["grid"][:2] == 0).all() and (o["grid"][:, :2] == 0).all() and (o["grid"][:, x0 + H:] == 0).all()
+    assert np.array_equal(o["GT"], (255.0 * ((tgt + 1.0) / 2.0).transpose(1, 2, 0)).astype(np.uint8))
+
+
+def test_checkpoint_missing_engine_tensor_is_an_error():
+    """A pruned checkpoint must not leave engine tensors at their zero initialisation: strict=False loading
+    reports it through LatentDiffusion.check_engine_weights; keys the inference path never reads may be absent."""
+    model, _ = _small_model()
+    model.check_engine_weights(["betas", "cond_stage_model.model.text_projection.weight", "model_ema.decay"])     # fine
+    with pytest.raises(RuntimeError, match="would stay zero"):
+        model.check_engine_weights(["model.diffusion_model.out.2.weight"])
+    with pytest.raises(RuntimeError, match="would stay zero"):
+        model.check_engine_weights(["face_ID_model.facenet.input_layer.0.weight"])
 
 
 def test_celeba_reader_contract(tmp_path):

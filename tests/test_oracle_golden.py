@@ -262,3 +262,26 @@ def test_e2e_small(golden_dir):
     u8 = encoders.to_uint8_image(x_dec)
     assert (np.abs(u8.astype(int) - g["u8"].astype(int)) <= 1).all()
     assert (u8 != g["u8"]).mean() < 1e-3
+
+
+def test_output_tree_vs_reference_golden(golden_dir):
+    """reface_amd/output.py against the files the reference's own save block (inference_test_bench.py:500-552) produced for the
+    e2e fixture: mask, GT and inpaint panels depend only on the inputs -> byte-for-byte; grid geometry exact."""
+    from reface_amd import output as O
+    g = np.load(os.path.join(golden_dir, "e2e_png.npz"))
+    B, H = 2, 256
+    target = torch.tanh(rnd((B, 3, H, H), 70))
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(H), indexing="ij")
+    ell = (((yy - H / 2) / (0.30 * H)) ** 2 + ((xx - H / 2) / (0.38 * H)) ** 2) <= 1.0
+    inpaint_mask = (~ell).float()[None, None].repeat(B, 1, 1, 1)
+    inpaint_image = target * inpaint_mask
+    zero = np.zeros((3, H, H), np.float32)
+    o = O.compose(zero, target[0].numpy(), inpaint_image[0].numpy(), inpaint_mask[0].numpy(), zero)
+    assert o["grid"].shape == g["grid"].shape
+    assert np.array_equal(o["mask"], g["mask"])
+    for k, nm in enumerate(("GT", "inpaint")):
+        assert np.array_equal(o[nm], g["grid"][2:2 + H, 2 + k * (H + 2):2 + k * (H + 2) + H]), nm
+    pad = np.ones(g["grid"].shape[:2], bool)
+    for k in range(4):
+        pad[2:2 + H, 2 + k * (H + 2):2 + k * (H + 2) + H] = False
+    assert (g["grid"][pad] == 0).all() and np.array_equal(o["grid"][pad], g["grid"][pad])

@@ -144,11 +144,15 @@ def _ddim_inputs():
     return x_T, z_inp, mask, c, uc
 
 
-@pytest.mark.parametrize("S,graph", [(5, False), (5, True), (50, True)])
-def test_ddim_vs_reference_golden(golden_dir, S, graph):
+@pytest.mark.parametrize("S,graph", [(5, False), (5, True), (50, True), (50, "per_step"), (5, "per_step")])
+def test_ddim_vs_reference_golden(golden_dir, S, graph, monkeypatch):
+    """graph=True: the whole S-step loop is ONE captured HIP graph (in-graph copies deliver the intermediates);
+    "per_step": one graph of a single step replayed S times (REFACE_GRAPH_STEPS=1); False: eager launches."""
     from reface_amd.ddim import DDIMSampler
     unet = make_unet(SMALL_UNET, 7)
-    sampler = DDIMSampler(_LDMStub(unet), use_graph=graph)
+    if graph == "per_step":
+        monkeypatch.setenv("REFACE_GRAPH_STEPS", "1")
+    sampler = DDIMSampler(_LDMStub(unet), use_graph=bool(graph))
     x_T, z_inp, mask, c, uc = _ddim_inputs()
     g = G(golden_dir, f"ddim_small_S{S}")
     samples, inter = sampler.sample(S=S, conditioning=c.to(DEV), batch_size=2, shape=[4, 16, 16], verbose=False,

@@ -424,6 +424,39 @@ def gen_e2e():
     save("e2e_small", landmarks=landmarks, c=c, uc=uc, post_mean=post.mean, post_logvar=post.logvar, eps=eps,
          z_inpaint=z_inpaint, mask64=mask64, samples=samples, x_dec=x_dec, u8=u8)
 
+    # ---- the on-disk output tree: the reference's OWN statements (scripts/inference_test_bench.py:500-552, read from the
+    # reference tree at generation time, never stored) executed on this run's tensors; PIL's save is replaced by a recorder.
+    import textwrap
+    import types as _types
+    from einops import rearrange
+    from torchvision.utils import make_grid                   # tools/ref_shims.py restatement (torchvision is not installed)
+    src = open("/root/reference/scripts/inference_test_bench.py").read().split("\n")
+    assert src[499].strip() == "def un_norm(x):" and src[551].strip().startswith("ref_img.save("), (src[499], src[551])
+    block = textwrap.dedent("\n".join(src[499:552]))
+    written = {}
+
+    class _Rec:
+        def __init__(self, a):
+            self.a = np.array(a)
+
+        def save(self, path):
+            written[os.path.basename(path)] = self.a
+
+    cv2 = _types.SimpleNamespace(COLOR_GRAY2RGB=8, cvtColor=lambda a, code: np.repeat(a, 3, axis=2))      # GRAY2RGB replicates the channel
+    ns = dict(torch=torch, np=np, os=os, rearrange=rearrange, make_grid=make_grid, Resize=lambda sz: Resize([H, H]), cv2=cv2,
+              Image=_types.SimpleNamespace(fromarray=_Rec), opt=_types.SimpleNamespace(skip_save=False),
+              x_checked_image_torch=x_img, test_batch=target, inpaint_image=inpaint_image, inpaint_mask=inpaint_mask,
+              test_model_kwargs={"ref_imgs": ref.unsqueeze(1)}, segment_id_batch=["a", "b"], grid_path="g", result_path="r",
+              sample_path="s", base_count=0)
+    exec(block, ns)
+    assert sorted(written) == ["a.png", "a_GT.png", "a_inpaint.png", "a_mask.png", "a_ref.png", "b.png", "b_GT.png", "b_inpaint.png",
+                               "b_mask.png", "b_ref.png", "grid-a.png", "grid-b.png"], sorted(written)
+    # item 0 only (random images do not compress): grid carries the GT / inpaint / ref / result panels
+    g0 = written["grid-a.png"]
+    for k, nm in enumerate(("a_GT.png", "a_inpaint.png", "a_ref.png", "a.png")):       # the individual files ARE the grid's panels
+        assert np.array_equal(g0[2:2 + H, 2 + k * (H + 2):2 + k * (H + 2) + H], written[nm]), nm
+    save("e2e_png", grid=g0, mask=written["a_mask.png"])
+
 
 GROUPS = dict(plms=gen_plms, schedule=gen_schedule, unet_ops=gen_unet_ops, unet_small=gen_unet_small, unet_full=gen_unet_full,
               ddim=gen_ddim, vae=gen_vae, arcface=gen_arcface, clip=gen_clip, e2e=gen_e2e)

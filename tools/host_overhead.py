@@ -25,10 +25,11 @@ for _ in range(2):
     print(f"sample: host returns after {a*1e3:.1f} ms, device done after {b_*1e3:.1f} ms | decode: host {c_*1e3:.1f} ms, device {d*1e3:.1f} ms")
 # per-step replay cost
 plan = list(sampler._plans.values())[0]
-g = plan["graph"]
+g = list(plan["graphs"].values())[0]
+nst = g["tab"].shape[0]
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(20): g.replay()
-torch.cuda.synchronize(); print(f"graph replay: {(time.perf_counter()-t0)/20*1e3:.2f} ms per step")
+for _ in range(3): g["graph"].replay()
+torch.cuda.synchronize(); print(f"graph replay ({nst} steps per graph): {(time.perf_counter()-t0)/3/nst*1e3:.3f} ms per step")
 eng = plan["eng"]
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(5): ops.run(plan["step"])

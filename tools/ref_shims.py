@@ -78,7 +78,29 @@ def install():
 
     tv = _mod("torchvision")
     tvu = _mod("torchvision.utils")
-    tvu.make_grid = lambda *a, **k: None
+
+    def make_grid(tensor, nrow=8, padding=2, normalize=False, value_range=None, scale_each=False, pad_value=0.0, **kw):
+        """torchvision.utils.make_grid restated from its documented behaviour for a 4-D float tensor, normalize=False: images
+        left to right, `nrow` per row, each preceded by `padding` pixels of `pad_value`, plus a closing border."""
+        assert tensor.dim() == 4 and not normalize and not scale_each
+        if tensor.size(0) == 1:
+            return tensor.squeeze(0)
+        import math
+        nmaps = tensor.size(0)
+        xmaps = min(nrow, nmaps)
+        ymaps = int(math.ceil(float(nmaps) / xmaps))
+        height, width = int(tensor.size(2) + padding), int(tensor.size(3) + padding)
+        grid = tensor.new_full((tensor.size(1), height * ymaps + padding, width * xmaps + padding), pad_value)
+        k = 0
+        for y in range(ymaps):
+            for x in range(xmaps):
+                if k >= nmaps:
+                    break
+                grid.narrow(1, y * height + padding, height - padding).narrow(2, x * width + padding, width - padding).copy_(tensor[k])
+                k += 1
+        return grid
+
+    tvu.make_grid = make_grid
     tvt = _mod("torchvision.transforms")
     tvf = _mod("torchvision.transforms.functional")
     tvm = _mod("torchvision.models")
