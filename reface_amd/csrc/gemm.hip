@@ -48,6 +48,7 @@ struct GemmParams {
     double* gn_part[2];
     int gn_cpg[2], gn_coff[2], gn_slot[2], gn_nch[2];
     int* plan;       // host only: {BM, BN, splitk} requested by rf_conv_gemm_plan (no launch)
+    int epi2_ok;     // host only: operand alignment / feature set allow the direct (register -> global) epilogue
 };
 
 template <typename T> struct MmaFrag;
@@ -81,8 +82,14 @@ template <typename TO> __device__ __forceinline__ float load_out(const TO* p);
 template <> __device__ __forceinline__ float load_out<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float load_out<bf16_t>(const bf16_t* p) { return bf2f(*p); }
 
-template <typename T, typename TO, int WM, int WN, int TM, int TN, bool CONV, bool GLDS, int NST>
+// EPI = 1: "direct" epilogue.  The MFMA operands are swapped (W fragment as the row operand, A fragment as the column operand)
+// and the W rows of each 32-row block are read in the order  row(i') = 16*((i'>>2)&1) + 4*(i'>>3) + (i'&3), so that lane
+// (m = l & 31, h = l >> 5) ends up with accumulator register r = output column 16*h + r of its row: 16 CONTIGUOUS columns per
+// 32x32 block.  Bias / activation / residual / GEGLU then happen in registers and every lane writes its row segments with 16-byte
+// stores -- no LDS staging pass, no barriers, and waves retire independently.
+template <typename T, typename TO, int WM, int WN, int TM, int TN, bool CONV, bool GLDS, int NST, int EPI = 0>
 __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams p) {
+    static_assert(EPI == 0 || GLDS, "the direct epilogue is built on the direct-to-LDS main loop");
     constexpr int NT = WM * WN * 64;
     constexpr int BM = 32 * TM * WM;
     constexpr int BN = 32 * TN * WN;
@@ -346,14 +353,20 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         constexpr int JS = ROT ? 2 : 0;      // B columns whose MFMAs go ahead of the first next-fragment reads
         u32x4_t fa[2][TM], fb[2][TN];
         const int frag_sw = (lrow >> 1) & 7;
-        int fk[4];           // swizzled byte position of k-step kk inside a fragment row
+        // W-tile row this lane reads for the row operand of its 32-row blocks (EPI = 1: permuted, see the kernel comment)
+        const int brow = EPI ? (16 * ((lrow >> 2) & 1) + 4 * (lrow >> 3) + (lrow & 3)) : lrow;
+        const int frag_swb = (brow >> 1) & 7;
+        int fk[4], fkb[4];   // swizzled byte position of k-step kk inside a fragment row (A side, W side)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) fk[kk] = ((kk * 2 + lhalf) ^ frag_sw) << 4;
+        for (int kk = 0; kk < 4; ++kk) {
+            fk[kk] = ((kk * 2 + lhalf) ^ frag_sw) << 4;
+            fkb[kk] = ((kk * 2 + lhalf) ^ frag_swb) << 4;
+        }
         // fragment row bases of the stage being multiplied (cur) and of the other stage (oth); swapped after every tile.
         // The loop body is ONE straight-line block (no per-tile variants): branches around MFMAs make the register allocator
         // keep two copies of the accumulators.
         const char* curA = ldsA + (wm * TM) * 4096 + lrow * 128;
-        const char* curB = ldsB + (wn * TN) * 4096 + lrow * 128;
+        const char* curB = ldsB + (wn * TN) * 4096 + brow * 128;
         const char* othA = curA + BM * 128;
         const char* othB = curB + BN * 128;
         // one k-step: its MFMAs, the fetch of the next step's fragments (k-step 3 fetches from the other stage, after the
@@ -364,11 +377,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             constexpr int fbc = ROT ? 0 : cur, fbn = ROT ? 0 : nx;
             constexpr int nkk = (kk + 1) & 3;
             const char* const nA = (kk < 3 ? curA : othA) + fk[nkk];
-            const char* const nB = (kk < 3 ? curB : othB) + fk[nkk];
+            const char* const nB = (kk < 3 ? curB : othB) + fkb[nkk];
 #pragma unroll
             for (int j = 0; j < JS; ++j)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) MmaFrag<T>::mma(acc[i][j], fa[cur][i], fb[fbc][j]);
+                for (int i = 0; i < TM; ++i) {
+                    if constexpr (EPI) MmaFrag<T>::mma(acc[i][j], fb[fbc][j], fa[cur][i]);
+                    else MmaFrag<T>::mma(acc[i][j], fa[cur][i], fb[fbc][j]);
+                }
             if (kk == 3) {
                 // own pieces of the next tile have landed and every fragment of this tile is in registers; past the barrier
                 // that holds for all waves: this stage may be overwritten (tile kt+2) and the other stage may be read
@@ -384,7 +400,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
             for (int j = JS; j < TN; ++j) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) MmaFrag<T>::mma(acc[i][j], fa[cur][i], fb[fbc][j]);
+                for (int i = 0; i < TM; ++i) {
+                    if constexpr (EPI) MmaFrag<T>::mma(acc[i][j], fb[fbc][j], fa[cur][i]);
+                    else MmaFrag<T>::mma(acc[i][j], fa[cur][i], fb[fbc][j]);
+                }
                 if (ROT) {
                     fb[0][j] = *(const u32x4_t*)(nB + j * 4096);
                     __builtin_amdgcn_sched_barrier(0);
@@ -408,7 +427,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[0][i] = *(const u32x4_t*)(curA + i * 4096 + fk[0]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[0][j] = *(const u32x4_t*)(curB + j * 4096 + fk[0]);
+            for (int j = 0; j < TN; ++j) fb[0][j] = *(const u32x4_t*)(curB + j * 4096 + fkb[0]);
         }
         for (int kt = 0; kt < nk; ++kt) {
             const int stage = kt & 1;
@@ -433,6 +452,144 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             if (kt + 1 < nk) store_tiles(buf ^ 1);
             __syncthreads();
         }
+    }
+
+    if constexpr (EPI == 1) {
+        // ---- direct epilogue: lane (row lrow of its 32-row block, half lhalf) holds columns 16*lhalf .. 16*lhalf+15 of every
+        // 32-column block of its wave tile.  Host guarantees (launch_typed): N % 16 == 0, 16-byte aligned rows of out / residual /
+        // bias / rowvec, no fused GroupNorm statistics, no PReLU, rowvec uniform per tile (or split-K, whose reduce pass adds it).
+        TO* const outp = (TO*)p.out + zb * p.sO;
+        const TO* const resp = p.residual ? (const TO*)p.residual + zb * p.sR : nullptr;
+        const bool partial_out = p.splitk > 1;
+        const float* const rvu = (p.rowvec && !partial_out) ? p.rowvec + (long long)(m0 / p.rows_per_sample) * p.ldv : nullptr;
+        constexpr int OV = sizeof(TO) == 2 ? 2 : 4;      // 16-byte vectors per 16 output values
+        auto store16 = [&](TO* dst, const float* v) {
+            if constexpr (sizeof(TO) == 2) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    u32x4_t w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = pack_bf2(v[8 * h + 2 * e], v[8 * h + 2 * e + 1]);
+                    ((u32x4_t*)dst)[h] = w;
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) ((f32x4_t*)dst)[h] = f32x4_t{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+            }
+        };
+        bool geglu = false;
+        if constexpr (TN % 2 == 0) geglu = p.act == RF_ACT_GEGLU;
+        if (partial_out) {
+            float* const wsz = p.ws + (long long)blockIdx.z * p.M * p.N;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + (wn * TN + j) * 32 + lhalf * 16;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = m0 + (wm * TM + i) * 32 + lrow;
+                    if (row < p.M && col < p.N) {
+                        float* dst = wsz + (long long)row * p.N + col;
+#pragma unroll
+                        for (int h = 0; h < 4; ++h)
+                            ((f32x4_t*)dst)[h] = f32x4_t{acc[i][j][4 * h], acc[i][j][4 * h + 1], acc[i][j][4 * h + 2], acc[i][j][4 * h + 3]};
+                    }
+                }
+            }
+        } else if (geglu) {
+            if constexpr (TN % 2 == 0) {
+#pragma unroll
+                for (int j = 0; j < TN; j += 2) {
+                    const int cv = n0 + (wn * TN + j) * 32 + lhalf * 16;           // value columns (packed order); gate = +32
+                    const int ocol = (n0 >> 1) + ((wn * TN + j) >> 1) * 32 + lhalf * 16;
+                    const bool cok = cv + 32 < p.N;
+                    float bv[16], bg[16];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        f32x4_t a = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
+                        if (p.bias && cok) { a = ((const f32x4_t*)(p.bias + cv))[h]; g = ((const f32x4_t*)(p.bias + cv + 32))[h]; }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { bv[4 * h + e] = a[e]; bg[4 * h + e] = g[e]; }
+                    }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int row = m0 + (wm * TM + i) * 32 + lrow;
+                        if (row < p.M && cok) {
+                            float v[16];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float a_ = acc[i][j][r] * p.alpha + bv[r], g_ = acc[i][j + 1][r] * p.alpha + bg[r];
+                                v[r] = a_ * gelu_erf(g_);
+                            }
+                            if (resp) {
+                                const u32x4_t* rp = (const u32x4_t*)(resp + (long long)row * p.ldr + ocol);
+#pragma unroll
+                                for (int h = 0; h < OV; ++h) {
+                                    float f[16 / OV];
+                                    unpack16<TO>(rp[h], f);
+#pragma unroll
+                                    for (int e = 0; e < 16 / OV; ++e) v[h * (16 / OV) + e] += f[e];
+                                }
+                            }
+                            store16(outp + (long long)row * p.ldo + ocol, v);
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + (wn * TN + j) * 32 + lhalf * 16;
+                const bool cok = col < p.N;
+                float cadd[16];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias && cok) a = ((const f32x4_t*)(p.bias + col))[h];
+                    if (rvu && cok) { const f32x4_t q = ((const f32x4_t*)(rvu + col))[h]; a[0] += q[0]; a[1] += q[1]; a[2] += q[2]; a[3] += q[3]; }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cadd[4 * h + e] = a[e];
+                }
+                // residual segments of the TM rows: issued together, ahead of use
+                u32x4_t rq[TM][OV];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = m0 + (wm * TM + i) * 32 + lrow;
+                    if (resp && row < p.M && cok) {
+                        const u32x4_t* rp = (const u32x4_t*)(resp + (long long)row * p.ldr + col);
+#pragma unroll
+                        for (int h = 0; h < OV; ++h) rq[i][h] = rp[h];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = m0 + (wm * TM + i) * 32 + lrow;
+                    if (row < p.M && cok) {
+                        float v[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float y = acc[i][j][r] * p.alpha + cadd[r];
+                            if (p.act == RF_ACT_SILU) y = silu_exact(y);
+                            else if (p.act == RF_ACT_QUICK_GELU) y = quick_gelu(y);
+                            else if (p.act == RF_ACT_GELU) y = gelu_erf(y);
+                            else if (p.act == RF_ACT_RELU) y = fmaxf(y, 0.0f);
+                            else if (p.act == RF_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
+                            v[r] = y;
+                        }
+                        if (resp) {
+#pragma unroll
+                            for (int h = 0; h < OV; ++h) {
+                                float f[16 / OV];
+                                unpack16<TO>(rq[i][h], f);
+#pragma unroll
+                                for (int e = 0; e < 16 / OV; ++e) v[h * (16 / OV) + e] += f[e];
+                            }
+                        }
+                        store16(outp + (long long)row * p.ldo + col, v);
+                    }
+                }
+            }
+        }
+        return;
     }
 
     // ---- epilogue: accumulators -> LDS (fp32 [ER][BN]) -> coalesced 16-byte row segments, in NCH row chunks
@@ -842,17 +999,24 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
                      "rf_conv_gemm: GroupNorm consumer %d: cpg=%d slot=%d needs %d slots of %d", c, p.gn_cpg[c], p.gn_slot[c], need, p.gn_nch[c]);
     }
     dim3 grid(p.tiles_m * p.tiles_n, d->batch, p.splitk), block(WM * WN * 64);
-#define RF_LAUNCH_VARIANT(CONV_, GLDS_)                                                                                         \
+    // direct epilogue: whenever the operands allow it and nothing needs the staged tile (fused GroupNorm statistics, a per-row
+    // timestep vector that changes inside the tile); RF_EPI2=0 switches it off (A/B runs)
+    static const int epi2_env = [] { const char* e = getenv("RF_EPI2"); return e ? atoi(e) : 1; }();
+    const bool epi2 = epi2_env && p.glds && p.epi2_ok && (p.gn_rows == 0 || p.splitk > 1) &&
+                      (!p.rowvec || p.splitk > 1 || p.rows_per_sample % BM == 0) && (d->act != RF_ACT_GEGLU || TN % 2 == 0);
+#define RF_LAUNCH_VARIANT(CONV_, GLDS_, EPI_)                                                                                   \
     {                                                                                                                            \
-        auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NST : 2)>;                                                          \
+        auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NST : 2), EPI_>;                                                    \
         static bool attr = false;                                                                                                \
         if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; } \
         hipLaunchKernelGGL(k, grid, block, smem, st, p);                                                                         \
     }
-    if (conv && p.glds) RF_LAUNCH_VARIANT(true, true)
-    else if (conv) RF_LAUNCH_VARIANT(true, false)
-    else if (p.glds) RF_LAUNCH_VARIANT(false, true)
-    else RF_LAUNCH_VARIANT(false, false)
+    if (conv && p.glds && epi2) RF_LAUNCH_VARIANT(true, true, 1)
+    else if (conv && p.glds) RF_LAUNCH_VARIANT(true, true, 0)
+    else if (conv) RF_LAUNCH_VARIANT(true, false, 0)
+    else if (p.glds && epi2) RF_LAUNCH_VARIANT(false, true, 1)
+    else if (p.glds) RF_LAUNCH_VARIANT(false, true, 0)
+    else RF_LAUNCH_VARIANT(false, false, 0)
 #undef RF_LAUNCH_VARIANT
     if (p.splitk > 1)
         hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3((p.N + SK_COLS - 1) / SK_COLS, (p.M + SK_ROWS - 1) / SK_ROWS), dim3(256), 0, st, p);
@@ -957,6 +1121,14 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
         if (d->bias) ok = ok && ((uintptr_t)d->bias % 16 == 0);
         if (d->rowvec) ok = ok && (d->ldv % 4 == 0) && ((uintptr_t)d->rowvec % 16 == 0);
         p.vec_ok = ok ? 1 : 0;
+        // direct epilogue: 16 contiguous output columns per lane, written / read as 16-byte vectors
+        const int es_o = d->out_dtype == RF_F32 ? 4 : 2;
+        bool e2 = (d->N % 16 == 0) && (nout % 16 == 0) && ((long long)d->ldo * es_o % 16 == 0) && ((uintptr_t)d->out % 16 == 0) &&
+                  ((long long)d->sO * es_o % 16 == 0) && d->act != RF_ACT_PRELU;
+        if (d->residual) e2 = e2 && ((long long)d->ldr * es_o % 16 == 0) && ((uintptr_t)d->residual % 16 == 0) && ((long long)d->sR * es_o % 16 == 0);
+        if (d->bias) e2 = e2 && ((uintptr_t)d->bias % 16 == 0);
+        if (d->rowvec) e2 = e2 && (d->ldv % 4 == 0) && ((uintptr_t)d->rowvec % 16 == 0);
+        p.epi2_ok = e2 ? 1 : 0;
     }
     {
         // direct-to-LDS main loop needs one source, 31-bit byte offsets ...
