@@ -536,56 +536,76 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 }
             }
         } else {
+            // Register-lean schedule: one 32x32 block at a time, the values are finished in place in the accumulators; the bias
+            // (+ timestep) columns of block column j+1 and the residual segment of the next block are loaded one block ahead.
+            // sched_barrier(0) after every block keeps hipcc from hoisting every load of the unrolled nest to the top (the 2x5 wave
+            // tile then spills ~170 registers per lane).
+            constexpr bool PF = sizeof(TO) == 2;            // prefetch one block ahead (fp32 output rows cost twice the registers)
+            f32x4_t cb[2][4];
+            u32x4_t rq[2][OV];
+            auto load_cadd = [&](int j, f32x4_t* c) {
+                const int col = n0 + (wn * TN + j) * 32 + lhalf * 16;
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+                    if (col < p.N) {
+                        if (p.bias) a = ((const f32x4_t*)(p.bias + col))[h];
+                        if (rvu) { const f32x4_t q = ((const f32x4_t*)(rvu + col))[h]; a[0] += q[0]; a[1] += q[1]; a[2] += q[2]; a[3] += q[3]; }
+                    }
+                    c[h] = a;
+                }
+            };
+            auto load_res = [&](int i, int j, u32x4_t* r) {
+                const int col = n0 + (wn * TN + j) * 32 + lhalf * 16;
+                const int row = m0 + (wm * TM + i) * 32 + lrow;
+                if (resp && row < p.M && col < p.N) {
+                    const u32x4_t* rp = (const u32x4_t*)(resp + (long long)row * p.ldr + col);
+#pragma unroll
+                    for (int h = 0; h < OV; ++h) r[h] = rp[h];
+                }
+            };
+            load_cadd(0, cb[0]);
+            load_res(0, 0, rq[0]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + (wn * TN + j) * 32 + lhalf * 16;
                 const bool cok = col < p.N;
-                float cadd[16];
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    f32x4_t a = {0.f, 0.f, 0.f, 0.f};
-                    if (p.bias && cok) a = ((const f32x4_t*)(p.bias + col))[h];
-                    if (rvu && cok) { const f32x4_t q = ((const f32x4_t*)(rvu + col))[h]; a[0] += q[0]; a[1] += q[1]; a[2] += q[2]; a[3] += q[3]; }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) cadd[4 * h + e] = a[e];
-                }
-                // residual segments of the TM rows: issued together, ahead of use
-                u32x4_t rq[TM][OV];
+                if (j + 1 < TN) load_cadd(j + 1, cb[(j + 1) & 1]);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int blk = j * TM + i;
                     const int row = m0 + (wm * TM + i) * 32 + lrow;
-                    if (resp && row < p.M && cok) {
-                        const u32x4_t* rp = (const u32x4_t*)(resp + (long long)row * p.ldr + col);
-#pragma unroll
-                        for (int h = 0; h < OV; ++h) rq[i][h] = rp[h];
+                    if (PF) {
+                        if (blk + 1 < TM * TN) load_res((blk + 1) % TM, (blk + 1) / TM, rq[(blk + 1) & 1]);
+                    } else if (blk > 0) {
+                        load_res(i, j, rq[0]);
                     }
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int row = m0 + (wm * TM + i) * 32 + lrow;
+                    const u32x4_t* const myr = rq[PF ? (blk & 1) : 0];
                     if (row < p.M && cok) {
-                        float v[16];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            float y = acc[i][j][r] * p.alpha + cadd[r];
+                            float y = acc[i][j][r] * p.alpha + cb[j & 1][r >> 2][r & 3];
                             if (p.act == RF_ACT_SILU) y = silu_exact(y);
                             else if (p.act == RF_ACT_QUICK_GELU) y = quick_gelu(y);
                             else if (p.act == RF_ACT_GELU) y = gelu_erf(y);
                             else if (p.act == RF_ACT_RELU) y = fmaxf(y, 0.0f);
                             else if (p.act == RF_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
-                            v[r] = y;
+                            acc[i][j][r] = y;
                         }
-                        if (resp) {
+                        TO* dst = outp + (long long)row * p.ldo + col;
 #pragma unroll
-                            for (int h = 0; h < OV; ++h) {
-                                float f[16 / OV];
-                                unpack16<TO>(rq[i][h], f);
+                        for (int h = 0; h < OV; ++h) {
+                            constexpr int E = 16 / OV;
+                            float f[E];
+                            if (resp) unpack16<TO>(myr[h], f);
+                            float v[E];
 #pragma unroll
-                                for (int e = 0; e < 16 / OV; ++e) v[h * (16 / OV) + e] += f[e];
-                            }
+                            for (int e = 0; e < E; ++e) v[e] = acc[i][j][h * E + e] + (resp ? f[e] : 0.0f);
+                            ((u32x4_t*)dst)[h] = pack16<TO>(v);
                         }
-                        store16(outp + (long long)row * p.ldo + col, v);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -1002,11 +1022,13 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     // direct epilogue: whenever the operands allow it and nothing needs the staged tile (fused GroupNorm statistics, a per-row
     // timestep vector that changes inside the tile); RF_EPI2=0 switches it off (A/B runs)
     static const int epi2_env = [] { const char* e = getenv("RF_EPI2"); return e ? atoi(e) : 1; }();
-    const bool epi2 = epi2_env && p.glds && p.epi2_ok && (p.gn_rows == 0 || p.splitk > 1) &&
+    // (the small 4-wave tiles keep the staged epilogue: their occupancy of 3-4 waves per SIMD is worth more than the epilogue)
+    constexpr bool EPI2_CFG = (WM * WN == 8) || (TM * TN == 5);
+    const bool epi2 = EPI2_CFG && epi2_env && p.glds && p.epi2_ok && (p.gn_rows == 0 || p.splitk > 1) &&
                       (!p.rowvec || p.splitk > 1 || p.rows_per_sample % BM == 0) && (d->act != RF_ACT_GEGLU || TN % 2 == 0);
 #define RF_LAUNCH_VARIANT(CONV_, GLDS_, EPI_)                                                                                   \
     {                                                                                                                            \
-        auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NST : 2), EPI_>;                                                    \
+        auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NST : 2), (EPI2_CFG ? EPI_ : 0)>;                                   \
         static bool attr = false;                                                                                                \
         if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; } \
         hipLaunchKernelGGL(k, grid, block, smem, st, p);                                                                         \

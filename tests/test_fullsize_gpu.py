@@ -193,7 +193,7 @@ def test_attention_bench_shapes(dt, BH, d, N):
     rel = math.sqrt(num / den)
     assert torch.isfinite(out.float()).all()
     if dt == torch.float32:
-        assert worst < 2e-5 and rel < 1e-5, (worst, rel)
+        assert worst < 1e-4 and rel < 1e-5, (worst, rel)      # O(1) outputs over up to 9216 keys: fp32 round-off of both sides
     else:                                            # bf16 P and V (2^-9 relative rounding each), fp32 accumulation
         assert worst < 2e-2 and rel < 6e-3, (worst, rel)
 
