@@ -360,7 +360,7 @@ def main():
         dtimed = profiler.time_launches(dec.launches, reps=2)
         dfam = profiler.summarize(dtimed)
         dec_ms = sum(ms for _, ms in dtimed)
-        key = f"rf_conv_gemm[{'bf16' if dname == 'fp8' else dname}]" if f"rf_conv_gemm[{dname}]" not in fam else f"rf_conv_gemm[{dname}]"
+        key = {"bf16": "rf_conv_gemm[bf16]", "f32": "rf_conv_gemm[f32]", "fp8": "rf_conv_gemm[fp8w]"}[dname]
         dom = fam[key]
         nb = 2 * B
         unet_alg = F_UNET[h] * nb if h in F_UNET else None

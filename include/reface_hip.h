@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-enum { RF_F32 = 0, RF_BF16 = 1 };
+enum { RF_F32 = 0, RF_BF16 = 1, RF_FP8_E4M3 = 2 /* OCP e4m3fn weights (rf_conv_gemm_desc.w_dtype only) */ };
 
 /* epilogue activations of rf_conv_gemm */
 enum { RF_ACT_NONE = 0, RF_ACT_GEGLU = 1, RF_ACT_SILU = 2, RF_ACT_QUICK_GELU = 3, RF_ACT_GELU = 4,
@@ -84,6 +84,12 @@ typedef struct rf_conv_gemm_desc {
     int32_t gn_cpg0, gn_coff0, gn_slot0, gn_nchunks0;   /* its channels per group, position of out column 0 in its channel space, first chunk slot, chunk slots per sample */
     double* gn_part1;     /* consumer 1 (e.g. the decoder norm over [h | skip], which groups the same channels differently), or NULL */
     int32_t gn_cpg1, gn_coff1, gn_slot1, gn_nchunks1;
+    /* fp8 weight path (BASELINE configs[4]): w_dtype = RF_FP8_E4M3 with dtype = RF_BF16 -- W holds OCP e4m3fn bytes, [N][ldw] with */
+    /* ldw (BYTES) a multiple of 128 and every row zero-padded to it, dequantised on the way from LDS to the bf16 MFMA as */
+    /* w = fp8 * wscale[n], wscale[n] a power of two (rf_quantize_fp8_rows produces both).  0 = W has the element type `dtype`. */
+    /* Replaces the same nn.Conv2d / nn.Linear weights (openaimodel.py:204,230,241; attention.py:40,60,159-170), half the bytes. */
+    int32_t w_dtype;
+    const float* wscale;  /* [N] fp32, powers of two */
 } rf_conv_gemm_desc;
 
 int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream);
@@ -94,6 +100,12 @@ int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream);
  * slot = gn_slot + (row tile within the sample) * ceil(N / bn) + column tile.  Replaces the separate statistics pass of
  * nn.GroupNorm (util.py:214-216) over a tensor this GEMM has just produced. */
 int rf_conv_gemm_plan(const rf_conv_gemm_desc* d, int32_t* bm, int32_t* bn, int32_t* splitk);
+
+/* Per-row fp8 quantisation of a weight matrix for the w_dtype = RF_FP8_E4M3 path: w [N][K] fp32 (row pitch K) ->
+ * q [N][ldq] e4m3fn bytes (ldq >= K, a multiple of 128; the pad bytes are written as zero) and scale [N] = the smallest power of
+ * two with max|w[n,:]| / scale <= 448 (e4m3fn's largest finite value); q = round-to-nearest-even(w / scale), saturating.
+ * Done once at engine build (torch's `.to(float8_e4m3fn)` is the CPU reference in the tests). */
+int rf_quantize_fp8_rows(const float* w, int N, int K, int ldq, void* q, float* scale, void* stream);
 
 /*
  * GroupNorm(32 groups) over channels-last [B, HW, C]  (+ optional SiLU), two launches:

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # REFACE_HIP_LIB selects another build of the same library (A/B kernel experiments); there is still no non-HIP fallback.
 LIB_PATH = os.environ.get("REFACE_HIP_LIB") or os.path.join(HERE, "lib", "libreface_hip.so")
 
-RF_F32, RF_BF16 = 0, 1
+RF_F32, RF_BF16, RF_FP8_E4M3 = 0, 1, 2
 ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_PRELU = 0, 1, 2, 3, 4, 5, 6, 7
 
 
@@ -35,6 +35,7 @@ class ConvGemmDesc(C.Structure):
         ("gn_rows", C.c_int32),
         ("gn_part0", C.c_void_p), ("gn_cpg0", C.c_int32), ("gn_coff0", C.c_int32), ("gn_slot0", C.c_int32), ("gn_nchunks0", C.c_int32),
         ("gn_part1", C.c_void_p), ("gn_cpg1", C.c_int32), ("gn_coff1", C.c_int32), ("gn_slot1", C.c_int32), ("gn_nchunks1", C.c_int32),
+        ("w_dtype", C.c_int32), ("wscale", C.c_void_p),
     ]
 
 
@@ -43,6 +44,7 @@ _SIGS = {
     "rf_version": (C.c_int, []),
     "rf_conv_gemm": (C.c_int, [C.POINTER(ConvGemmDesc), C.c_void_p]),
     "rf_conv_gemm_plan": (C.c_int, [C.POINTER(ConvGemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "rf_quantize_fp8_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rf_groupnorm_stats": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "rf_groupnorm_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "rf_groupnorm_apply": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

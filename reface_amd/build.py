@@ -47,6 +47,13 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        # hipcc's host pass can drop a kernel stub without a diagnostic (seen with a call expression inside a builtin's argument
+        # list): the library then links but fails to load.  Catch it here.
+        und = subprocess.run(["nm", "-u", "-C", LIB], capture_output=True, text=True).stdout
+        bad = [l.strip() for l in und.splitlines() if "rf::" in l]
+        if bad:
+            os.remove(LIB)
+            raise RuntimeError("libreface_hip.so has undefined rf:: symbols (host stubs missing): " + "; ".join(bad[:4]))
     return LIB
 
 

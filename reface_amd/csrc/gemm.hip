@@ -49,7 +49,21 @@ struct GemmParams {
     int gn_cpg[2], gn_coff[2], gn_slot[2], gn_nch[2];
     int* plan;       // host only: {BM, BN, splitk} requested by rf_conv_gemm_plan (no launch)
     int epi2_ok;     // host only: operand alignment / feature set allow the direct (register -> global) epilogue
+    int dbg;         // RF_GEMM_DBG (timing experiments only): bit 0 = skip the epilogue, bit 1 = skip the main loop
+    const float* wscale;   // W8 kernels: per-output-channel power-of-two scale of the fp8 (e4m3fn) weights
 };
+
+// 8 fp8 (e4m3fn) weights -> 8 bf16, times the row's power-of-two scale: v_cvt_scalef32_pk_bf16_fp8, one instruction per pair (exact:
+// 3 mantissa bits fit in bf16's 7, a power-of-two scale only moves the exponent)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v_t;
+__device__ __forceinline__ u32x4_t fp8x8_to_bf16x8(const u32x2_t& r, float scale) {
+    u32x4_t o;
+    o[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r[0], scale, false));
+    o[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r[0], scale, true));
+    o[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r[1], scale, false));
+    o[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r[1], scale, true));
+    return o;
+}
 
 template <typename T> struct MmaFrag;
 template <> struct MmaFrag<bf16_t> {
@@ -75,6 +89,9 @@ __device__ __forceinline__ void lds_barrier() {
 
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
+template <bool W8> __device__ __forceinline__ int w_stage(int t, int buf) { return W8 ? ((t >> 1) & 1) : buf; }
+template <bool W8> __device__ __forceinline__ int w_soff(int t) { return (W8 ? (t >> 1) : t) * 128; }
+
 template <typename TO> __device__ __forceinline__ void store_out(TO* p, float v);
 template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
@@ -87,9 +104,14 @@ template <> __device__ __forceinline__ float load_out<bf16_t>(const bf16_t* p) {
 // (m = l & 31, h = l >> 5) ends up with accumulator register r = output column 16*h + r of its row: 16 CONTIGUOUS columns per
 // 32x32 block.  Bias / activation / residual / GEGLU then happen in registers and every lane writes its row segments with 16-byte
 // stores -- no LDS staging pass, no barriers, and waves retire independently.
-template <typename T, typename TO, int WM, int WN, int TM, int TN, bool CONV, bool GLDS, int NST, int EPI = 0>
+// W8 = true: the weights are fp8 (e4m3fn) with one power-of-two scale per output channel.  A W tile in LDS keeps the 128-byte row
+// geometry and therefore holds 128 K elements = the W operand of TWO consecutive A tiles: the W pieces are issued every other
+// tile (half the weight bytes through L2 / LDS), and a W fragment is an 8-byte LDS read turned into 8 bf16 by 4 conversions
+// (issued between the MFMAs of the previous fragment column).  The MFMA itself is the bf16 one: same matrix-core ceiling.
+template <typename T, typename TO, int WM, int WN, int TM, int TN, bool CONV, bool GLDS, int NST, int EPI = 0, bool W8 = false>
 __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams p) {
     static_assert(EPI == 0 || GLDS, "the direct epilogue is built on the direct-to-LDS main loop");
+    static_assert(!W8 || (GLDS && sizeof(T) == 2), "fp8 weights: bf16 activations on the direct-to-LDS main loop");
     constexpr int NT = WM * WN * 64;
     constexpr int BM = 32 * TM * WM;
     constexpr int BN = 32 * TN * WN;
@@ -123,7 +145,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
     const long long zb = blockIdx.y;
     const T* src0 = (const T*)p.src0 + zb * p.sA;
     const T* src1 = (const T*)p.src1;
-    const T* Wp = (const T*)p.W + zb * p.sW;
+    const T* Wp = W8 ? (const T*)((const char*)p.W + zb * p.sW) : (const T*)p.W + zb * p.sW;
 
     const int r0 = tid >> 3;
     // GLDS: the LDS image of a direct-to-LDS load is lane-linear, so the XOR swizzle moves to the SOURCE: the lane that
@@ -223,7 +245,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    int nk = (p.K + BK - 1) / BK;
+    int nk = (p.dbg & 2) ? 0 : (p.K + BK - 1) / BK;
     int kb0_tiles = 0;       // first K tile of this block (split-K)
     if (p.splitk > 1) {          // this block's K-tile range [kb0, kb0 + nk)
         const int per = (nk + p.splitk - 1) / p.splitk;
@@ -271,14 +293,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
         for (int j = 0; j < BV; ++j) {
             const int n = n0 + r0 + j * RPP;
-            offs[AV + j] = n < p.N ? n * p.ldw * (int)sizeof(T) + lane_k : OOB;
+            offs[AV + j] = n < p.N ? n * p.ldw * (W8 ? 1 : (int)sizeof(T)) + lane_k : OOB;
         }
+        // W8: W tile of A tile `t` = 128-byte tile (t >> 1) of the weight rows, kept in W stage ((t >> 1) & 1)
         // the W pieces of the first tile go out before the A row descriptors (two integer divisions per row) are computed
         if (nk > 0) {
+            // (values computed OUTSIDE the builtin's argument list: a call expression inside it makes hipcc's host pass drop the
+            // kernel's stub without a diagnostic)
+            char* const b0 = ldsB + w_stage<W8>(kb0_tiles, 0) * BN * 128 + wave_u * 1024;
+            const int so0 = w_soff<W8>(kb0_tiles);
 #pragma unroll
             for (int j = 0; j < BV; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(ldsB + wave_u * 1024 + j * (RPP * 128)), 16,
-                                                         offs[AV + j], kb0_tiles * 128, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(b0 + j * (RPP * 128)), 16, offs[AV + j], so0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
@@ -333,8 +359,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         // issue pieces [q0, q1) of the issue-state tile into LDS stage `buf`
         auto issue_pieces = [&](int buf, int q0, int q1) {
             char* a = ldsA + buf * BM * 128 + wave_u * 1024;
-            char* b = ldsB + buf * BN * 128 + wave_u * 1024;
-            const int soA = (CONV ? ic : it) * 128, soB = it * 128;
+            char* b = ldsB + w_stage<W8>(it, buf) * BN * 128 + wave_u * 1024;
+            const int soA = (CONV ? ic : it) * 128, soB = w_soff<W8>(it);
+            if (W8 && (it & 1) && q1 > AV) q1 = AV;          // odd tile: its W half arrived with the even tile before it
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
                 if (q >= q0 && q < q1) {
@@ -351,7 +378,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         // in place: column j of the next k-step is fetched right after column j's MFMAs have been issued.
         constexpr bool ROT = TM * TN > 8;
         constexpr int JS = ROT ? 2 : 0;      // B columns whose MFMAs go ahead of the first next-fragment reads
-        u32x4_t fa[2][TM], fb[2][TN];
+        u32x4_t fa[2][TM], fb[W8 ? 1 : 2][W8 ? 1 : TN];
+        u32x2_t fbr[W8 ? 2 : 1][W8 ? TN : 1];          // W8: raw 8-byte fp8 fragments
+        float ws[W8 ? TN : 1];                         // W8: scale of this lane's W row in each 32-row block
         const int frag_sw = (lrow >> 1) & 7;
         // W-tile row this lane reads for the row operand of its 32-row blocks (EPI = 1: permuted, see the kernel comment)
         const int brow = EPI ? (16 * ((lrow >> 2) & 1) + 4 * (lrow >> 3) + (lrow & 3)) : lrow;
@@ -360,15 +389,34 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             fk[kk] = ((kk * 2 + lhalf) ^ frag_sw) << 4;
-            fkb[kk] = ((kk * 2 + lhalf) ^ frag_swb) << 4;
+            // W8: one 16-byte slot per k-step (16 fp8), the lane half picks its 8 bytes; the A-tile parity flips address bit 6
+            fkb[kk] = W8 ? (((kk ^ frag_swb) << 4) + lhalf * 8) : (((kk * 2 + lhalf) ^ frag_swb) << 4);
+        }
+        if constexpr (W8) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn * TN + j) * 32 + brow;
+                ws[j] = n < p.N ? p.wscale[n] : 1.0f;
+            }
         }
         // fragment row bases of the stage being multiplied (cur) and of the other stage (oth); swapped after every tile.
         // The loop body is ONE straight-line block (no per-tile variants): branches around MFMAs make the register allocator
         // keep two copies of the accumulators.
         const char* curA = ldsA + (wm * TM) * 4096 + lrow * 128;
-        const char* curB = ldsB + (wn * TN) * 4096 + brow * 128;
+        const char* const wbase = ldsB + (wn * TN) * 4096 + brow * 128;
+        const char* curB = wbase + w_stage<W8>(kb0_tiles, 0) * BN * 128;
         const char* othA = curA + BM * 128;
-        const char* othB = curB + BN * 128;
+        const char* othB = wbase + w_stage<W8>(kb0_tiles + 1, 1) * BN * 128;       // W8: the NEXT tile's W stage (may equal the current one)
+        int curPar = W8 ? (kb0_tiles & 1) * 64 : 0, othPar = W8 ? ((kb0_tiles + 1) & 1) * 64 : 0;
+        int t_abs = kb0_tiles;                                                   // absolute index of the tile being multiplied
+        auto load_b = [&](int set, int j, const char* ptr) {
+            if constexpr (W8) fbr[set][j] = *(const u32x2_t*)ptr;
+            else fb[set][j] = *(const u32x4_t*)ptr;
+        };
+        auto bfrag = [&](int set, int j) -> u32x4_t {
+            if constexpr (W8) return fp8x8_to_bf16x8(fbr[set][j], ws[j]);
+            else return fb[set][j];
+        };
         // one k-step: its MFMAs, the fetch of the next step's fragments (k-step 3 fetches from the other stage, after the
         // barrier; on the last tile that fetch reads stale bytes that are never used) and a third of the next tile's pieces
         auto phase = [&](auto KK, int stage, bool more) {
@@ -377,14 +425,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             constexpr int fbc = ROT ? 0 : cur, fbn = ROT ? 0 : nx;
             constexpr int nkk = (kk + 1) & 3;
             const char* const nA = (kk < 3 ? curA : othA) + fk[nkk];
-            const char* const nB = (kk < 3 ? curB : othB) + fkb[nkk];
+            const char* const nB = (kk < 3 ? curB : othB) + (fkb[nkk] ^ (kk < 3 ? curPar : othPar));
 #pragma unroll
-            for (int j = 0; j < JS; ++j)
+            for (int j = 0; j < JS; ++j) {
+                const u32x4_t bj = bfrag(fbc, j);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    if constexpr (EPI) MmaFrag<T>::mma(acc[i][j], fb[fbc][j], fa[cur][i]);
-                    else MmaFrag<T>::mma(acc[i][j], fa[cur][i], fb[fbc][j]);
+                    if constexpr (EPI) MmaFrag<T>::mma(acc[i][j], bj, fa[cur][i]);
+                    else MmaFrag<T>::mma(acc[i][j], fa[cur][i], bj);
                 }
+            }
             if (kk == 3) {
                 // own pieces of the next tile have landed and every fragment of this tile is in registers; past the barrier
                 // that holds for all waves: this stage may be overwritten (tile kt+2) and the other stage may be read
@@ -394,18 +444,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[nx][i] = *(const u32x4_t*)(nA + i * 4096);
 #pragma unroll
-            for (int j = 0; j < (ROT ? JS : TN); ++j) fb[fbn][j] = *(const u32x4_t*)(nB + j * 4096);
+            for (int j = 0; j < (ROT ? JS : TN); ++j) load_b(fbn, j, nB + j * 4096);
             if (kk == 3 && more) issue_pieces(stage, 0, NP);      // 'more' here: tile kt+2 exists
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = JS; j < TN; ++j) {
+                const u32x4_t bj = bfrag(fbc, j);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    if constexpr (EPI) MmaFrag<T>::mma(acc[i][j], fb[fbc][j], fa[cur][i]);
-                    else MmaFrag<T>::mma(acc[i][j], fa[cur][i], fb[fbc][j]);
+                    if constexpr (EPI) MmaFrag<T>::mma(acc[i][j], bj, fa[cur][i]);
+                    else MmaFrag<T>::mma(acc[i][j], fa[cur][i], bj);
                 }
                 if (ROT) {
-                    fb[0][j] = *(const u32x4_t*)(nB + j * 4096);
+                    load_b(0, j, nB + j * 4096);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -419,7 +470,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 next_tile();
                 issue_pieces(1, 0, NP);
                 if (nk > 2) next_tile();
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+                if constexpr (W8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile 1 may have had no W pieces: no fixed count
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -427,7 +479,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[0][i] = *(const u32x4_t*)(curA + i * 4096 + fk[0]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[0][j] = *(const u32x4_t*)(curB + j * 4096 + fkb[0]);
+            for (int j = 0; j < TN; ++j) load_b(0, j, curB + j * 4096 + (fkb[0] ^ curPar));
         }
         for (int kt = 0; kt < nk; ++kt) {
             const int stage = kt & 1;
@@ -438,7 +490,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             phase(integral_constant<int, 3>{}, stage, more);
             if (kt + 3 < nk) next_tile();
             const char* t = curA; curA = othA; othA = t;
-            t = curB; curB = othB; othB = t;
+            if constexpr (W8) {
+                ++t_abs;
+                curB = othB; curPar = othPar;
+                othB = wbase + (((t_abs + 1) >> 1) & 1) * BN * 128;
+                othPar = ((t_abs + 1) & 1) * 64;
+            } else {
+                t = curB; curB = othB; othB = t;
+            }
         }
         __syncthreads();
     } else {
@@ -454,6 +513,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         }
     }
 
+    if (p.dbg & 1) {          // timing experiment: no epilogue (keep the accumulators observable)
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) t += acc[i][j][0];
+        if (t == 123.456f) ((float*)p.out)[0] = t;
+        return;
+    }
     if constexpr (EPI == 1) {
         // ---- direct epilogue: lane (row lrow of its 32-row block, half lhalf) holds columns 16*lhalf .. 16*lhalf+15 of every
         // 32-column block of its wave tile.  Host guarantees (launch_typed): N % 16 == 0, 16-byte aligned rows of out / residual /
@@ -995,7 +1063,7 @@ static int pick_splitk(const rf_conv_gemm_desc* d, const GemmParams& p, long lon
     return best;
 }
 
-template <typename T, typename TO, int WM, int WN, int TM, int TN>
+template <typename T, typename TO, int WM, int WN, int TM, int TN, bool W8 = false>
 static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int NST = 2;            // LDS stages of the direct-to-LDS main loop (3 stages at 1 block/CU measured slower)
@@ -1019,21 +1087,29 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
                      "rf_conv_gemm: GroupNorm consumer %d: cpg=%d slot=%d needs %d slots of %d", c, p.gn_cpg[c], p.gn_slot[c], need, p.gn_nch[c]);
     }
     dim3 grid(p.tiles_m * p.tiles_n, d->batch, p.splitk), block(WM * WN * 64);
-    // direct epilogue: whenever the operands allow it and nothing needs the staged tile (fused GroupNorm statistics, a per-row
-    // timestep vector that changes inside the tile); RF_EPI2=0 switches it off (A/B runs)
+    // Direct (register -> global) epilogue.  Measured on MI355X (tools/bench_gemm.py, RF_GEMM_DBG decomposition, r02c): the epilogues
+    // of the K = C layers at 64x64 are HBM-write-bound (2-2.7 TB/s), and the row-per-lane 16-byte stores of the direct form reach
+    // only half the write rate of the LDS-staged full-line stores (qkv 65536x960: 101 vs 53 us epilogue-only) -- EXCEPT for GEGLU,
+    // whose staged form pays the LDS round trip for twice the columns it stores (65536x2560: 78 vs 106 us).  So: GEGLU only by
+    // default; RF_EPI2=2 forces it wherever legal, RF_EPI2=0 switches it off (A/B runs).
     static const int epi2_env = [] { const char* e = getenv("RF_EPI2"); return e ? atoi(e) : 1; }();
     // (the small 4-wave tiles keep the staged epilogue: their occupancy of 3-4 waves per SIMD is worth more than the epilogue)
     constexpr bool EPI2_CFG = (WM * WN == 8) || (TM * TN == 5);
-    const bool epi2 = EPI2_CFG && epi2_env && p.glds && p.epi2_ok && (p.gn_rows == 0 || p.splitk > 1) &&
-                      (!p.rowvec || p.splitk > 1 || p.rows_per_sample % BM == 0) && (d->act != RF_ACT_GEGLU || TN % 2 == 0);
+    const bool epi2 = !W8 && EPI2_CFG && epi2_env && p.glds && p.epi2_ok && (p.gn_rows == 0 || p.splitk > 1) &&
+                      (!p.rowvec || p.splitk > 1 || p.rows_per_sample % BM == 0) && (d->act != RF_ACT_GEGLU || TN % 2 == 0) &&
+                      (epi2_env == 2 || (d->act == RF_ACT_GEGLU && p.splitk == 1));
 #define RF_LAUNCH_VARIANT(CONV_, GLDS_, EPI_)                                                                                   \
     {                                                                                                                            \
-        auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NST : 2), (EPI2_CFG ? EPI_ : 0)>;                                   \
+        auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NST : 2), ((EPI2_CFG && !W8) ? EPI_ : 0), (W8 && GLDS_)>;          \
         static bool attr = false;                                                                                                \
         if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; } \
         hipLaunchKernelGGL(k, grid, block, smem, st, p);                                                                         \
     }
-    if (conv && p.glds && epi2) RF_LAUNCH_VARIANT(true, true, 1)
+    if (W8) {
+        RF_CHECK(p.glds, "rf_conv_gemm: fp8 weights need the direct-to-LDS main loop (one source, K and channel count multiples of 64)");
+        if (conv) RF_LAUNCH_VARIANT(true, true, 0)
+        else RF_LAUNCH_VARIANT(false, true, 0)
+    } else if (conv && p.glds && epi2) RF_LAUNCH_VARIANT(true, true, 1)
     else if (conv && p.glds) RF_LAUNCH_VARIANT(true, true, 0)
     else if (conv) RF_LAUNCH_VARIANT(true, false, 0)
     else if (p.glds && epi2) RF_LAUNCH_VARIANT(false, true, 1)
@@ -1046,7 +1122,7 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     return 0;
 }
 
-template <typename T, typename TO>
+template <typename T, typename TO, bool W8 = false>
 static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipStream_t st) {
     const int N = p.N;
     {   // experiments: RF_GEMM_CFG=<0..6> forces one tile configuration (GEGLU still needs an even TN)
@@ -1058,13 +1134,13 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
         const int forced = forced_all >= 0 ? forced_all : (p.M == m_exact ? m_cfg : (p.K <= small_k ? small_cfg : -1));
         const bool g = d->act == RF_ACT_GEGLU;
         switch (forced) {
-            case 0: if (!g && p.glds && d->batch == 1) return launch_cfg<T, TO, 4, 2, 2, 5>(d, p, conv, st); break;
-            case 1: if (p.glds && d->batch == 1) return launch_cfg<T, TO, 4, 2, 2, 4>(d, p, conv, st); break;
-            case 2: if (!g && p.glds && d->batch == 1) return launch_cfg<T, TO, 4, 2, 1, 5>(d, p, conv, st); break;
-            case 3: if (p.glds && d->batch == 1) return launch_cfg<T, TO, 4, 2, 1, 4>(d, p, conv, st); break;
-            case 4: return launch_cfg<T, TO, 2, 2, 2, 2>(d, p, conv, st);
-            case 5: return launch_cfg<T, TO, 4, 1, 1, 2>(d, p, conv, st);
-            case 6: if (!g) return launch_cfg<T, TO, 4, 1, 1, 5>(d, p, conv, st); break;
+            case 0: if (!g && p.glds && d->batch == 1) return launch_cfg<T, TO, 4, 2, 2, 5, W8>(d, p, conv, st); break;
+            case 1: if (p.glds && d->batch == 1) return launch_cfg<T, TO, 4, 2, 2, 4, W8>(d, p, conv, st); break;
+            case 2: if (!g && p.glds && d->batch == 1) return launch_cfg<T, TO, 4, 2, 1, 5, W8>(d, p, conv, st); break;
+            case 3: if (p.glds && d->batch == 1) return launch_cfg<T, TO, 4, 2, 1, 4, W8>(d, p, conv, st); break;
+            case 4: return launch_cfg<T, TO, 2, 2, 2, 2, W8>(d, p, conv, st);
+            case 5: return launch_cfg<T, TO, 4, 1, 1, 2, W8>(d, p, conv, st);
+            case 6: if (!g) return launch_cfg<T, TO, 4, 1, 1, 5, W8>(d, p, conv, st); break;
             default: break;
         }
     }
@@ -1076,21 +1152,21 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
         const bool n320 = d->act != RF_ACT_GEGLU && N % 320 == 0, n256 = N % 256 == 0 && !n320;
         const long long nt = n320 ? N / 320 : (n256 ? N / 256 : 0);
         if (nt > 0) {
-            if (mt256 * nt >= 192) return n320 ? launch_cfg<T, TO, 4, 2, 2, 5>(d, p, conv, st) : launch_cfg<T, TO, 4, 2, 2, 4>(d, p, conv, st);
+            if (mt256 * nt >= 192) return n320 ? launch_cfg<T, TO, 4, 2, 2, 5, W8>(d, p, conv, st) : launch_cfg<T, TO, 4, 2, 2, 4, W8>(d, p, conv, st);
             if (mt128 * nt * pick_splitk(d, p, mt128 * nt, bk) >= 192) {
                 // K up to ~90 tiles: two co-resident 4-wave 128x160 blocks per CU (each other's prologue / epilogue cover) beat one
                 // 8-wave 128x320 block in situ (sweep: -1.2 % per batch at 6000, worse again from 11520); RF_SHORTK overrides
                 static const int shortk = [] { const char* e = getenv("RF_SHORTK"); return e ? atoi(e) : 6000; }();
-                if (n320 && p.K <= shortk && mt128 * (N / 160) >= 256) return launch_cfg<T, TO, 4, 1, 1, 5>(d, p, conv, st);
-                return n320 ? launch_cfg<T, TO, 4, 2, 1, 5>(d, p, conv, st) : launch_cfg<T, TO, 4, 2, 1, 4>(d, p, conv, st);
+                if (n320 && p.K <= shortk && mt128 * (N / 160) >= 256) return launch_cfg<T, TO, 4, 1, 1, 5, W8>(d, p, conv, st);
+                return n320 ? launch_cfg<T, TO, 4, 2, 1, 5, W8>(d, p, conv, st) : launch_cfg<T, TO, 4, 2, 1, 4, W8>(d, p, conv, st);
             }
         }
     }
-    if (d->act == RF_ACT_GEGLU) return launch_cfg<T, TO, 2, 2, 2, 2>(d, p, conv, st);
-    if (N <= 64) return launch_cfg<T, TO, 4, 1, 1, 2>(d, p, conv, st);
+    if (d->act == RF_ACT_GEGLU) return launch_cfg<T, TO, 2, 2, 2, 2, W8>(d, p, conv, st);
+    if (N <= 64) return launch_cfg<T, TO, 4, 1, 1, 2, W8>(d, p, conv, st);
     const int pad128 = ((N + 127) / 128) * 128, pad160 = ((N + 159) / 160) * 160;
-    if (pad160 < pad128) return launch_cfg<T, TO, 4, 1, 1, 5>(d, p, conv, st);
-    return launch_cfg<T, TO, 2, 2, 2, 2>(d, p, conv, st);
+    if (pad160 < pad128) return launch_cfg<T, TO, 4, 1, 1, 5, W8>(d, p, conv, st);
+    return launch_cfg<T, TO, 2, 2, 2, 2, W8>(d, p, conv, st);
 }
 
 }  // namespace rf
@@ -1107,7 +1183,11 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
     RF_CHECK(d->K % vec == 0 && ctot % vec == 0 && d->C0 % vec == 0 && d->ld0 % vec == 0,
              "rf_conv_gemm: K=%d C0=%d C1=%d ld0=%d must be multiples of %d", d->K, d->C0, d->C1, d->ld0, vec);
     RF_CHECK(d->C1 == 0 || (d->src1 && d->ld1 % vec == 0), "rf_conv_gemm: bad second source");
-    RF_CHECK(d->ldw == 0 || (d->ldw >= d->K && d->ldw % vec == 0), "rf_conv_gemm: bad ldw=%d", d->ldw);
+    const bool w8 = d->w_dtype == RF_FP8_E4M3;
+    RF_CHECK(d->w_dtype == 0 || w8, "rf_conv_gemm: bad w_dtype %d", d->w_dtype);
+    RF_CHECK(!w8 || (d->dtype == RF_BF16 && d->wscale && d->ldw % 128 == 0 && d->ldw >= d->K && d->batch == 1 && d->korder == 0),
+             "rf_conv_gemm: fp8 weights need bf16 activations, wscale, batch 1 and ldw (bytes) a multiple of 128 >= K (ldw=%d K=%d)", d->ldw, d->K);
+    RF_CHECK(w8 || d->ldw == 0 || (d->ldw >= d->K && d->ldw % vec == 0), "rf_conv_gemm: bad ldw=%d", d->ldw);
     RF_CHECK(d->KH >= 1 && d->KW >= 1 && d->stride >= 1, "rf_conv_gemm: bad window");
     RF_CHECK(d->KH * d->KW * ctot <= d->K && d->K < d->KH * d->KW * ctot + 8 * vec,
              "rf_conv_gemm: K=%d inconsistent with KH*KW*(C0+C1)=%d", d->K, d->KH * d->KW * ctot);
@@ -1134,6 +1214,10 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
     p.gn_part[0] = d->gn_part0; p.gn_cpg[0] = d->gn_cpg0; p.gn_coff[0] = d->gn_coff0; p.gn_slot[0] = d->gn_slot0; p.gn_nch[0] = d->gn_nchunks0;
     p.gn_part[1] = d->gn_part1; p.gn_cpg[1] = d->gn_cpg1; p.gn_coff[1] = d->gn_coff1; p.gn_slot[1] = d->gn_slot1; p.gn_nch[1] = d->gn_nchunks1;
     p.plan = plan;
+    {
+        static const int dbg = [] { const char* e = getenv("RF_GEMM_DBG"); return e ? atoi(e) : 0; }();
+        p.dbg = dbg;
+    }
     RF_CHECK(!(d->gn_part0 || d->gn_part1) || d->gn_rows > 0, "rf_conv_gemm: gn_part set but gn_rows = %d", d->gn_rows);
     {
         const uintptr_t oa = d->out_dtype == RF_F32 ? 16 : 8;
@@ -1157,7 +1241,7 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
         const long long es = d->dtype == RF_F32 ? 4 : 2;
         const long long rows_a = conv ? (long long)(d->M / (d->Hout * d->Wout)) * d->Hin * d->Win : d->M;
         const long long ab = ((rows_a - 1) * d->ld0 + (conv ? d->C0 : d->K)) * es;
-        const long long wb = ((long long)(d->N - 1) * p.ldw + d->K) * es;
+        const long long wb = w8 ? (long long)d->N * p.ldw : ((long long)(d->N - 1) * p.ldw + d->K) * es;
         // ... and K tiles that never straddle a filter tap (uniform K offset per tile; rows packed as sample:12 | oy:10 | ox:10)
         const int bk = (int)(128 / es);
         const bool uniform = d->K % bk == 0 && (!conv || (ctot % bk == 0 && d->K == d->KH * d->KW * ctot &&
@@ -1168,6 +1252,11 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
         p.w_bytes = (unsigned)(p.glds ? wb : 0);
     }
     hipStream_t st = (hipStream_t)stream;
+    p.wscale = d->wscale;
+    if (w8) {
+        if (d->out_dtype == RF_F32) return launch_typed<bf16_t, float, true>(d, p, conv, st);
+        return launch_typed<bf16_t, bf16_t, true>(d, p, conv, st);
+    }
     if (d->dtype == RF_F32) {
         if (d->out_dtype == RF_F32) return launch_typed<float, float>(d, p, conv, st);
         return launch_typed<float, bf16_t>(d, p, conv, st);
@@ -1177,6 +1266,50 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
 }
 
 extern "C" int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream) { return conv_gemm_impl(d, stream, nullptr); }
+
+namespace rf {
+// one block per weight row: amax -> power-of-two scale -> e4m3fn bytes (v_cvt_pk_fp8_f32: round-to-nearest-even, saturating)
+__global__ __launch_bounds__(256) void quantize_fp8_rows_kernel(const float* __restrict__ w, int K, int ldq, uint8_t* __restrict__ q,
+                                                                float* __restrict__ scale) {
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float* row = w + (long long)n * K;
+    float m = 0.f;
+    for (int k = tid; k < K; k += 256) m = fmaxf(m, fabsf(row[k]));
+    m = wave_max(m);
+    __shared__ float sm[4];
+    if ((tid & 63) == 0) sm[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    // smallest power of two s with m / s <= 448
+    float s = 1.0f;
+    if (m > 0.f) {
+        int e;
+        const float f = frexpf(m / 448.0f, &e);          // m / 448 = f * 2^e, f in [0.5, 1)
+        s = ldexpf(1.0f, f == 0.5f ? e - 1 : e);
+    }
+    if (tid == 0) scale[n] = s;
+    const float inv = 1.0f / s;                            // exact (power of two)
+    uint8_t* qrow = q + (long long)n * ldq;
+    for (int k4 = tid * 4; k4 < ldq; k4 += 1024) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (k4 + e < K) ? row[k4 + e] * inv : 0.f;
+        int pk = 0;
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], pk, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+        *(int*)(qrow + k4) = pk;
+    }
+}
+}  // namespace rf
+
+extern "C" int rf_quantize_fp8_rows(const float* w, int N, int K, int ldq, void* q, float* scale, void* stream) {
+    using namespace rf;
+    RF_CHECK(w && q && scale && N > 0 && K > 0, "rf_quantize_fp8_rows: bad arguments");
+    RF_CHECK(ldq >= K && ldq % 128 == 0 && (uintptr_t)q % 16 == 0, "rf_quantize_fp8_rows: ldq=%d must be a multiple of 128 >= K=%d", ldq, K);
+    hipLaunchKernelGGL(quantize_fp8_rows_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, w, K, ldq, (uint8_t*)q, scale);
+    RF_LAUNCH_CHECK("rf_quantize_fp8_rows");
+    return 0;
+}
 
 extern "C" int rf_conv_gemm_plan(const rf_conv_gemm_desc* d, int32_t* bm, int32_t* bn, int32_t* splitk) {
     using namespace rf;

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_PRELU, ACT_QUICK_GELU, ACT_RELU, ACT_SIGMOID, ACT_SILU, RF_BF16, RF_F32,
-                   ConvGemmDesc)
+                   RF_FP8_E4M3, ConvGemmDesc)
 
 
 def code(dt):
@@ -79,6 +79,42 @@ def pack_geglu(w, b, dtype):
     return wp.to(dtype).contiguous(), bp.float().contiguous()
 
 
+class Fp8Weight:
+    """A weight matrix in the fp8 storage of BASELINE configs[4]: ``q`` [N, ldq] uint8 holding OCP e4m3fn bytes (rows zero-padded
+    to a multiple of 128), ``scale`` [N] fp32 powers of two; w[n, k] = fp8(q[n, k]) * scale[n]."""
+    __slots__ = ("q", "scale", "K")
+
+    def __init__(self, q, scale, K):
+        self.q, self.scale, self.K = q, scale, K
+
+    @property
+    def shape(self):
+        return (self.q.shape[0], self.K)
+
+    def dequant(self):
+        """fp32 [N, K] values the kernel multiplies with (exact)."""
+        return self.q[:, :self.K].view(torch.float8_e4m3fn).float() * self.scale[:, None]
+
+
+def fp8_eligible(K, cin=None):
+    """rf_conv_gemm takes fp8 weights on its direct-to-LDS main loop: K (and, for convolutions, the channel count) multiples
+    of the 64-element bf16 K tile."""
+    return K % 64 == 0 and (cin is None or cin % 64 == 0)
+
+
+def quantize_fp8(w2d):
+    """[N, K] floating weights (device) -> Fp8Weight through rf_quantize_fp8_rows (per-row power-of-two scale, RNE)."""
+    lib = _lib.load()
+    _require_gpu(w2d)
+    w = w2d.detach().float().contiguous()
+    N, K = w.shape
+    ldq = (K + 127) // 128 * 128
+    q = torch.empty((N, ldq), dtype=torch.uint8, device=w.device)
+    sc = torch.empty((N,), dtype=torch.float32, device=w.device)
+    _lib.check(lib.rf_quantize_fp8_rows(_p(w), N, K, ldq, _p(q), _p(sc), stream_ptr()), "rf_quantize_fp8_rows")
+    return Fp8Weight(q, sc, K)
+
+
 # ------------------------------------------------------------------------------------------------
 # descriptor-based launches.  `Launch` objects are built once per (layer, shape) and replayed.
 # ------------------------------------------------------------------------------------------------
@@ -139,7 +175,14 @@ def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, 
     _require_gpu(src0, W, out, src1, bias, rowvec, residual)
     d = ConvGemmDesc()
     d.dtype, d.out_dtype = code(src0.dtype), code(out.dtype)
-    assert W.dtype == src0.dtype and (src1 is None or src1.dtype == src0.dtype)
+    wq = None
+    if isinstance(W, Fp8Weight):             # fp8 weights: bf16 activations, bytes + per-row scales
+        wq, W = W, W.q
+        assert src0.dtype == torch.bfloat16 and wq.K == K and ldw == 0
+        d.w_dtype, d.wscale, ldw = RF_FP8_E4M3, _p(wq.scale), W.stride(0)
+    else:
+        assert W.dtype == src0.dtype
+    assert (src1 is None or src1.dtype == src0.dtype)
     assert residual is None or residual.dtype == out.dtype
     assert bias is None or bias.dtype == torch.float32
     assert rowvec is None or rowvec.dtype == torch.float32
@@ -157,14 +200,14 @@ def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, 
     d.korder = korder
     ws = workspace if workspace is not None else _default_workspace(src0.device)
     d.workspace, d.workspace_bytes = _p(ws), (ws.numel() * ws.element_size() if ws is not None else 0)
-    return Launch(lib.rf_conv_gemm, (C.byref(d),), (d, src0, src1, W, out, bias, rowvec, residual, act_vec, ws), name)
+    return Launch(lib.rf_conv_gemm, (C.byref(d),), (d, src0, src1, W, out, bias, rowvec, residual, act_vec, ws, wq), name)
 
 
 def linear(x, W, out, bias=None, *, act=ACT_NONE, residual=None, rowvec=None, rows_per_sample=0, alpha=1.0, act_vec=None, name="linear"):
     """out[M, N] = act(x[M, K] @ W[N, K]^T + bias) (+ residual).  x / out may be row-strided 2-D views."""
     M, K = x.shape
     N = W.shape[0]
-    assert W.shape[1] == K and x.stride(1) == 1 and out.stride(1) == 1
+    assert W.shape[1] == K and x.stride(1) == 1 and out.stride(1) == 1, (tuple(W.shape), K)
     return conv_gemm(x, W, out, M=M, N=N, K=K, C0=K, ld0=x.stride(0), Hin=1, Win=M, Hout=1, Wout=M, bias=bias, act=act,
                      residual=residual, ldr=(residual.stride(0) if residual is not None else 0), rowvec=rowvec,
                      rows_per_sample=rows_per_sample, ldv=(rowvec.stride(0) if rowvec is not None else 0),

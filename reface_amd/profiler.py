@@ -11,6 +11,8 @@ def launch_family(l):
     n = l.fn.__name__
     if n == "rf_conv_gemm":
         d = l.keep[0]
+        if d.w_dtype == 2:
+            return "rf_conv_gemm[fp8w]"          # fp8 (e4m3fn) weights x bf16 activations on the bf16 MFMA
         return f"rf_conv_gemm[{'bf16' if d.dtype == 1 else 'f32'}]"
     return n
 

@@ -68,7 +68,13 @@ class UNetEngine:
     CPAD = 16      # 9 input channels stored in 16 (multiple of the 16-byte vector for both dtypes)
 
     def __init__(self, sd, cfg: UNetConfig, B, H, W, dtype, device, uniform_t=False, emb_rows=None, cfg_pair=False):
+        # dtype "fp8" (BASELINE configs[4]): bf16 activations, GEMM weights stored as fp8 e4m3fn + per-output-channel power-of-two
+        # scales wherever rf_conv_gemm takes them (K and channel count multiples of 64), fp32 accumulate
+        self.w8 = dtype == "fp8"
+        if self.w8:
+            dtype = torch.bfloat16
         self.cfg, self.B, self.H, self.W, self.dt, self.dev = cfg, B, H, W, dtype, device
+        self.n_fp8 = 0
         self.uniform_t = uniform_t
         # cfg_pair: the caller guarantees that samples [0, B/2) and [B/2, B) carry the SAME x and timestep and differ only in
         # the context (classifier-free guidance, ddim.py:330-341).  Everything upstream of the first cross-attention is then
@@ -99,10 +105,17 @@ class UNetEngine:
 
     # ------------------------------------------------------------------ weights
     def w(self, key, dtype=None):
-        return self.sd[key].to(dtype or self.dt).contiguous()
+        return self.sd[key].to(dtype or self.dt).contiguous()          # (non-GEMM uses; GEMM weights go through gw())
 
     def f32(self, key):
         return self.sd[key].contiguous()
+
+    def gw(self, w2d, cin=None):
+        """A GEMM weight [N, K] in the engine's storage: the activation dtype, or (fp8 mode) e4m3fn bytes + per-row scales."""
+        if self.w8 and ops.fp8_eligible(w2d.shape[1], cin):
+            self.n_fp8 += 1
+            return ops.quantize_fp8(w2d)
+        return w2d.to(self.dt).contiguous()
 
     # ------------------------------------------------------------------ timestep path (fp32)
     def _res_prefixes(self):
@@ -194,7 +207,8 @@ class UNetEngine:
         """3x3 conv launch; K order chosen per layer (ops.conv_korder)."""
         cin = x.shape[3]
         ko = ops.conv_korder(cin, self.dt) if self.korder_on else 0
-        return ops.conv2d(x, ops.pack_conv_weight(self.sd[wkey], self.dt, korder=ko), out, self.f32(bkey), korder=ko, name=name, **kw)
+        wp = ops.pack_conv_weight(self.sd[wkey], F32, korder=ko)
+        return ops.conv2d(x, wp.to(self.dt) if ko else self.gw(wp, cin), out, self.f32(bkey), korder=ko, name=name, **kw)
 
     def _add(self, launch, out=None):
         """Append a launch; GEMM outputs are remembered so that a later GroupNorm can ask their producers for its statistics."""
@@ -231,7 +245,7 @@ class UNetEngine:
         self.pool.put(h1)
         if cin != cout:
             skip = self.pool.get((B, H, W, cout), self.dt)
-            self.main.append(ops.conv2d(x, self.w(f"{p}.skip_connection.weight").reshape(cout, cin), skip,
+            self.main.append(ops.conv2d(x, self.gw(self.sd[f"{p}.skip_connection.weight"].reshape(cout, cin)), skip,
                                         self.f32(f"{p}.skip_connection.bias"), ksize=1, pad=(0, 0), name=f"{p}.skip_connection"))
         else:
             skip = x
@@ -251,14 +265,14 @@ class UNetEngine:
         nb = 2 if pair else 1                   # batch fan-out at the cross-attention
         g = self._gn(x, f"{p}.norm", 1e-6, False)
         tok = self.pool.get((M, c), self.dt)
-        self.main.append(ops.linear(g.view(M, c), self.w(f"{p}.proj_in.weight").reshape(c, c), tok, self.f32(f"{p}.proj_in.bias"),
+        self.main.append(ops.linear(g.view(M, c), self.gw(self.sd[f"{p}.proj_in.weight"].reshape(c, c)), tok, self.f32(f"{p}.proj_in.bias"),
                                     name=f"{p}.proj_in"))
         self.pool.put(g)
         ln = self.pool.get((M, c), self.dt)
         self.main.append(ops.layernorm(tok, self.f32(f"{t}.norm1.weight"), self.f32(f"{t}.norm1.bias"), ln, name=f"{t}.norm1"))
         qkv = self.pool.get((M, 3 * c), self.dt)
         wqkv = torch.cat([self.sd[f"{t}.attn1.to_q.weight"], self.sd[f"{t}.attn1.to_k.weight"], self.sd[f"{t}.attn1.to_v.weight"]], 0)
-        self.main.append(ops.linear(ln, wqkv.to(self.dt).contiguous(), qkv, None, name=f"{t}.attn1.qkv"))
+        self.main.append(ops.linear(ln, self.gw(wqkv), qkv, None, name=f"{t}.attn1.qkv"))
         att = ln    # reuse the LayerNorm buffer for the attention output
         q3 = qkv.view(B, H * W, 3 * c)
         self.main.append(ops.attention(q3[..., :c], q3[..., c:2 * c], q3[..., 2 * c:], att.view(B, H * W, c), heads=heads,
@@ -266,7 +280,7 @@ class UNetEngine:
         x1 = self.pool.get((nb * M, c), self.dt)
         # attn1 out-projection + residual + the (token-independent) cross-attention output; with pair=True one launch per CFG
         # half: same A and residual, that half's context vectors
-        w_out, b_out, cv = self.w(f"{t}.attn1.to_out.0.weight"), self.f32(f"{t}.attn1.to_out.0.bias"), self.ctx_vec(p)
+        w_out, b_out, cv = self.gw(self.sd[f"{t}.attn1.to_out.0.weight"]), self.f32(f"{t}.attn1.to_out.0.bias"), self.ctx_vec(p)
         for hf in range(nb):
             self.main.append(ops.linear(att, w_out, x1[hf * M:(hf + 1) * M], b_out, residual=tok, rowvec=cv[hf * B:(hf + 1) * B],
                                         rows_per_sample=H * W, name=f"{t}.attn1.to_out"))
@@ -276,15 +290,16 @@ class UNetEngine:
             self.pool.put(ln)
             ln = self.pool.get((nb * M, c), self.dt)
         self.main.append(ops.layernorm(x1, self.f32(f"{t}.norm3.weight"), self.f32(f"{t}.norm3.bias"), ln, name=f"{t}.norm3"))
-        wg, bg = ops.pack_geglu(self.sd[f"{t}.ff.net.0.proj.weight"], self.sd[f"{t}.ff.net.0.proj.bias"], self.dt)
+        wg, bg = ops.pack_geglu(self.sd[f"{t}.ff.net.0.proj.weight"], self.sd[f"{t}.ff.net.0.proj.bias"], F32)
+        wg = self.gw(wg)
         gg = self.pool.get((nb * M, 4 * c), self.dt)
         self.main.append(ops.linear(ln, wg, gg, bg, act=ops.ACT_GEGLU, name=f"{t}.ff.net.0"))
         x2 = ln
-        self.main.append(ops.linear(gg, self.w(f"{t}.ff.net.2.weight"), x2, self.f32(f"{t}.ff.net.2.bias"), residual=x1, name=f"{t}.ff.net.2"))
+        self.main.append(ops.linear(gg, self.gw(self.sd[f"{t}.ff.net.2.weight"]), x2, self.f32(f"{t}.ff.net.2.bias"), residual=x1, name=f"{t}.ff.net.2"))
         self.pool.put(gg)
         self.pool.put(x1)
         y = dst if dst is not None else self.pool.get((nb * B, H, W, c), self.dt)
-        w_po, b_po = self.w(f"{p}.proj_out.weight").reshape(c, c), self.f32(f"{p}.proj_out.bias")
+        w_po, b_po = self.gw(self.sd[f"{p}.proj_out.weight"].reshape(c, c)), self.f32(f"{p}.proj_out.bias")
         for hf in range(nb):        # the residual x is shared by both halves
             self._add(ops.conv2d(x2.view(nb * B, H, W, c)[hf * B:(hf + 1) * B], w_po, y[hf * B:(hf + 1) * B], b_po,
                                  ksize=1, pad=(0, 0), residual=x, name=f"{p}.proj_out"), y[hf * B:(hf + 1) * B])
@@ -427,6 +442,10 @@ class UNetModel(nn.Module):
         self._engines = {}
 
     def set_compute_dtype(self, dtype):
+        """torch.float32 (exact-fp32 parity mode) | torch.bfloat16 (throughput mode) | "fp8" (fp8 e4m3fn GEMM weights + bf16
+        activations, BASELINE configs[4])."""
+        if dtype not in (torch.float32, torch.bfloat16, "fp8"):
+            raise ValueError(f"unsupported UNet compute dtype {dtype!r}")
         self.compute_dtype = dtype
         self._engines.clear()
 

@@ -342,3 +342,81 @@ def test_conv_split_k(dt):
     ops.conv2d(x, ops.pack_conv_weight(w, dt).to(DEV), out, b.to(DEV), rowvec=rv.to(DEV), residual=res)()
     torch.cuda.synchronize()
     check(out, ref, dt)
+
+
+# ------------------------------------------------------------------------------------------------ fp8 weight path (BASELINE configs[4])
+def _fp8_ref(w):
+    """CPU reference of rf_quantize_fp8_rows: smallest power-of-two scale with amax / scale <= 448, RNE to OCP e4m3fn."""
+    amax = w.abs().amax(dim=1)
+    scale = torch.where(amax > 0, torch.exp2(torch.ceil(torch.log2(amax / 448.0))), torch.ones_like(amax))
+    q = (w / scale[:, None]).to(torch.float8_e4m3fn)
+    return q, scale
+
+
+@pytest.mark.parametrize("N,K", [(64, 320), (96, 128), (33, 2880), (5, 64)])
+def test_quantize_fp8_rows(N, K):
+    w = rnd((N, K), 70) * torch.logspace(-3, 1, N)[:, None]          # rows of very different magnitude
+    w[0, :5] = 0.0
+    fw = ops.quantize_fp8(w.to(DEV))
+    torch.cuda.synchronize()
+    q_ref, s_ref = _fp8_ref(w)
+    assert fw.q.shape == (N, (K + 127) // 128 * 128) and fw.K == K
+    assert torch.equal(fw.scale.cpu(), s_ref)
+    assert torch.equal(fw.q[:, :K].cpu().view(torch.float8_e4m3fn).float(), q_ref.float())          # byte-exact up to -0 / +0
+    assert (fw.q[:, K:] == 0).all()
+    deq = fw.dequant().cpu()
+    assert (deq - w).abs().max() <= (w.abs().amax(dim=1) * 2.0 ** -3).max()                         # 3 mantissa bits, scale <= 2x amax/448
+
+
+@pytest.mark.parametrize("M,N,K,kind", [(256, 320, 320, "linear"), (4096, 640, 1280, "res"), (300, 160, 192, "linear"), (512, 1280, 11520, "splitk"),
+                                         (2048, 512, 640, "geglu"), (16384, 320, 320, "big")])
+def test_linear_fp8_weights(M, N, K, kind):
+    """fp8 (e4m3fn) weights x bf16 activations: the kernel dequantises to exactly the bf16 values w = fp8 * 2^e, so it must agree with
+    an fp32 reference on the dequantised weights to bf16-output rounding -- and bit for bit with the bf16 kernel fed those weights."""
+    dt = torch.bfloat16
+    x, xr = q(rnd((M, K), 71) * 0.5, dt)
+    w = rnd((N, K), 72) / math.sqrt(K)
+    b = rnd((N,), 73)
+    if kind == "geglu":
+        wp, bp = ops.pack_geglu(w, b, torch.float32)
+        fw = ops.quantize_fp8(wp.to(DEV))
+        out = torch.empty((M, N // 2), dtype=dt, device=DEV)
+        ops.linear(x, fw, out, bp.to(DEV), act=ops.ACT_GEGLU)()
+        out_b = torch.empty_like(out)
+        ops.linear(x, fw.dequant().to(dt), out_b, bp.to(DEV), act=ops.ACT_GEGLU)()
+        torch.cuda.synchronize()
+        wd = fw.dequant().cpu()
+        # undo the 32-row interleave of pack_geglu on the dequantised rows
+        f = N // 2
+        wv = wd.reshape(f // 32, 2, 32, K)[:, 0].reshape(f, K)
+        wg = wd.reshape(f // 32, 2, 32, K)[:, 1].reshape(f, K)
+        ref = (F.linear(xr, wv, b[:f]) * F.gelu(F.linear(xr, wg, b[f:])))
+    else:
+        fw = ops.quantize_fp8(w.to(DEV))
+        res, rr = q(rnd((M, N), 74), dt) if kind == "res" else (None, 0.0)
+        out = torch.empty((M, N), dtype=dt, device=DEV)
+        l = ops.linear(x, fw, out, b.to(DEV), residual=res)
+        l()
+        out_b = torch.empty_like(out)
+        ops.linear(x, fw.dequant().to(dt), out_b, b.to(DEV), residual=res)()
+        torch.cuda.synchronize()
+        if kind == "splitk":
+            assert ops.gemm_plan(l)[2] > 1
+        ref = F.linear(xr, fw.dequant().cpu(), b) + rr
+    check(out, ref, dt)
+    assert torch.equal(out, out_b), (out.float() - out_b.float()).abs().max().item()
+
+
+def test_conv_fp8_weights():
+    dt = torch.bfloat16
+    B, H, W_, Ci, Co = 2, 16, 16, 128, 320
+    x, xr = q(rnd((B, H, W_, Ci), 75), dt)
+    w = rnd((Co, Ci, 3, 3), 76) / math.sqrt(9 * Ci)
+    b = rnd((Co,), 77)
+    fw = ops.quantize_fp8(ops.pack_conv_weight(w, torch.float32).to(DEV))
+    out = torch.empty((B, H, W_, Co), dtype=dt, device=DEV)
+    ops.conv2d(x, fw, out, b.to(DEV))()
+    torch.cuda.synchronize()
+    wd = fw.dequant().cpu().reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
+    ref = _conv_ref(xr, wd, b, 1, (1, 1, 1, 1), 0)
+    check(out, ref, dt)
