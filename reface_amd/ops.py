@@ -172,7 +172,7 @@ def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, 
               act=ACT_NONE, ldo=None, alpha=1.0, batch=1, sA=0, sW=0, sO=0, sR=0, ldw=0, act_vec=None, korder=0, workspace=None, name="rf_conv_gemm"):
     """Prepare an rf_conv_gemm launch (see include/reface_hip.h)."""
     lib = _lib.load()
-    _require_gpu(src0, W, out, src1, bias, rowvec, residual)
+    _require_gpu(src0, W.q if isinstance(W, Fp8Weight) else W, out, src1, bias, rowvec, residual)
     d = ConvGemmDesc()
     d.dtype, d.out_dtype = code(src0.dtype), code(out.dtype)
     wq = None
