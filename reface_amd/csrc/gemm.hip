@@ -110,7 +110,8 @@ template <> __device__ __forceinline__ float load_out<bf16_t>(const bf16_t* p) {
 // (issued between the MFMAs of the previous fragment column).  The MFMA itself is the bf16 one: same matrix-core ceiling.
 template <typename T, typename TO, int WM, int WN, int TM, int TN, bool CONV, bool GLDS, int NST, int EPI = 0, bool W8 = false>
 __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams p) {
-    static_assert(EPI == 0 || GLDS, "the direct epilogue is built on the direct-to-LDS main loop");
+    static_assert(EPI == 0 || GLDS, "the direct / packed epilogues are built on the direct-to-LDS main loop");
+    static_assert(EPI != 2 || sizeof(TO) == 2, "the packed staged epilogue writes bf16");
     static_assert(!W8 || (GLDS && sizeof(T) == 2), "fp8 weights: bf16 activations on the direct-to-LDS main loop");
     constexpr int NT = WM * WN * 64;
     constexpr int BM = 32 * TM * WM;
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         float ws[W8 ? TN : 1];                         // W8: scale of this lane's W row in each 32-row block
         const int frag_sw = (lrow >> 1) & 7;
         // W-tile row this lane reads for the row operand of its 32-row blocks (EPI = 1: permuted, see the kernel comment)
-        const int brow = EPI ? (16 * ((lrow >> 2) & 1) + 4 * (lrow >> 3) + (lrow & 3)) : lrow;
+        const int brow = EPI == 1 ? (16 * ((lrow >> 2) & 1) + 4 * (lrow >> 3) + (lrow & 3)) : lrow;
         const int frag_swb = (brow >> 1) & 7;
         int fk[4], fkb[4];   // swizzled byte position of k-step kk inside a fragment row (A side, W side)
 #pragma unroll
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 const u32x4_t bj = bfrag(fbc, j);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    if constexpr (EPI) MmaFrag<T>::mma(acc[i][j], bj, fa[cur][i]);
+                    if constexpr (EPI == 1) MmaFrag<T>::mma(acc[i][j], bj, fa[cur][i]);
                     else MmaFrag<T>::mma(acc[i][j], fa[cur][i], bj);
                 }
             }
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 const u32x4_t bj = bfrag(fbc, j);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    if constexpr (EPI) MmaFrag<T>::mma(acc[i][j], bj, fa[cur][i]);
+                    if constexpr (EPI == 1) MmaFrag<T>::mma(acc[i][j], bj, fa[cur][i]);
                     else MmaFrag<T>::mma(acc[i][j], fa[cur][i], bj);
                 }
                 if (ROT) {
@@ -520,6 +521,153 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
             for (int j = 0; j < TN; ++j) t += acc[i][j][0];
         if (t == 123.456f) ((float*)p.out)[0] = t;
+        return;
+    }
+    if constexpr (EPI == 2) {
+        // ---- packed staged epilogue (bf16 output).  The chunked fp32 staging of the general path keeps 6 of 8 waves idle while two
+        // write 80 KB of LDS with 4-byte stores, four times per tile (15 us of a 256x320 tile's 27 us at K = 320, RF_GEMM_DBG
+        // decomposition r02c).  Here bias / timestep vector / activation / GEGLU happen in registers (a lane owns ONE column per
+        // 32-column block), neighbouring lanes exchange one value by DPP so that each holds a (col 2c, col 2c+1) bf16 pair of
+        // alternating rows, and ALL waves write the whole tile as bf16 [BM][BNo] in one pass (half the LDS bytes: a 256x320 tile is
+        // exactly the 160 KB of LDS).  One barrier later every thread streams 16-byte row segments: residual add (fp32),
+        // GroupNorm partial sums of the values as stored, 16-byte global stores.  Host guarantees: N % 16 == 0, 16-byte aligned
+        // rows, no split-K, no PReLU, per-tile uniform timestep vector.
+        bool geglu = false;
+        if constexpr (TN % 2 == 0) geglu = p.act == RF_ACT_GEGLU;
+        const int BNo = geglu ? BN / 2 : BN;                 // columns of the staged tile
+        char* const tile = smem;
+        TO* const outp = (TO*)p.out + zb * p.sO;
+        const TO* const resp = p.residual ? (const TO*)p.residual + zb * p.sR : nullptr;
+        const float* const rvu = p.rowvec ? p.rowvec + (long long)(m0 / p.rows_per_sample) * p.ldv : nullptr;
+        const int odd = lane & 1;
+        // phase 1: registers -> bf16 tile
+        auto stage_block = [&](const float* y, int rowb, int colb) {
+            // y[16]: this lane's column of a 32x32 block (rows (r&3) + 8*(r>>2) + 4*lhalf); rowb / colb: block origin in the tile
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float send = odd ? y[r] : y[r + 1];            // what the neighbour lane (col ^ 1) needs
+                const float keep = odd ? y[r + 1] : y[r];
+                const float got = as_f32((uint32_t)__builtin_amdgcn_mov_dpp((int)as_u32(send), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+                const uint32_t w = odd ? pack_bf2(got, keep) : pack_bf2(keep, got);       // (col 2c, col 2c+1)
+                const int row = rowb + (r & 3) + 8 * (r >> 2) + 4 * lhalf + odd;        // even lanes: row of r, odd lanes: row of r+1
+                *(uint32_t*)(tile + (row * BNo + colb + (lrow & ~1)) * 2) = w;
+            }
+        };
+        if (geglu) {
+            if constexpr (TN % 2 == 0) {
+#pragma unroll
+                for (int j = 0; j < TN; j += 2) {
+                    const int cv = n0 + (wn * TN + j) * 32 + lrow;
+                    const float bv = (p.bias && cv < p.N) ? p.bias[cv] : 0.f, bg = (p.bias && cv + 32 < p.N) ? p.bias[cv + 32] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        float y[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) y[r] = (acc[i][j][r] * p.alpha + bv) * gelu_erf(acc[i][j + 1][r] * p.alpha + bg);
+                        stage_block(y, (wm * TM + i) * 32, ((wn * TN + j) >> 1) * 32);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + (wn * TN + j) * 32 + lrow;
+                float cadd = 0.f;
+                if (col < p.N) {
+                    if (p.bias) cadd = p.bias[col];
+                    if (rvu) cadd += rvu[col];
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float y[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) y[r] = acc[i][j][r] * p.alpha + cadd;       // (host: act is NONE or GEGLU on this path --
+                                                                                            // an unrolled 5-way activation chain per value
+                                                                                            // is 24 k instructions, beyond the I-cache)
+                    stage_block(y, (wm * TM + i) * 32, (wn * TN + j) * 32);
+                }
+            }
+        }
+        lds_barrier();
+        // phase 2: thread -> one fixed 8-column segment, every EROWS-th row
+        const int VPR8 = BNo / 8;                        // 16-byte segments per row
+        const int EROWS = NT / VPR8;
+        const int cs = tid % VPR8, er = tid / VPR8;
+        const int ncol0 = geglu ? (n0 >> 1) : n0, Nout = geglu ? (p.N >> 1) : p.N;
+        const int cl = cs * 8, col = ncol0 + cl;
+        const bool t_on = er < EROWS && col < Nout;
+        const bool gn_on = p.gn_rows > 0;
+        float gsum[8], gsq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gsum[e] = gsq[e] = 0.f;
+        constexpr int U = 4;                              // rows of residual loads in flight
+        for (int rl0 = er; rl0 < BM; rl0 += U * EROWS) {
+            u32x4_t rq[U], sv[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rl = rl0 + u * EROWS, row = m0 + rl;
+                ok[u] = t_on && rl < BM && row < p.M;
+                if (ok[u]) {
+                    if (resp) rq[u] = *(const u32x4_t*)(resp + (long long)row * p.ldr + col);
+                    sv[u] = *(const u32x4_t*)(tile + (rl * BNo + cl) * 2);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
+                const int row = m0 + rl0 + u * EROWS;
+                u32x4_t w = sv[u];
+                if (resp) {
+                    float a[8], b[8];
+                    unpack16<bf16_t>(sv[u], a);
+                    unpack16<bf16_t>(rq[u], b);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] += b[e];
+                    w = pack16<bf16_t>(a);
+                }
+                if (gn_on) {
+                    float a[8];
+                    unpack16<bf16_t>(w, a);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { gsum[e] += a[e]; gsq[e] += a[e] * a[e]; }
+                }
+                if (p.dbg & 4) {          // experiment: two 8-byte stores instead of one 16-byte store
+                    u32x2_t* d2 = (u32x2_t*)(outp + (long long)row * p.ldo + col);
+                    d2[0] = u32x2_t{w[0], w[1]};
+                    d2[1] = u32x2_t{w[2], w[3]};
+                } else if (!(p.dbg & 8)) {
+                    *(u32x4_t*)(outp + (long long)row * p.ldo + col) = w;
+                }
+            }
+        }
+        if (gn_on) {
+            // column sums of the tile: [EROWS][BNo] per-thread partials -> 32 group sums per consumer -> one chunk slot (fp64)
+            lds_barrier();                                 // every thread is done with the staged tile
+            float* const csum = (float*)smem;              // [2][EROWS][BNo]
+            if (er < EROWS) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    csum[er * BNo + cl + e] = gsum[e];
+                    csum[(EROWS + er) * BNo + cl + e] = gsq[e];
+                }
+            }
+            lds_barrier();
+            if (tid < 64) {
+                const int c = tid >> 5, g = tid & 31;
+                if (p.gn_part[c]) {
+                    const int cpg = p.gn_cpg[c], base = p.gn_coff[c] + n0;            // consumer channel of local column 0
+                    const int lo = max(0, g * cpg - base), hi = min(min(BN, p.N - n0), (g + 1) * cpg - base);
+                    double sa = 0.0, sq = 0.0;
+                    for (int k = lo; k < hi; ++k)
+                        for (int r = 0; r < EROWS; ++r) { sa += (double)csum[r * BNo + k]; sq += (double)csum[(EROWS + r) * BNo + k]; }
+                    const int b = m0 / p.gn_rows, mt = (m0 - b * p.gn_rows) / BM;
+                    double* o = p.gn_part[c] + (((long long)b * p.gn_nch[c] + p.gn_slot[c] + mt * p.tiles_n + tile_n) * 32 + g) * 2;
+                    o[0] = sa;
+                    o[1] = sq;
+                }
+            }
+        }
         return;
     }
     if constexpr (EPI == 1) {
@@ -652,15 +800,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                     const u32x4_t* const myr = rq[PF ? (blk & 1) : 0];
                     if (row < p.M && cok) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            float y = acc[i][j][r] * p.alpha + cb[j & 1][r >> 2][r & 3];
-                            if (p.act == RF_ACT_SILU) y = silu_exact(y);
-                            else if (p.act == RF_ACT_QUICK_GELU) y = quick_gelu(y);
-                            else if (p.act == RF_ACT_GELU) y = gelu_erf(y);
-                            else if (p.act == RF_ACT_RELU) y = fmaxf(y, 0.0f);
-                            else if (p.act == RF_ACT_SIGMOID) y = 1.0f / (1.0f + expf(-y));
-                            acc[i][j][r] = y;
-                        }
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * p.alpha + cb[j & 1][r >> 2][r & 3];   // (act NONE here)
                         TO* dst = outp + (long long)row * p.ldo + col;
 #pragma unroll
                         for (int h = 0; h < OV; ++h) {
@@ -1087,34 +1227,46 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
                      "rf_conv_gemm: GroupNorm consumer %d: cpg=%d slot=%d needs %d slots of %d", c, p.gn_cpg[c], p.gn_slot[c], need, p.gn_nch[c]);
     }
     dim3 grid(p.tiles_m * p.tiles_n, d->batch, p.splitk), block(WM * WN * 64);
-    // Direct (register -> global) epilogue.  Measured on MI355X (tools/bench_gemm.py, RF_GEMM_DBG decomposition, r02c): the epilogues
-    // of the K = C layers at 64x64 are HBM-write-bound (2-2.7 TB/s), and the row-per-lane 16-byte stores of the direct form reach
-    // only half the write rate of the LDS-staged full-line stores (qkv 65536x960: 101 vs 53 us epilogue-only) -- EXCEPT for GEGLU,
-    // whose staged form pays the LDS round trip for twice the columns it stores (65536x2560: 78 vs 106 us).  So: GEGLU only by
-    // default; RF_EPI2=2 forces it wherever legal, RF_EPI2=0 switches it off (A/B runs).
-    static const int epi2_env = [] { const char* e = getenv("RF_EPI2"); return e ? atoi(e) : 1; }();
-    // (the small 4-wave tiles keep the staged epilogue: their occupancy of 3-4 waves per SIMD is worth more than the epilogue)
-    constexpr bool EPI2_CFG = (WM * WN == 8) || (TM * TN == 5);
-    const bool epi2 = !W8 && EPI2_CFG && epi2_env && p.glds && p.epi2_ok && (p.gn_rows == 0 || p.splitk > 1) &&
-                      (!p.rowvec || p.splitk > 1 || p.rows_per_sample % BM == 0) && (d->act != RF_ACT_GEGLU || TN % 2 == 0) &&
-                      (epi2_env == 2 || (d->act == RF_ACT_GEGLU && p.splitk == 1));
+    // Epilogue selection (RF_GEMM_DBG decomposition + tools/bench_gemm.py A/B, r02c: the chunked fp32 staging costs 47 us of the 84 us
+    // of the 65536x960x320 qkv GEMM).
+    //   EPI 1, direct register -> global row segments: no LDS pass, no barriers; fastest wherever nothing needs the tile as a whole
+    //          (qkv 86 -> 59 us, proj 33 -> 24, ff2 62 -> 52, GEGLU 196 -> 164).  8-wave tiles and the 128x160 tile.
+    //   EPI 2, bf16 tile staged in ONE pass by all waves (packed pairs): carries the fused GroupNorm statistics (bf16 output).
+    //   EPI 0, fp32 tile staged in row chunks: everything else (split-K partials, per-row timestep vectors, activations other than
+    //          GEGLU, fp32 output with statistics, unaligned shapes).
+    // RF_EPI=0 forces EPI 0, RF_EPI=1 / 2 allow only that fast form (A/B runs).
+    static const int epi_env = [] { const char* e = getenv("RF_EPI"); return e ? atoi(e) : -1; }();
+    constexpr bool PACKED_OK = sizeof(TO) == 2;
+    constexpr bool DIRECT_OK = (WM * WN == 8) || (TM * TN == 5);
+    const bool ep_common = p.glds && p.epi2_ok && p.splitk == 1 && (!p.rowvec || p.rows_per_sample % BM == 0) &&
+                           (d->act == RF_ACT_NONE || (d->act == RF_ACT_GEGLU && TN % 2 == 0));
+    const bool direct = DIRECT_OK && (epi_env < 0 || epi_env == 1) && ep_common && p.gn_rows == 0;
+    const bool packed = !direct && PACKED_OK && (epi_env < 0 || epi_env == 2) && ep_common;
+    constexpr int smem_pk = BM * BN * 2;
+    const int smem_l = (packed && smem_pk > smem) ? smem_pk : smem;
 #define RF_LAUNCH_VARIANT(CONV_, GLDS_, EPI_)                                                                                   \
     {                                                                                                                            \
-        auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NST : 2), ((EPI2_CFG && !W8) ? EPI_ : 0), (W8 && GLDS_)>;          \
+        constexpr int E_ = (EPI_ == 2 && PACKED_OK) ? 2 : ((EPI_ == 1 && DIRECT_OK) ? 1 : 0);                                   \
+        auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NST : 2), E_, (W8 && GLDS_)>;                   \
         static bool attr = false;                                                                                                \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; } \
-        hipLaunchKernelGGL(k, grid, block, smem, st, p);                                                                         \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem_pk > smem ? smem_pk : smem); attr = true; } \
+        hipLaunchKernelGGL(k, grid, block, smem_l, st, p);                                                                       \
     }
-    if (W8) {
-        RF_CHECK(p.glds, "rf_conv_gemm: fp8 weights need the direct-to-LDS main loop (one source, K and channel count multiples of 64)");
-        if (conv) RF_LAUNCH_VARIANT(true, true, 0)
+    const int esel = packed ? 2 : (direct ? 1 : 0);
+    if (W8) RF_CHECK(p.glds, "rf_conv_gemm: fp8 weights need the direct-to-LDS main loop (one source, K and channel count multiples of 64)");
+    if (conv && p.glds) {
+        if (esel == 2) RF_LAUNCH_VARIANT(true, true, 2)
+        else if (esel == 1) RF_LAUNCH_VARIANT(true, true, 1)
+        else RF_LAUNCH_VARIANT(true, true, 0)
+    } else if (conv) {
+        RF_LAUNCH_VARIANT(true, false, 0)
+    } else if (p.glds) {
+        if (esel == 2) RF_LAUNCH_VARIANT(false, true, 2)
+        else if (esel == 1) RF_LAUNCH_VARIANT(false, true, 1)
         else RF_LAUNCH_VARIANT(false, true, 0)
-    } else if (conv && p.glds && epi2) RF_LAUNCH_VARIANT(true, true, 1)
-    else if (conv && p.glds) RF_LAUNCH_VARIANT(true, true, 0)
-    else if (conv) RF_LAUNCH_VARIANT(true, false, 0)
-    else if (p.glds && epi2) RF_LAUNCH_VARIANT(false, true, 1)
-    else if (p.glds) RF_LAUNCH_VARIANT(false, true, 0)
-    else RF_LAUNCH_VARIANT(false, false, 0)
+    } else {
+        RF_LAUNCH_VARIANT(false, false, 0)
+    }
 #undef RF_LAUNCH_VARIANT
     if (p.splitk > 1)
         hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3((p.N + SK_COLS - 1) / SK_COLS, (p.M + SK_ROWS - 1) / SK_ROWS), dim3(256), 0, st, p);
