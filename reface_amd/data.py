@@ -136,6 +136,50 @@ class FFdataset(FFHQdataset):
         super().__init__(state=state, dataset_dir=dataset_dir, first_target=first_target, first_source=first_source, n_targets=n_targets, **kw)
 
 
+class VideoDataset(Dataset):
+    """Targets of the selected-swap / one-image / video callers (ldm/data/video_swap_dataset.py:86-295): ``data_path/<i>.png`` aligned
+    target crops and ``mask_path/<i>.png`` their face-parsing label maps, i = 0 .. n-1.  Item = (target [3,512,512] in [-1,1], prior =
+    target, {inpaint_image, inpaint_mask (1 = keep)}, 12-digit index) -- no ``ref_imgs``: the caller supplies ONE source face for
+    every target.  ``gray_outer_mask=False`` uses the fixed label list [2, 3, 5, 6, 7] of ``__getitem_black__``."""
+
+    def __init__(self, label_transform=None, data_path="Video_processing/target_frames", mask_path="Video_processing/target_masks", **args):
+        from PIL import Image
+        self.Image = Image
+        self.gray_outer_mask = bool(args["gray_outer_mask"])
+        # (the reference tests ``hasattr(args, 'preserve_mask')`` on a dict, which is always False: the *_FFHQ lists are what it uses)
+        self.remove_tar = list(args["remove_mask_tar_FFHQ"])
+        self.preserve_src = list(args["preserve_mask_src_FFHQ"])
+        n_img, n_lab = len(os.listdir(data_path)), len(os.listdir(mask_path))
+        assert n_img == n_lab, "The number of images must be equal to the number of labels"
+        self.imgs = [os.path.join(data_path, f"{i}.png") for i in range(n_img)]
+        self.labels = [os.path.join(mask_path, f"{i}.png") for i in range(n_lab)]
+
+    def __len__(self):
+        return len(self.imgs)
+
+    def __getitem__(self, index):
+        Image = self.Image
+        img_p = Image.open(self.imgs[index]).convert("RGB").resize((512, 512))
+        lab = np.array(Image.open(self.labels[index]).convert("L"))
+        keep = self.remove_tar if self.gray_outer_mask else [2, 3, 5, 6, 7]
+        mask_img = Image.fromarray(np.where(np.isin(lab, keep), 255, 0).astype(np.uint8)).convert("L")
+        image_tensor = _normalize(_to_tensor(img_p), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
+        mask_tensor = 1.0 - _to_tensor(mask_img)
+        return image_tensor, image_tensor, {"inpaint_image": image_tensor * mask_tensor, "inpaint_mask": mask_tensor}, str(index).zfill(12)
+
+
+def load_source_reference(img_path, mask_path, preserve):
+    """The ONE source face of the selected-swap callers (inference_swap_selected.py:525-553): RGB image resized to 224x224 (the reference
+    uses A.Resize = cv2 INTER_LINEAR; PIL bilinear stands in, as in the test-bench readers: parity unpinned for that resize), CLIP
+    normalisation, times its preserved-label mask resized to 224x224 (bilinear on the tensor) -> [1, 3, 224, 224]."""
+    from PIL import Image
+    ref = Image.open(img_path).convert("RGB").resize((224, 224), Image.BILINEAR)
+    lab = np.array(Image.open(mask_path).convert("L"))
+    m = _to_tensor(Image.fromarray(np.where(np.isin(lab, preserve), 255, 0).astype(np.uint8)).convert("L"))
+    m = torch.nn.functional.interpolate(m[None], size=(224, 224), mode="bilinear", align_corners=False)[0]
+    return (_normalize(_to_tensor(ref), CLIP_MEAN, CLIP_STD) * m).unsqueeze(0)
+
+
 def shard_indices(n, rank, world):
     """Pairs are independent: rank r takes indices r, r + world, ...."""
     return list(range(rank, n, world))

@@ -201,51 +201,27 @@ def main(argv=None):
                     return
                 cur = nxt
 
+    from reface_amd.pipeline import SwapRunner
+    runner = SwapRunner(model, sampler, opt)
     with torch.no_grad(), model.ema_scope():
         for (test_batch, prior, test_model_kwargs, segment_id_batch), lm136 in with_landmark_prefetch(loader):
             if opt.Start_from_target:                   # inference_test_bench.py:414-435: noised target (or prior) latent as x_T
-                x0_img = prior                          # `use_prior = True` is hard-wired in the reference (:402, :424-429)
-                z0 = model.get_first_stage_encoding(model.encode_first_stage(x0_img.to(device).float()))
-                t0 = int(opt.target_start_noise_t)
-                t_q = torch.randint(t0 - 1, t0, (z0.shape[0],), device="cpu").long()
-                start_code = model.q_sample(x_start=z0, t=t_q, noise=torch.randn_like(z0))
+                start_code = runner.start_from_target(prior)      # `use_prior = True` is hard-wired in the reference (:402, :424-429)
             test_model_kwargs = {n: test_model_kwargs[n].to(device, non_blocking=True) for n in test_model_kwargs}
             B = test_batch.shape[0]
-            uc = model.learnable_vector.repeat(B, 1, 1) if opt.scale != 1.0 else None
-            landmarks = model.get_landmarks(test_batch, landmarks136=lm136) if model.Landmark_cond else None
-            c = model.conditioning_with_feat(test_model_kwargs["ref_imgs"].squeeze(1).to(torch.float32), landmarks=landmarks,
-                                             tar=test_batch.to("cuda").to(torch.float32)).float()
-            if len(c.shape) == 2:
-                c = c.unsqueeze(1)
             inpaint_image, inpaint_mask = test_model_kwargs["inpaint_image"], test_model_kwargs["inpaint_mask"]
-            z_inpaint = model.get_first_stage_encoding(model.encode_first_stage(inpaint_image)).detach()
-            test_model_kwargs["inpaint_image"] = z_inpaint
-            h = z_inpaint.shape[-1]
-            m64 = torch.empty((B, 1, h, h), dtype=torch.float32, device=device)
-            ops.bilinear_resize(inpaint_mask.float().contiguous(), m64)()     # torchvision Resize on a tensor (inference_test_bench.py:465)
-            test_model_kwargs["inpaint_mask"] = m64
-            shape = [opt.C, opt.H // opt.f, opt.W // opt.f]
-            x_T = None if start_code is None else start_code[:B]
-            samples_ddim, _ = sampler.sample(S=opt.ddim_steps, conditioning=c, batch_size=B, shape=shape, verbose=False,
-                                             unconditional_guidance_scale=opt.scale, unconditional_conditioning=uc, eta=opt.ddim_eta,
-                                             x_T=x_T, log_every_t=100, test_model_kwargs=test_model_kwargs)
-            x_dec = model.decode_first_stage(samples_ddim)
+            ref = test_model_kwargs["ref_imgs"].squeeze(1)
+            x_img, _ = runner.run_batch(test_batch, test_model_kwargs, ref, start_code=start_code, landmarks136=lm136)
             slot = host[n_batches % 2]                  # double-buffered pinned host staging: D2H of batch i overlaps batch i+1
             if slot is None or slot[0].shape[0] < B:
-                slot = host[n_batches % 2] = (torch.empty(x_dec.shape, dtype=torch.float32).pin_memory(), torch.cuda.Event())
+                slot = host[n_batches % 2] = (torch.empty(x_img.shape, dtype=torch.float32).pin_memory(), torch.cuda.Event())
             else:
                 slot[1].synchronize()                   # the copy that last used this slot has landed (two batches ago)
-            x_img = torch.empty_like(x_dec)
-            ops.to_image(x_dec, x_img)()
             slot[0][:B].copy_(x_img, non_blocking=True)
             n_done += B
             n_batches += 1
             if not opt.skip_save:
-                # reference panel of the grid / <id>_ref.png: 224 -> image size, bilinear (torchvision Resize on a tensor, :523)
-                ref = test_model_kwargs["ref_imgs"].squeeze(1).float().contiguous()
-                ref_big = torch.empty((B, 3, opt.H, opt.W), dtype=torch.float32, device=device)
-                ops.bilinear_resize(ref, ref_big)()
-                ref_np = ref_big.cpu().numpy()
+                ref_np = runner.resized_reference(ref, opt.H, opt.W).cpu().numpy()
                 slot[1].record()
                 slot[1].synchronize()
                 writer.submit(list(segment_id_batch), slot[0][:B].numpy().copy(), test_batch.float().numpy(), inpaint_image.cpu().numpy(),

@@ -389,3 +389,60 @@ def test_detect_landmarks_host_half():
     assert calls[0] == ((32, 32, 3), np.uint8, 1)
     host.detector = None
     assert float(LatentDiffusion.detect_landmarks(host, x).abs().sum()) == 0.0
+
+
+def _prepared_swap_tree(root, n_tar=3, n_src=2, size=96):
+    """<Base_dir>/{target_cropped,mask_frames,source_cropped,source_mask}/<i>.png as stage 1 of the reference writes it."""
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    for d, n in (("target_cropped", n_tar), ("mask_frames", n_tar), ("source_cropped", n_src), ("source_mask", n_src)):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+        for i in range(n):
+            if "mask" in d:                                                        # label maps are 512x512 (the parser's output size)
+                L = 512
+                lab = np.zeros((L, L), np.uint8)
+                lab[L // 4:3 * L // 4, L // 4:3 * L // 4] = 1                      # skin
+                lab[L // 2 - 20:L // 2 + 20, L // 2 - 20:L // 2 + 20] = 2          # nose
+                lab[:40, :] = 13                                                   # hair (not in the FFHQ lists)
+                Image.fromarray(lab).save(os.path.join(root, d, f"{i}.png"))
+            else:
+                Image.fromarray(rng.integers(0, 256, (size, size, 3), dtype=np.uint8)).save(os.path.join(root, d, f"{i}.png"))
+
+
+def test_video_dataset_and_source_reference(tmp_path):
+    """VideoDataset / source-face loader of the selected-swap callers (video_swap_dataset.py:86-295, inference_swap_selected.py:525-553)."""
+    from reface_amd.data import CLIP_MEAN, CLIP_STD, VideoDataset, load_source_reference
+    import ldm.data.video_swap_dataset as shim
+    assert shim.VideoDataset is VideoDataset
+    root = str(tmp_path / "base")
+    _prepared_swap_tree(root)
+    args = dict(gray_outer_mask=True, remove_mask_tar_FFHQ=[1, 2, 3, 5, 6, 7, 9], preserve_mask_src_FFHQ=[1, 2, 3, 5, 6, 7, 9])
+    ds = VideoDataset(data_path=os.path.join(root, "target_cropped"), mask_path=os.path.join(root, "mask_frames"), **args)
+    assert len(ds) == 3
+    t, prior, kw, sid = ds[1]
+    assert t.shape == (3, 512, 512) and -1.0 <= t.min() and t.max() <= 1.0 and torch.equal(prior, t) and sid == "000000000001"
+    m = kw["inpaint_mask"]
+    assert m.shape == (1, 512, 512) and set(m.unique().tolist()) <= {0.0, 1.0} and set(kw) == {"inpaint_image", "inpaint_mask"}
+    assert m[0, 0, 0] == 1.0 and m[0, 256, 256] == 0.0                      # hair kept, face region cut out
+    assert torch.equal(kw["inpaint_image"], t * m)
+    blk = VideoDataset(data_path=os.path.join(root, "target_cropped"), mask_path=os.path.join(root, "mask_frames"), **dict(args, gray_outer_mask=False))
+    assert blk[0][2]["inpaint_mask"][0, 200, 200] == 1.0 and blk[0][2]["inpaint_mask"][0, 256, 256] == 0.0     # only labels 2,3,5,6,7
+    ref = load_source_reference(os.path.join(root, "source_cropped", "0.png"), os.path.join(root, "source_mask", "0.png"), args["preserve_mask_src_FFHQ"])
+    assert ref.shape == (1, 3, 224, 224)
+    assert (ref[0, :, 0, 0] == 0).all() and ref[0, :, 112, 112].abs().sum() > 0                # masked outside the preserved labels
+    lo = [(0.0 - mu) / sd for mu, sd in zip(CLIP_MEAN, CLIP_STD)]
+    assert ref[0, 0].min() >= lo[0] - 1e-5
+
+
+def test_swap_selected_cli_surface(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import importlib
+    cli = importlib.import_module("inference_swap_selected")
+    flags = {a.option_strings[0] for a in cli.build_parser()._actions if a.option_strings}
+    ref = {"--prompt", "--outdir", "--Base_dir", "--skip_grid", "--skip_save", "--ddim_steps", "--plms", "--laion400m", "--fixed_code",
+           "--Start_from_target", "--only_target_crop", "--target_start_noise_t", "--ddim_eta", "--n_iter", "--H", "--W", "--C", "--f",
+           "--n_samples", "--n_rows", "--scale", "--target_folder", "--src_folder", "--src_image_mask", "--from-file", "--config", "--ckpt",
+           "--seed", "--rank", "--precision", "--faceParser_name", "--faceParsing_ckpt", "--segnext_config", "--save_vis", "--seg12"}
+    assert ref <= flags, ref - flags
+    d = cli.build_parser().parse_args([])
+    assert (d.ddim_steps, d.n_samples, d.scale, d.precision, d.Base_dir) == (50, 12, 5, "autocast", "results_video")
