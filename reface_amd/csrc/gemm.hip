@@ -148,6 +148,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
     const T* src1 = (const T*)p.src1;
     const T* Wp = W8 ? (const T*)((const char*)p.W + zb * p.sW) : (const T*)p.W + zb * p.sW;
 
+    // EPI 1: the per-column constants of this tile (bias + the tile's timestep / context vector) are fetched NOW, one column per
+    // thread, and parked in LDS after the main loop: fetched in the epilogue they cost one exposed L2 / HBM round trip per
+    // 32-column block (5 per tile: 25 of the 60 us of the 65536x960x320 qkv GEMM, RF_GEMM_DBG=8 experiment r02g)
+    float colc = 0.f;
+    if constexpr (EPI == 1) {
+        if (tid < BN && n0 + tid < p.N && p.splitk == 1) {
+            if (p.bias) colc = p.bias[n0 + tid];
+            if (p.rowvec) colc += p.rowvec[(long long)(m0 / p.rows_per_sample) * p.ldv + n0 + tid];
+        }
+    }
     const int r0 = tid >> 3;
     // GLDS: the LDS image of a direct-to-LDS load is lane-linear, so the XOR swizzle moves to the SOURCE: the lane that
     // lands on 16-byte position p of row r fetches k-slot p ^ ((r >> 1) & 7)  (r0 + 32*i keeps (r >> 1) & 7 for every i)
@@ -563,7 +573,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                     for (int i = 0; i < TM; ++i) {
                         float y[16];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) y[r] = (acc[i][j][r] * p.alpha + bv) * gelu_erf(acc[i][j + 1][r] * p.alpha + bg);
+                        for (int r = 0; r < 16; ++r) y[r] = (acc[i][j][r] * p.alpha + bv) * gelu_for<T>(acc[i][j + 1][r] * p.alpha + bg);
                         stage_block(y, (wm * TM + i) * 32, ((wn * TN + j) >> 1) * 32);
                     }
                 }
@@ -680,6 +690,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         const float* const rvu = (p.rowvec && !partial_out) ? p.rowvec + (long long)(m0 / p.rows_per_sample) * p.ldv : nullptr;
         constexpr int OV = sizeof(TO) == 2 ? 2 : 4;      // 16-byte vectors per 16 output values
         auto store16 = [&](TO* dst, const float* v) {
+            if (p.dbg & 8) return;                                                          // experiment: no global stores
+            if (p.dbg & 16) dst = (TO*)p.out + (((dst - (TO*)p.out) * (long long)sizeof(TO)) & 0xFFFFF) / (long long)sizeof(TO);   // experiment: all stores into 1 MB
             if constexpr (sizeof(TO) == 2) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -693,6 +705,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 for (int h = 0; h < 4; ++h) ((f32x4_t*)dst)[h] = f32x4_t{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
             }
         };
+        // column constants -> LDS (the main loop ended on a barrier: the operand stages are dead)
+        float* const colc_lds = (float*)smem;
+        if (tid < BN) colc_lds[tid] = colc;
+        lds_barrier();
         bool geglu = false;
         if constexpr (TN % 2 == 0) geglu = p.act == RF_ACT_GEGLU;
         if (partial_out) {
@@ -721,8 +737,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                     float bv[16], bg[16];
 #pragma unroll
                     for (int h = 0; h < 4; ++h) {
-                        f32x4_t a = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
-                        if (p.bias && cok) { a = ((const f32x4_t*)(p.bias + cv))[h]; g = ((const f32x4_t*)(p.bias + cv + 32))[h]; }
+                        const f32x4_t a = ((const f32x4_t*)(colc_lds + (cv - n0)))[h], g = ((const f32x4_t*)(colc_lds + (cv - n0) + 32))[h];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { bv[4 * h + e] = a[e]; bg[4 * h + e] = g[e]; }
                     }
@@ -734,7 +749,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 const float a_ = acc[i][j][r] * p.alpha + bv[r], g_ = acc[i][j + 1][r] * p.alpha + bg[r];
-                                v[r] = a_ * gelu_erf(g_);
+                                v[r] = a_ * gelu_for<T>(g_);
                             }
                             if (resp) {
                                 const u32x4_t* rp = (const u32x4_t*)(resp + (long long)row * p.ldr + ocol);
@@ -752,26 +767,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 }
             }
         } else {
-            // Register-lean schedule: one 32x32 block at a time, the values are finished in place in the accumulators; the bias
-            // (+ timestep) columns of block column j+1 and the residual segment of the next block are loaded one block ahead.
-            // sched_barrier(0) after every block keeps hipcc from hoisting every load of the unrolled nest to the top (the 2x5 wave
-            // tile then spills ~170 registers per lane).
-            constexpr bool PF = sizeof(TO) == 2;            // prefetch one block ahead (fp32 output rows cost twice the registers)
-            f32x4_t cb[2][4];
-            u32x4_t rq[2][OV];
-            auto load_cadd = [&](int j, f32x4_t* c) {
-                const int col = n0 + (wn * TN + j) * 32 + lhalf * 16;
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    f32x4_t a = {0.f, 0.f, 0.f, 0.f};
-                    if (col < p.N) {
-                        if (p.bias) a = ((const f32x4_t*)(p.bias + col))[h];
-                        if (rvu) { const f32x4_t q = ((const f32x4_t*)(rvu + col))[h]; a[0] += q[0]; a[1] += q[1]; a[2] += q[2]; a[3] += q[3]; }
-                    }
-                    c[h] = a;
-                }
-            };
-            auto load_res = [&](int i, int j, u32x4_t* r) {
+            // One 32x32 block at a time; the column constants come from LDS, the residual segments through a ring of PFD blocks in
+            // flight.  sched_barrier(0) after every block keeps hipcc from hoisting every load of the unrolled nest to the top (the 2x5
+            // wave tile then spills ~170 registers per lane).
+            constexpr int NBLK = TM * TN;
+            constexpr int PFD = sizeof(TO) == 2 ? (NBLK < 4 ? NBLK : 4) : 2;      // residual blocks in flight (8 / 16 registers each): the
+                                                                                  // fragment registers of the main loop are free now
+            u32x4_t rq[PFD][OV];
+            auto load_res = [&](int blk, u32x4_t* r) {
+                const int i = blk % TM, j = blk / TM;
                 const int col = n0 + (wn * TN + j) * 32 + lhalf * 16;
                 const int row = m0 + (wm * TM + i) * 32 + lrow;
                 if (resp && row < p.M && col < p.N) {
@@ -780,39 +784,33 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                     for (int h = 0; h < OV; ++h) r[h] = rp[h];
                 }
             };
-            load_cadd(0, cb[0]);
-            load_res(0, 0, rq[0]);
+#pragma unroll
+            for (int b = 0; b < PFD; ++b) load_res(b, rq[b]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + (wn * TN + j) * 32 + lhalf * 16;
                 const bool cok = col < p.N;
-                if (j + 1 < TN) load_cadd(j + 1, cb[(j + 1) & 1]);
+                f32x4_t cb[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) cb[h] = ((const f32x4_t*)(colc_lds + (col - n0)))[h];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    constexpr int dummy = 0; (void)dummy;
                     const int blk = j * TM + i;
                     const int row = m0 + (wm * TM + i) * 32 + lrow;
-                    if (PF) {
-                        if (blk + 1 < TM * TN) load_res((blk + 1) % TM, (blk + 1) / TM, rq[(blk + 1) & 1]);
-                    } else if (blk > 0) {
-                        load_res(i, j, rq[0]);
-                    }
-                    const u32x4_t* const myr = rq[PF ? (blk & 1) : 0];
+                    const u32x4_t* const myr = rq[blk % PFD];
                     if (row < p.M && cok) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * p.alpha + cb[j & 1][r >> 2][r & 3];   // (act NONE here)
                         TO* dst = outp + (long long)row * p.ldo + col;
 #pragma unroll
                         for (int h = 0; h < OV; ++h) {
                             constexpr int E = 16 / OV;
-                            float f[E];
+                            float f[E], v[E];
                             if (resp) unpack16<TO>(myr[h], f);
-                            float v[E];
 #pragma unroll
-                            for (int e = 0; e < E; ++e) v[e] = acc[i][j][h * E + e] + (resp ? f[e] : 0.0f);
-                            ((u32x4_t*)dst)[h] = pack16<TO>(v);
+                            for (int e = 0; e < E; ++e) v[e] = acc[i][j][h * E + e] * p.alpha + cb[(h * E + e) >> 2][(h * E + e) & 3] + (resp ? f[e] : 0.0f);
+                            if (!(p.dbg & 8)) ((u32x4_t*)dst)[h] = pack16<TO>(v);
                         }
                     }
+                    if (blk + PFD < NBLK) load_res(blk + PFD, rq[blk % PFD]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -886,7 +884,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float a_ = a4[e] * p.alpha + ba[e], g_ = g4[e] * p.alpha + bg[e];
-                v[e] = a_ * gelu_erf(g_);
+                v[e] = a_ * gelu_for<T>(g_);
             }
             TO* dst = outp + (long long)row * p.ldo + ocol;
             if (p.vec_ok) {
