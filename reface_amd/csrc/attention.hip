@@ -209,22 +209,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[qb][kb][r] = 0.f;
-        {
-            // all K fragments of the tile first (2 x STEPS 16-byte LDS reads in flight), then the MFMAs: hipcc otherwise emits
-            // read -> wait -> 2 MFMAs per fragment and the wave sits out the LDS latency five times per tile
-            u32x4_t kf[2][STEPS];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int st = 0; st < STEPS; ++st) kf[kb][st] = *(const u32x4_t*)(ldsK + (kb * 32 + lq) * KROW + st * 32 + lh * 16);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int st = 0; st < STEPS; ++st) {
+                const u32x4_t kf = *(const u32x4_t*)(ldsK + (kb * 32 + lq) * KROW + st * 32 + lh * 16);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int st = 0; st < STEPS; ++st)
-#pragma unroll
-                    for (int qb = 0; qb < QB; ++qb) AttnMma<T>::mma(s[qb][kb], kf[kb][st], qf[qb][st]);
-        }
+                for (int qb = 0; qb < QB; ++qb) AttnMma<T>::mma(s[qb][kb], kf, qf[qb][st]);
+            }
         // ---- online softmax on raw scores (scale > 0): p = exp2(c2 * s - c2 * m); keys of this lane: kb*32 + 8*(r>>2) + 4*lh + (r&3)
         if (kv0 + KV_TILE > p.Nk) {       // tail tile only: mask keys beyond Nk
 #pragma unroll
@@ -237,15 +229,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         }
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            // four independent max chains (a single chain is 17 dependent v_max3 per query block)
-            float m4[4];
+            float mx = s[qb][0][0];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) m4[c] = fmaxf(s[qb][0][c], s[qb][1][c]);
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 4; r < 16; r += 4)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) m4[c] = fmaxf(m4[c], fmaxf(s[qb][0][r + c], s[qb][1][r + c]));
-            float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][kb][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[qb], mx);
             const float mc = m_new * c2;
