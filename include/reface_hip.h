@@ -189,6 +189,17 @@ int rf_l2norm_rows(const float* x, float* y, int rows, int cols, void* stream);
 int rf_combine3(const float* a, const float* b, const float* c, float wa, float wb, float wc, float den, float* out, int64_t n, void* stream);
 /* y = clamp((x + 1) / 2, 0, 1)  (scripts/inference_test_bench.py:494) */
 int rf_to_image(const float* x, float* y, int64_t n, void* stream);
+
+/*
+ * Input preparation on the device -- what the test-bench dataset does per image on the host (ldm/data/test_bench_dataset.py:283-355:
+ * torchvision ToTensor + Normalize, np.isin label masks, tensor products).  Same float operation order => bit-identical tensors.
+ *   rf_u8_to_norm : uint8 [B, HW, 3] (HWC) -> fp32 [B, 3, HW]: (x / 255 - mean[c]) / std[c]
+ *   rf_label_mask : uint8 label map [n] -> fp32 {0, 1}: lut256[label] != 0, optionally inverted (target keep-mask = 1 - isin)
+ *   rf_mul_mask   : out[b, c, p] = x[b, c, p] * mask[b, p]
+ */
+int rf_u8_to_norm(const void* x_u8, int B, int HW, const float* mean3, const float* std3, float* out, void* stream);
+int rf_label_mask(const void* labels_u8, int64_t n, const void* lut256_u8, int invert, float* out, void* stream);
+int rf_mul_mask(const float* x, const float* mask, int B, int C, int HW, float* out, void* stream);
 /* elementwise y = silu(x) on fp32 (emb path, openaimodel.py:219) */
 int rf_silu_f32(const float* x, float* y, int64_t n, void* stream);
 

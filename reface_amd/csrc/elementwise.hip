@@ -120,6 +120,35 @@ __global__ void to_image_kernel(const float* __restrict__ x, float* __restrict__
 
 static inline dim3 grid1d(long long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
+
+// ---- input preparation on the device (test_bench_dataset.py:283-355 does this per image on the host with PIL / torch-CPU ops)
+// uint8 HWC image -> fp32 NCHW (x / 255 - mean[c]) / std[c]   (torchvision ToTensor + Normalize, same operation order)
+__global__ void u8_to_norm_kernel(const uint8_t* __restrict__ x, int B, int HW, const float* __restrict__ mean,
+                                  const float* __restrict__ stdv, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*HW pixels
+    if (i >= (long long)B * HW) return;
+    const int b = (int)(i / HW), p = (int)(i - (long long)b * HW);
+    const uint8_t* px = x + i * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[((long long)b * 3 + c) * HW + p] = ((float)px[c] / 255.0f - mean[c]) / stdv[c];
+}
+// label map -> {0, 1} mask: out = invert ? 1 - lut[label] : lut[label]   (np.isin(label, keep) -> 255 -> ToTensor; `1 -` for targets)
+__global__ void label_mask_kernel(const uint8_t* __restrict__ lab, long long n, const uint8_t* __restrict__ lut, int invert,
+                                  float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float m = lut[lab[i]] ? 1.0f : 0.0f;
+    out[i] = invert ? 1.0f - m : m;
+}
+// out[b, c, p] = x[b, c, p] * mask[b, 0, p]
+__global__ void mul_mask_kernel(const float* __restrict__ x, const float* __restrict__ mask, int B, int C, int HW, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * C * HW) return;
+    const int p = (int)(i % HW);
+    const int b = (int)(i / ((long long)C * HW));
+    out[i] = x[i] * mask[(long long)b * HW + p];
+}
+
 }  // namespace rf
 
 using namespace rf;
@@ -201,5 +230,32 @@ extern "C" int rf_to_image(const float* x, float* y, int64_t n, void* stream) {
     RF_CHECK(x && y && n > 0, "rf_to_image: bad arguments");
     hipLaunchKernelGGL(to_image_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, x, y, (long long)n);
     RF_LAUNCH_CHECK("rf_to_image");
+    return 0;
+}
+
+extern "C" int rf_u8_to_norm(const void* x, int B, int HW, const float* mean, const float* stdv, float* out, void* stream) {
+    using namespace rf;
+    RF_CHECK(x && mean && stdv && out && B > 0 && HW > 0, "rf_u8_to_norm: bad arguments");
+    const long long n = (long long)B * HW;
+    hipLaunchKernelGGL(u8_to_norm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)x, B, HW, mean, stdv, out);
+    RF_LAUNCH_CHECK("rf_u8_to_norm");
+    return 0;
+}
+
+extern "C" int rf_label_mask(const void* labels, int64_t n, const void* lut256, int invert, float* out, void* stream) {
+    using namespace rf;
+    RF_CHECK(labels && lut256 && out && n > 0, "rf_label_mask: bad arguments");
+    hipLaunchKernelGGL(label_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)labels, (long long)n,
+                       (const uint8_t*)lut256, invert, out);
+    RF_LAUNCH_CHECK("rf_label_mask");
+    return 0;
+}
+
+extern "C" int rf_mul_mask(const float* x, const float* mask, int B, int C, int HW, float* out, void* stream) {
+    using namespace rf;
+    RF_CHECK(x && mask && out && B > 0 && C > 0 && HW > 0, "rf_mul_mask: bad arguments");
+    const long long n = (long long)B * C * HW;
+    hipLaunchKernelGGL(mul_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, mask, B, C, HW, out);
+    RF_LAUNCH_CHECK("rf_mul_mask");
     return 0;
 }

@@ -66,12 +66,15 @@ class CelebAdataset(Dataset):
 
     def __init__(self, state="test", dataset_dir="dataset/FaceData/CelebAMask-HQ", gray_outer_mask=True, remove_mask_tar=None,
                  preserve_mask_src=None, preserve_mask=None, fraction=1.0, first_target=28000, n_targets=1000, first_source=29000,
-                 **_ignored):
+                 raw=False, **_ignored):
         if state != "test":
             raise NotImplementedError("only the test split is on the inference path (train / validation splits feed main.py)")
         from PIL import Image
         self.Image = Image
         self.gray_outer_mask = bool(gray_outer_mask)
+        # raw=True: items are the decoded / resized uint8 arrays only (target HWC, its label map, 224x224 source HWC, its label map, id);
+        # normalisation, label masks and the mask products then run on the GPU (reface_amd/prep.py) -- bit-identical tensors
+        self.raw = bool(raw)
         if preserve_mask is not None:
             remove_mask_tar = preserve_mask_src = preserve_mask
         self.remove_tar = list(remove_mask_tar if remove_mask_tar is not None else [1, 2, 4, 5, 8, 9, 6, 7, 10, 11, 12, 17])
@@ -96,6 +99,11 @@ class CelebAdataset(Dataset):
     def __getitem__(self, index):
         Image = self.Image
         img_p = Image.open(self.imgs[index]).convert("RGB").resize((512, 512))                 # PIL default filter, as the reference
+        if self.raw:
+            ref = Image.open(self.ref_imgs[index]).convert("RGB").resize((224, 224), Image.BILINEAR)
+            u8 = lambda im: torch.from_numpy(np.asarray(im, dtype=np.uint8).copy())
+            return (u8(img_p), u8(Image.open(self.labels[index]).convert("L")), u8(ref),
+                    u8(Image.open(self.ref_labels[index]).convert("L")), str(index).zfill(12))
         image_tensor = _normalize(_to_tensor(img_p), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
         tar_labels = self.remove_tar if self.gray_outer_mask else self.preserve_src
         mask_tensor = 1.0 - _to_tensor(self._label_mask(self.labels[index], tar_labels))     # 1 = keep, 0 = region to generate

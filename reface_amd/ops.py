@@ -418,6 +418,31 @@ def to_image(x, out, name="to_image"):
     return Launch(lib.rf_to_image, (_p(x), _p(out), x.numel()), (x, out), name)
 
 
+def u8_to_norm(x_u8, mean, std, out, name="u8_to_norm"):
+    """x_u8 [B, H, W, 3] uint8 -> out [B, 3, H, W] fp32 = (x / 255 - mean) / std (ToTensor + Normalize)."""
+    lib = _lib.load()
+    _require_gpu(x_u8, mean, std, out)
+    B, H, W_, C3 = x_u8.shape
+    assert C3 == 3 and x_u8.dtype == torch.uint8 and x_u8.is_contiguous() and out.is_contiguous() and out.dtype == torch.float32
+    return Launch(lib.rf_u8_to_norm, (_p(x_u8), B, H * W_, _p(mean), _p(std), _p(out)), (x_u8, mean, std, out), name)
+
+
+def label_mask(labels_u8, lut256, out, *, invert, name="label_mask"):
+    lib = _lib.load()
+    _require_gpu(labels_u8, lut256, out)
+    assert labels_u8.dtype == torch.uint8 and lut256.dtype == torch.uint8 and lut256.numel() == 256 and out.dtype == torch.float32
+    assert labels_u8.is_contiguous() and out.is_contiguous() and out.numel() == labels_u8.numel()
+    return Launch(lib.rf_label_mask, (_p(labels_u8), labels_u8.numel(), _p(lut256), int(bool(invert)), _p(out)), (labels_u8, lut256, out), name)
+
+
+def mul_mask(x, mask, out, name="mul_mask"):
+    lib = _lib.load()
+    _require_gpu(x, mask, out)
+    B, Cc, H, W_ = x.shape
+    assert x.is_contiguous() and mask.is_contiguous() and out.is_contiguous() and mask.numel() == B * H * W_
+    return Launch(lib.rf_mul_mask, (_p(x), _p(mask), B, Cc, H * W_, _p(out)), (x, mask, out), name)
+
+
 def gaussian_sample(moments, eps, out, *, scale, name="gaussian_sample"):
     lib = _lib.load()
     _require_gpu(moments, eps, out)

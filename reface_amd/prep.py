@@ -1,0 +1,51 @@
+"""Device-side input preparation of the test-bench items (second half).
+
+The reference's dataset builds every tensor on the host, per image (ldm/data/test_bench_dataset.py:283-355): ToTensor + Normalize of
+the 512x512 target, ``1 - isin(labels, remove)`` keep-mask, masked target, ToTensor + CLIP-Normalize of the 224x224 source, its
+``isin(labels, preserve)`` mask resized to 224x224 (bilinear), product.  With ``raw=True`` the dataset workers only decode / resize
+(PIL) and hand over uint8 arrays; this module does the rest on the GPU with the same float operation order, so the tensors are
+bit-identical to the host path (tests/test_e2e_gpu.py::test_device_prep_matches_host).
+"""
+import torch
+
+from . import ops
+from .data import CLIP_MEAN, CLIP_STD
+
+
+class DevicePrep:
+    def __init__(self, remove_tar, preserve_src, gray_outer_mask=True, device="cuda"):
+        self.dev = torch.device(device)
+        self.gray = bool(gray_outer_mask)
+
+        def lut(labels):
+            t = torch.zeros(256, dtype=torch.uint8)
+            t[torch.tensor(list(labels), dtype=torch.long)] = 1
+            return t.to(self.dev)
+        self.lut_tar = lut(remove_tar if self.gray else preserve_src)      # __getitem_black__ uses preserve_src for the target too
+        self.lut_src = lut(preserve_src)
+        f = lambda v: torch.tensor(v, dtype=torch.float32, device=self.dev)
+        self.m05, self.s05 = f((0.5, 0.5, 0.5)), f((0.5, 0.5, 0.5))
+        self.mclip, self.sclip = f(CLIP_MEAN), f(CLIP_STD)
+
+    @torch.no_grad()
+    def __call__(self, tar_u8, tar_lab, ref_u8, ref_lab):
+        """uint8 batches (host or device): tar [B,H,W,3], tar_lab [B,H,W], ref [B,224,224,3], ref_lab [B,Hl,Wl] ->
+        (target [B,3,H,W] in [-1,1], {"inpaint_image", "inpaint_mask" [B,1,H,W] (1 = keep), "ref_imgs" [B,1,3,224,224]})."""
+        dev = self.dev
+        tar_u8, tar_lab, ref_u8, ref_lab = (t.to(dev, non_blocking=True).contiguous() for t in (tar_u8, tar_lab, ref_u8, ref_lab))
+        B, H, W, _ = tar_u8.shape
+        target = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+        ops.u8_to_norm(tar_u8, self.m05, self.s05, target)()
+        mask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        ops.label_mask(tar_lab, self.lut_tar, mask, invert=True)()
+        inpaint = torch.empty_like(target)
+        ops.mul_mask(target, mask, inpaint)()
+        ref = torch.empty((B, 3, 224, 224), dtype=torch.float32, device=dev)
+        ops.u8_to_norm(ref_u8, self.mclip, self.sclip, ref)()
+        if self.gray:
+            m_full = torch.empty((B, 1) + tuple(ref_lab.shape[1:]), dtype=torch.float32, device=dev)
+            ops.label_mask(ref_lab, self.lut_src, m_full, invert=False)()
+            m224 = torch.empty((B, 1, 224, 224), dtype=torch.float32, device=dev)
+            ops.bilinear_resize(m_full, m224)()                      # T.Resize((224, 224)) on a tensor: bilinear, no antialias
+            ops.mul_mask(ref, m224, ref)()
+        return target, {"inpaint_image": inpaint, "inpaint_mask": mask, "ref_imgs": ref.unsqueeze(1)}

@@ -66,6 +66,7 @@ def build_parser():
     p.add_argument("--n_items", type=int, default=8, help="number of synthetic pairs (--dataset synthetic)")
     p.add_argument("--clip_vision_config", type=str, default=None, help="JSON dict overriding the CLIP ViT dims (tests)")
     p.add_argument("--num_workers", type=int, default=4, help="DataLoader workers of the folder readers (reference: 4)")
+    p.add_argument("--gpu_prep", action="store_true", help="folder readers hand over uint8 arrays; normalise / mask / resize run on the GPU")
     return p
 
 
@@ -152,6 +153,8 @@ def main(argv=None):
         if opt.dataset_dir is not None and "dataset_dir" not in test_args:
             test_args["dataset_dir"] = opt.dataset_dir
         test_args.setdefault("state", "test")
+        if opt.gpu_prep:
+            test_args["raw"] = True
         if opt.dataset == "FF++" and opt.dataset_dir is not None:       # inference_test_bench.py:383: the flag overrides the config
             test_args["dataset_dir"] = opt.dataset_dir
         full = {"CelebA": CelebAdataset, "FFHQ": FFHQdataset, "FF++": FFdataset}[opt.dataset](**test_args)
@@ -203,8 +206,24 @@ def main(argv=None):
 
     from reface_amd.pipeline import SwapRunner
     runner = SwapRunner(model, sampler, opt)
+    prep = None
+    if opt.gpu_prep and opt.dataset != "synthetic":
+        from reface_amd.prep import DevicePrep
+        prep = DevicePrep(full.remove_tar, full.preserve_src, full.gray_outer_mask)
+
+    def unpack(batches):
+        """raw uint8 items -> the dataset's tensor contract, prepared on the GPU (--gpu_prep); identity otherwise"""
+        for item in batches:
+            if prep is None:
+                yield item
+            else:
+                tar_u8, tar_lab, ref_u8, ref_lab, ids = item
+                target, kw = prep(tar_u8, tar_lab, ref_u8, ref_lab)
+                t_host = target.cpu()
+                yield t_host, t_host, kw, ids
+
     with torch.no_grad(), model.ema_scope():
-        for (test_batch, prior, test_model_kwargs, segment_id_batch), lm136 in with_landmark_prefetch(loader):
+        for (test_batch, prior, test_model_kwargs, segment_id_batch), lm136 in with_landmark_prefetch(unpack(loader)):
             if opt.Start_from_target:                   # inference_test_bench.py:414-435: noised target (or prior) latent as x_T
                 start_code = runner.start_from_target(prior)      # `use_prior = True` is hard-wired in the reference (:402, :424-429)
             test_model_kwargs = {n: test_model_kwargs[n].to(device, non_blocking=True) for n in test_model_kwargs}

@@ -197,3 +197,32 @@ def test_cli_swap_selected(tmp_path):
     # without the prepared tree the CLI says what is out of scope instead of failing somewhere inside
     r2 = subprocess.run(cmd[:4] + ["--Base_dir", str(tmp_path / "nothing")] + cmd[6:], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r2.returncode != 0 and "stage 1" in (r2.stderr + r2.stdout)
+
+
+def test_device_prep_matches_host(tmp_path):
+    """SURVEY 8f.1 (second half): the dataset's tensors built on the GPU from uint8 arrays (reface_amd/prep.py, rf_u8_to_norm /
+    rf_label_mask / rf_mul_mask / rf_bilinear_resize) are bit-identical to the host path of the same reader."""
+    from PIL import Image
+    from reface_amd.data import CelebAdataset
+    from reface_amd.prep import DevicePrep
+    root = tmp_path / "CelebAMask-HQ"
+    (root / "CelebA-HQ-img").mkdir(parents=True)
+    (root / "CelebA-HQ-mask" / "Overall_mask").mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    for i in (28000, 28001, 29000, 29001):
+        Image.fromarray(rng.integers(0, 256, (96, 80, 3), dtype=np.uint8)).save(root / "CelebA-HQ-img" / f"{i}.jpg")
+        Image.fromarray(rng.integers(0, 19, (512, 512), dtype=np.uint8)).save(root / "CelebA-HQ-mask" / "Overall_mask" / f"{i}.png")
+    for gray in (True, False):
+        kw = dict(dataset_dir=str(root), n_targets=2, gray_outer_mask=gray)
+        host, raw = CelebAdataset(**kw), CelebAdataset(raw=True, **kw)
+        prep = DevicePrep(raw.remove_tar, raw.preserve_src, raw.gray_outer_mask)
+        items = [raw[i] for i in range(2)]
+        target, out = prep(*(torch.stack([it[k] for it in items]) for k in range(4)))
+        torch.cuda.synchronize()
+        for i in range(2):
+            t, _, hk, sid = host[i]
+            assert sid == items[i][4]
+            assert torch.equal(target[i].cpu(), t)
+            assert torch.equal(out["inpaint_mask"][i].cpu(), hk["inpaint_mask"])
+            assert torch.equal(out["inpaint_image"][i].cpu(), hk["inpaint_image"])
+            assert torch.equal(out["ref_imgs"][i].cpu(), hk["ref_imgs"]), (out["ref_imgs"][i].cpu() - hk["ref_imgs"]).abs().max()
