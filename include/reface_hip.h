@@ -192,7 +192,7 @@ int rf_to_image(const float* x, float* y, int64_t n, void* stream);
 
 /*
  * Input preparation on the device -- what the test-bench dataset does per image on the host (ldm/data/test_bench_dataset.py:283-355:
- * torchvision ToTensor + Normalize, np.isin label masks, tensor products).  Same float operation order => bit-identical tensors.
+ * torchvision ToTensor + Normalize, np.isin label masks, tensor products).  Same float operation order => bit-identical tensors (the resized source mask: 1 ulp).
  *   rf_u8_to_norm : uint8 [B, HW, 3] (HWC) -> fp32 [B, 3, HW]: (x / 255 - mean[c]) / std[c]
  *   rf_label_mask : uint8 label map [n] -> fp32 {0, 1}: lut256[label] != 0, optionally inverted (target keep-mask = 1 - isin)
  *   rf_mul_mask   : out[b, c, p] = x[b, c, p] * mask[b, p]

@@ -73,7 +73,7 @@ class CelebAdataset(Dataset):
         self.Image = Image
         self.gray_outer_mask = bool(gray_outer_mask)
         # raw=True: items are the decoded / resized uint8 arrays only (target HWC, its label map, 224x224 source HWC, its label map, id);
-        # normalisation, label masks and the mask products then run on the GPU (reface_amd/prep.py) -- bit-identical tensors
+        # normalisation, label masks and the mask products then run on the GPU (reface_amd/prep.py)
         self.raw = bool(raw)
         if preserve_mask is not None:
             remove_mask_tar = preserve_mask_src = preserve_mask

@@ -3,8 +3,9 @@
 The reference's dataset builds every tensor on the host, per image (ldm/data/test_bench_dataset.py:283-355): ToTensor + Normalize of
 the 512x512 target, ``1 - isin(labels, remove)`` keep-mask, masked target, ToTensor + CLIP-Normalize of the 224x224 source, its
 ``isin(labels, preserve)`` mask resized to 224x224 (bilinear), product.  With ``raw=True`` the dataset workers only decode / resize
-(PIL) and hand over uint8 arrays; this module does the rest on the GPU with the same float operation order, so the tensors are
-bit-identical to the host path (tests/test_e2e_gpu.py::test_device_prep_matches_host).
+(PIL) and hand over uint8 arrays; this module does the rest on the GPU with the same float operation order, so the target, keep-mask
+and masked target are bit-identical to the host path and the masked source face agrees to one fp32 ulp (its mask goes through a
+non-integer-ratio bilinear resize; tests/test_e2e_gpu.py::test_device_prep_matches_host).
 """
 import torch
 

