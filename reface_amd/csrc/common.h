@@ -131,9 +131,22 @@ template <typename T> __device__ __forceinline__ float gelu_for(float x) {
 }
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + expf(-1.702f * x)); }
 
+// Sum over the 64 lanes, result in every lane.  DPP / permlane-swap steps (a few cycles of latency each) instead of six dependent
+// ds_bpermute round trips (__shfl_xor: ~120 cycles each -- the two reductions of a LayerNorm row were 1.5k cycles of pure latency).
+// Within a row of 16 lanes: xor 1, xor 2, half-mirror, mirror; then v_permlane16_swap / v_permlane32_swap (gfx950) for rows / halves.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += as_f32((uint32_t)__builtin_amdgcn_mov_dpp((int)as_u32(v), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+    v += as_f32((uint32_t)__builtin_amdgcn_mov_dpp((int)as_u32(v), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+    v += as_f32((uint32_t)__builtin_amdgcn_mov_dpp((int)as_u32(v), 0x141, 0xF, 0xF, true));     // row_half_mirror
+    v += as_f32((uint32_t)__builtin_amdgcn_mov_dpp((int)as_u32(v), 0x140, 0xF, 0xF, true));     // row_mirror
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(as_u32(v), as_u32(v), false, false);
+        v = as_f32(r[0]) + as_f32(r[1]);
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(as_u32(v), as_u32(v), false, false);
+        v = as_f32(r[0]) + as_f32(r[1]);
+    }
     return v;
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -142,8 +155,18 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = fmaxf(v, as_f32((uint32_t)__builtin_amdgcn_mov_dpp((int)as_u32(v), 0xB1, 0xF, 0xF, true)));
+    v = fmaxf(v, as_f32((uint32_t)__builtin_amdgcn_mov_dpp((int)as_u32(v), 0x4E, 0xF, 0xF, true)));
+    v = fmaxf(v, as_f32((uint32_t)__builtin_amdgcn_mov_dpp((int)as_u32(v), 0x141, 0xF, 0xF, true)));
+    v = fmaxf(v, as_f32((uint32_t)__builtin_amdgcn_mov_dpp((int)as_u32(v), 0x140, 0xF, 0xF, true)));
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(as_u32(v), as_u32(v), false, false);
+        v = fmaxf(as_f32(r[0]), as_f32(r[1]));
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(as_u32(v), as_u32(v), false, false);
+        v = fmaxf(as_f32(r[0]), as_f32(r[1]));
+    }
     return v;
 }
 

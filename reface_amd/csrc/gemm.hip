@@ -7,10 +7,12 @@
 // every lane feeds the MFMA from one 16-B fragment (lane l: row l&31, slot 2*kk + (l>>5)):
 //   bf16 : 1 x v_mfma_f32_32x32x16_bf16 per fragment pair (8 k per lane-half)
 //   fp32 : 4 x v_mfma_f32_32x32x2_f32   per fragment pair (exact fp32 FMA chain, 157 TF peak)
-// The A operand is gathered on the fly from channels-last source tensors (3x3 / 1x1, stride,
-// asymmetric padding, nearest x2 upsample folded into the addressing, 2-source channel concat),
-// staged global -> registers -> LDS with the next tile's loads issued before the current tile's
-// MFMAs (one barrier per K-tile, double-buffered LDS).
+// The A operand is gathered on the fly from channels-last source tensors (3x3 / 1x1, stride, asymmetric padding, nearest x2
+// upsample folded into the addressing, 2-source channel concat).  Hot path (GLDS): both operands go global -> LDS directly
+// (buffer_load_dwordx4 ... lds, no staging registers; the XOR swizzle is applied on the SOURCE side), two LDS stages, the pieces
+// of tile kt+2 issued right behind the barrier that retires tile kt, a register-level fragment pipeline under the MFMAs.  Shapes the
+// DMA cannot express (two sources, K tiles straddling a filter tap, fp32 operands with ragged K) take the register-staged loop
+// (global -> registers -> LDS, next tile's loads issued before the current tile's MFMAs).  Epilogues: see the EPI parameter.
 #include <cstdlib>
 #include <type_traits>
 
@@ -102,8 +104,9 @@ template <> __device__ __forceinline__ float load_out<bf16_t>(const bf16_t* p) {
 // EPI = 1: "direct" epilogue.  The MFMA operands are swapped (W fragment as the row operand, A fragment as the column operand)
 // and the W rows of each 32-row block are read in the order  row(i') = 16*((i'>>2)&1) + 4*(i'>>3) + (i'&3), so that lane
 // (m = l & 31, h = l >> 5) ends up with accumulator register r = output column 16*h + r of its row: 16 CONTIGUOUS columns per
-// 32x32 block.  Bias / activation / residual / GEGLU then happen in registers and every lane writes its row segments with 16-byte
-// stores -- no LDS staging pass, no barriers, and waves retire independently.
+// 32x32 block.  Bias / timestep vector / residual / GEGLU then happen in registers and every lane writes its row segments with 16-byte
+// stores -- no staging pass of the tile through LDS (only the BN column constants are parked there, one barrier), and the waves
+// retire independently.  EPI = 2: the whole tile staged ONCE as bf16 by all waves (opt-in, measured neutral).
 // W8 = true: the weights are fp8 (e4m3fn) with one power-of-two scale per output channel.  A W tile in LDS keeps the 128-byte row
 // geometry and therefore holds 128 K elements = the W operand of TWO consecutive A tiles: the W pieces are issued every other
 // tile (half the weight bytes through L2 / LDS), and a W fragment is an 8-byte LDS read turned into 8 bf16 by 4 conversions

@@ -206,58 +206,86 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
 
 // ------------------------------------------------------------------------------------------------
 constexpr int LN_MAXV = 6;
-template <typename T, typename TO>
+constexpr int LN_RPW = 4;          // rows per wave: their loads are issued together (one row per wave keeps ONE 16-byte load per lane in
+                                   // flight and the kernel sits at 2.5 TB/s, latency-bound)
+// NV = 16-byte vectors per lane (C <= NV * 64 * VEC); two-pass statistics in registers, fp32.
+template <typename T, typename TO, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int M, int C, int ldx, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, TO* __restrict__ out, int ldo) {
     constexpr int VEC = elem<T>::VEC;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
     const int lane = threadIdx.x & 63;
-    if (row >= M) return;
+    if (row0 >= M) return;
     const int nvec = C / VEC;
-    const T* xr = x + (long long)row * ldx;
-    float f[LN_MAXV][VEC];
-    float sum = 0.f;
+    float f[LN_RPW][NV][VEC];
+    u32x4_t raw[LN_RPW][NV];
 #pragma unroll
-    for (int q = 0; q < LN_MAXV; ++q) {
+    for (int r = 0; r < LN_RPW; ++r)
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int v = lane + q * 64;
+            raw[r][q] = u32x4_t{0u, 0u, 0u, 0u};
+            if (v < nvec && row0 + r < M) raw[r][q] = *(const u32x4_t*)(x + (long long)(row0 + r) * ldx + v * VEC);
+        }
+    // affine parameters of this lane's columns (the same for every row)
+    float g[NV][VEC], bt[NV][VEC];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
         const int v = lane + q * 64;
-        if (v < nvec) {
-            const u32x4_t raw = *(const u32x4_t*)(xr + v * VEC);
-            unpack16<T>(raw, f[q]);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) sum += f[q][e];
+        for (int e = 0; e < VEC; ++e) {
+            g[q][e] = v < nvec ? gamma[v * VEC + e] : 0.f;
+            bt[q][e] = v < nvec ? beta[v * VEC + e] : 0.f;
         }
     }
-    const float mean = wave_sum(sum) / (float)C;
-    float sq = 0.f;
+    float mean[LN_RPW], rstd[LN_RPW];
 #pragma unroll
-    for (int q = 0; q < LN_MAXV; ++q) {
-        const int v = lane + q * 64;
-        if (v < nvec) {
+    for (int r = 0; r < LN_RPW; ++r) {
+        float sum = 0.f;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) { const float d = f[q][e] - mean; sq += d * d; }
-        }
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
-    TO* orow = out + (long long)row * ldo;
+        for (int q = 0; q < NV; ++q) {
+            unpack16<T>(raw[r][q], f[r][q]);
+            if (lane + q * 64 < nvec) {
 #pragma unroll
-    for (int q = 0; q < LN_MAXV; ++q) {
-        const int v = lane + q * 64;
-        if (v < nvec) {
-            float y[VEC];
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                y[e] = (f[q][e] - mean) * rstd * gamma[v * VEC + e] + beta[v * VEC + e];
+                for (int e = 0; e < VEC; ++e) sum += f[r][q][e];
             }
-            if constexpr (sizeof(TO) == sizeof(T)) {
-                *(u32x4_t*)(orow + v * VEC) = pack16<TO>(y);
-            } else if constexpr (sizeof(TO) == 4) {
-                *(u32x4_t*)(orow + v * VEC) = pack16<float>(y);
-                *(u32x4_t*)(orow + v * VEC + 4) = pack16<float>(y + 4);
-            } else {
-                u32x2_t h;
-                h[0] = pack_bf2(y[0], y[1]);
-                h[1] = pack_bf2(y[2], y[3]);
-                *(u32x2_t*)(orow + v * VEC) = h;
+        }
+        mean[r] = wave_sum(sum) / (float)C;
+    }
+#pragma unroll
+    for (int r = 0; r < LN_RPW; ++r) {
+        float sq = 0.f;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            if (lane + q * 64 < nvec) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { const float d = f[r][q][e] - mean[r]; sq += d * d; }
+            }
+        }
+        rstd[r] = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
+    }
+#pragma unroll
+    for (int r = 0; r < LN_RPW; ++r) {
+        if (row0 + r >= M) break;
+        TO* orow = out + (long long)(row0 + r) * ldo;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int v = lane + q * 64;
+            if (v < nvec) {
+                float y[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) y[e] = (f[r][q][e] - mean[r]) * rstd[r] * g[q][e] + bt[q][e];
+                if constexpr (sizeof(TO) == sizeof(T)) {
+                    *(u32x4_t*)(orow + v * VEC) = pack16<TO>(y);
+                } else if constexpr (sizeof(TO) == 4) {
+                    *(u32x4_t*)(orow + v * VEC) = pack16<float>(y);
+                    *(u32x4_t*)(orow + v * VEC + 4) = pack16<float>(y + 4);
+                } else {
+                    u32x2_t h;
+                    h[0] = pack_bf2(y[0], y[1]);
+                    h[1] = pack_bf2(y[2], y[3]);
+                    *(u32x2_t*)(orow + v * VEC) = h;
+                }
             }
         }
     }
@@ -384,14 +412,17 @@ extern "C" int rf_layernorm(int dtype, const void* x, int M, int C, int ldx, con
     RF_CHECK(x && gamma && beta && out && M > 0, "rf_layernorm: bad arguments");
     RF_CHECK((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "rf_layernorm: gamma / beta must be 16-byte aligned");
     RF_CHECK(C % vec == 0 && ldx % vec == 0 && ldo % 8 == 0 && C / vec <= 64 * LN_MAXV, "rf_layernorm: C=%d ldx=%d ldo=%d unsupported", C, ldx, ldo);
-    dim3 grid((M + 3) / 4);
+    dim3 grid((M + 4 * LN_RPW - 1) / (4 * LN_RPW));
     hipStream_t st = (hipStream_t)stream;
-#define LN(T, TO) hipLaunchKernelGGL((layernorm_kernel<T, TO>), grid, dim3(256), 0, st, (const T*)x, M, C, ldx, gamma, beta, eps, (TO*)out, ldo)
-    if (dtype == RF_F32 && out_dtype == RF_F32) LN(float, float);
-    else if (dtype == RF_F32) LN(float, bf16_t);
-    else if (out_dtype == RF_F32) LN(bf16_t, float);
-    else LN(bf16_t, bf16_t);
+    const int nv = (C / vec + 63) / 64;          // 16-byte vectors per lane
+#define LN_(T, TO, NV) hipLaunchKernelGGL((layernorm_kernel<T, TO, NV>), grid, dim3(256), 0, st, (const T*)x, M, C, ldx, gamma, beta, eps, (TO*)out, ldo)
+#define LN(T, TO) { if (nv <= 1) LN_(T, TO, 1); else if (nv <= 2) LN_(T, TO, 2); else if (nv <= 3) LN_(T, TO, 3); else LN_(T, TO, LN_MAXV); }
+    if (dtype == RF_F32 && out_dtype == RF_F32) LN(float, float)
+    else if (dtype == RF_F32) LN(float, bf16_t)
+    else if (out_dtype == RF_F32) LN(bf16_t, float)
+    else LN(bf16_t, bf16_t)
 #undef LN
+#undef LN_
     RF_LAUNCH_CHECK("rf_layernorm");
     return 0;
 }

@@ -61,11 +61,6 @@ def pack_conv_weight(w, dtype, cin_pad=None, korder=0):
     return wp.reshape(co, kh * kw * cp).to(dtype).contiguous()
 
 
-def pack_concat_conv_weight(w, c0, dtype):
-    """conv over cat([a(c0 ch), b]) -- same layout as pack_conv_weight (channels already in cat order)."""
-    return pack_conv_weight(w, dtype)
-
-
 def pack_geglu(w, b, dtype):
     """GEGLU projection [2F, C] (value rows 0..F-1, gate rows F..2F-1) -> rows interleaved in blocks
     of 32 (value block, gate block) so one MFMA wave tile holds matching value/gate columns."""
