@@ -206,8 +206,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
 
 // ------------------------------------------------------------------------------------------------
 constexpr int LN_MAXV = 6;
-constexpr int LN_RPW = 4;          // rows per wave: their loads are issued together (one row per wave keeps ONE 16-byte load per lane in
-                                   // flight and the kernel sits at 2.5 TB/s, latency-bound)
+constexpr int LN_RPW = 1;          // rows per wave.  4 (loads of four rows in flight per lane) measured -3 % on the 65536-row launches alone and
+                                   // +14 % on the step's 32 launches in situ (the 1024 / 4096-row levels lose their parallelism): 1 it stays
 // NV = 16-byte vectors per lane (C <= NV * 64 * VEC); two-pass statistics in registers, fp32.
 template <typename T, typename TO, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int M, int C, int ldx, const float* __restrict__ gamma,

@@ -11,7 +11,9 @@ python3 - <<PY
 import csv, glob, collections, json, re
 def fam(n):
     m = re.search(r"conv_gemm_kernel<(unsigned short|float), (unsigned short|float)", n)
-    if m: return "rf_conv_gemm[%s]" % ("bf16" if m.group(1) == "unsigned short" else "f32")
+    if m:
+        if re.search(r", true>\(", n): return "rf_conv_gemm[fp8w]"          # last template argument W8
+        return "rf_conv_gemm[%s]" % ("bf16" if m.group(1) == "unsigned short" else "f32")
     m = re.search(r"rf::(\w+?)_kernel", n)
     return "rf_" + m.group(1) if m else "other"
 out = {}
