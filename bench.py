@@ -387,7 +387,7 @@ def main():
             log(f"   dec {k:24s} calls {v['calls']:4d}  {v['ms']:9.3f} ms  {v['tflops_per_s']:8.1f} TFLOP/s")
         if args.profile_json:
             def row(l, ms):
-                r = {"name": l.name, "family": profiler.launch_family(l), "ms": ms, "flop": profiler.gemm_flops(l) + profiler.attention_flops(l)}
+                r = {"name": l.name, "family": profiler.launch_family(l), "ms": ms, "flop": profiler.gemm_flops(l) + profiler.attention_flops(l) + profiler.ffn_flops(l)}
                 if l.fn.__name__ == "rf_conv_gemm":
                     d = l.keep[0]
                     r.update(M=d.M, N=d.N, K=d.K, act=d.act, batch=d.batch)

@@ -101,6 +101,14 @@ int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream);
  * nn.GroupNorm (util.py:214-216) over a tensor this GEMM has just produced. */
 int rf_conv_gemm_plan(const rf_conv_gemm_desc* d, int32_t* bm, int32_t* bn, int32_t* splitk);
 
+/* Fused transformer feed-forward at C = 320 (the 64x64 level):  out = (GEGLU(x W1^T + b1)) W2^T + b2 + residual, bf16 in / out, fp32
+ * accumulate, GELU on the tanh form (the bf16 mode's).  The [M, 4C] hidden tensor stays in registers (tokens on lanes, see ffn.hip).
+ *   w1p / b1p : ff.net.0.proj [8C, C] / [8C] with rows interleaved in blocks of 32 (value | gate), as rf_conv_gemm's GEGLU takes them
+ *   w2q       : ff.net.2 [C, 4C] with the columns of every 16-group in the order 0-3, 8-11, 4-7, 12-15
+ * Replaces FeedForward.forward (attention.py:40-76) + the residual add of BasicTransformerBlock (attention.py:243). */
+int rf_ffn_geglu(const void* x, int ldx, const void* w1p, const float* b1p, const void* w2q, const float* b2, const void* residual, int ldr,
+                 void* out, int ldo, int M, int C, void* stream);
+
 /* Per-row fp8 quantisation of a weight matrix for the w_dtype = RF_FP8_E4M3 path: w [N][K] fp32 (row pitch K) ->
  * q [N][ldq] e4m3fn bytes (ldq >= K, a multiple of 128; the pad bytes are written as zero) and scale [N] = the smallest power of
  * two with max|w[n,:]| / scale <= 448 (e4m3fn's largest finite value); q = round-to-nearest-even(w / scale), saturating.

@@ -1,0 +1,263 @@
+// Fused transformer feed-forward  out = (GEGLU(x W1^T + b1)) W2^T + b2 + residual   (attention.py:40-76: FeedForward with GEGLU)
+// for C = 320 (the 64x64 level, M = 65536 tokens per CFG batch of 16): the [M, 4C] hidden tensor -- 168 MB written by the GEGLU GEMM
+// and read back by ff.net.2 in the unfused form -- never leaves the CU.
+//
+// Everything is computed TRANSPOSED, tokens on lanes (the flash-attention trick of attention.hip):
+//   S^T[hidden, tok]  = W1c[hidden, :] . X^T[:, tok]     MFMA A = W1 rows (LDS, streamed), B = X rows (LDS, resident)
+//   H^T               = value * gelu(gate)               in registers: value / gate blocks have the same (lane, register) map
+//   O^T[n, tok]      += W2[n, hidden] . H^T[hidden, tok]  MFMA A = W2 rows (LDS, streamed), B = H^T straight from registers
+// The K order a register-fed B operand implies (rows 0-3, 8-11 | 4-7, 12-15 of each 16) is absorbed by the host-side column order
+// of W2; the W2 rows of a 32-row block are read in the permuted order of gemm.hip's direct epilogue, so a lane ends with 16
+// contiguous output columns of its token: bias + residual + 16-byte stores straight from registers.
+//
+// Block = 4 waves = 128 tokens, ONE wave per SIMD (up to 512 VGPRs: 160 output + 64 hidden accumulators).  LDS: X tile 80 KB
+// (resident), W1 K-tiles 2 x 16 KB, W2 chunk 40 KB, per-wave bias slots -- 156 KB.  Hidden dimension in chunks of 64 (20 chunks).
+#include "common.h"
+
+namespace rf {
+
+struct FfnParams {
+    const bf16_t* x; int ldx;
+    const bf16_t* w1; const float* b1;       // [8C][C] GEGLU-packed rows (32 value | 32 gate), [8C]
+    const bf16_t* w2; const float* b2;       // [C][4C] hidden columns permuted inside every 16-group, [C]
+    const bf16_t* res; int ldr;
+    bf16_t* out; int ldo;
+    int M;
+};
+
+__device__ __forceinline__ int ffn_lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+template <int C>
+__global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
+    constexpr int CK = C / 64;               // K tiles of GEMM 1
+    constexpr int NB = C / 32;               // 32-row blocks of the output (transposed)
+    constexpr int F = 4 * C;                 // hidden width
+    constexpr int NCH = F / 64;              // hidden chunks of 64
+    constexpr int XB = CK * 16384, W1B = 16384, W2B = C * 128;
+    constexpr int OFF_W1 = XB, OFF_W2 = XB + 2 * W1B, OFF_B = OFF_W2 + W2B;     // bias slots: [2 stages][4 waves][128 floats]
+    constexpr int NPX = CK * 16 / 4, NPW1 = 4, NPW2 = C / 8 / 4, NPB = 2;        // DMA pieces per wave
+    static_assert(OFF_B + 2 * 4 * 512 <= 160 * 1024, "LDS budget");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    // XCD-aware block order (as gemm.hip): XCD x owns a contiguous run of token tiles
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = bid * 128;
+
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)(((long long)(p.M - 1) * p.ldx + C) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, (unsigned)(2 * F * C * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (unsigned)(C * F * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.b1, 0, (unsigned)(2 * F * 4), 0x00020000);
+    constexpr int OOB = 0x7fffffff;
+    // a DMA piece = 8 rows x 128 B written lane-linearly; lane l lands on row (l >> 3), 16-byte position (l & 7) and fetches k-slot
+    // (l & 7) ^ swizzle(row): the XOR swizzle lives on the source side
+    const int prow = lane >> 3;
+    auto kslot = [&](int row) { return ((lane & 7) ^ ((row >> 1) & 7)) * 16; };
+
+    // ---- DMA issue helpers (every wave issues the same number of pieces: counted vmcnt waits are wave-uniform)
+    auto issue_x = [&]() {
+#pragma unroll
+        for (int q = 0; q < NPX; ++q) {
+            const int pc = wave + 4 * q;                 // piece index: (K tile, row group)
+            const int kt = pc / 16, row = (pc % 16) * 8 + prow;
+            const int off = (m0 + row < p.M) ? (m0 + row) * p.ldx * 2 + kt * 128 + kslot(row) : OOB;
+            char* dst = smem + kt * 16384 + (pc % 16) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
+        }
+    };
+    auto issue_w1 = [&](int g) {                          // global W1 tile index g = chunk * CK + kt
+        const int c = g / CK, kt = g - c * CK;
+        char* base = smem + OFF_W1 + (g & 1) * W1B;
+#pragma unroll
+        for (int q = 0; q < NPW1; ++q) {
+            const int rg = wave + 4 * q, row = rg * 8 + prow;                     // row inside the 128-row chunk
+            const int off = (c * 128 + row) * C * 2 + kslot(row);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (__attribute__((address_space(3))) void*)(base + rg * 1024), 16, off, kt * 128, 0, 0);
+        }
+    };
+    auto issue_w2 = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < NPW2; ++q) {
+            const int rg = wave + 4 * q, row = rg * 8 + prow;
+            const int off = row * F * 2 + kslot(row);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (__attribute__((address_space(3))) void*)(smem + OFF_W2 + rg * 1024), 16, off, c * 128, 0, 0);
+        }
+    };
+    auto issue_b1 = [&](int c) {                          // this wave's private copy of the chunk's 128 bias values (2 x 64 floats)
+        char* base = smem + OFF_B + ((c & 1) * 4 + wave) * 512;
+#pragma unroll
+        for (int q = 0; q < NPB; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB1, (__attribute__((address_space(3))) void*)(base + q * 256), 4, (c * 128 + q * 64 + lane) * 4, 0, 0, 0);
+    };
+
+    // ---- prologue: X tile, W1 tiles 0 and 1, W2 chunk 0, bias chunk 0
+    issue_x();
+    issue_w1(0);
+    issue_w1(1);
+    issue_w2(0);
+    issue_b1(0);
+
+    f32x16_t acc2[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
+
+    // fragment addressing
+    const int tok = wave * 32 + lrow;                     // this lane's token row inside the X tile
+    const int xsw = (tok >> 1) & 7, wsw = (lrow >> 1) & 7;
+    const int brow = 16 * ((lrow >> 2) & 1) + 4 * (lrow >> 3) + (lrow & 3);     // permuted W2 row (see gemm.hip EPI = 1)
+    const int bsw = (brow >> 1) & 7;
+    const char* const xbase = smem + tok * 128;
+    const char* const w2base = smem + OFF_W2 + brow * 128;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int g = 0;                                            // global W1 tile counter
+    for (int c = 0; c < NCH; ++c) {
+        f32x16_t acc1[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[b][r] = 0.f;
+        // ---- GEMM 1: S^T (128 packed rows x 32 tokens per wave) over K = C
+#pragma unroll 1
+        for (int kt = 0; kt < CK; ++kt, ++g) {
+            const char* const w1base = smem + OFF_W1 + (g & 1) * W1B + lrow * 128;
+            u32x4_t xf[2], wf[2][4];
+            xf[0] = *(const u32x4_t*)(xbase + kt * 16384 + (((0 + lhalf) ^ xsw) << 4));
+#pragma unroll
+            for (int b = 0; b < 4; ++b) wf[0][b] = *(const u32x4_t*)(w1base + b * 4096 + (((0 + lhalf) ^ wsw) << 4));
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int cur = kk & 1, nx = cur ^ 1;
+                if (kk < 3) {
+                    xf[nx] = *(const u32x4_t*)(xbase + kt * 16384 + ((((kk + 1) * 2 + lhalf) ^ xsw) << 4));
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) wf[nx][b] = *(const u32x4_t*)(w1base + b * 4096 + ((((kk + 1) * 2 + lhalf) ^ wsw) << 4));
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc1[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[cur][b]), __builtin_bit_cast(bf16x8_t, xf[cur]), acc1[b], 0, 0, 0);
+            }
+            // tile g+1 must have landed (loads complete in order: younger W2 / bias pieces may stay in flight), every wave must be
+            // done with this stage before tile g+2 overwrites it
+            if (kt == 0 && c > 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPW2 + NPB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (g + 2 < NCH * CK) issue_w1(g + 2);
+        }
+        // ---- GEGLU in registers: h = (value + bv) * gelu(gate + bg), packed to the B fragments of GEMM 2
+        u32x4_t hb[4];
+        {
+            const float* const bl = (const float*)(smem + OFF_B + ((c & 1) * 4 + wave) * 512);
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                float h[16];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4_t bv = *(const f32x4_t*)(bl + pr * 64 + 8 * q4 + 4 * lhalf), bg = *(const f32x4_t*)(bl + pr * 64 + 32 + 8 * q4 + 4 * lhalf);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * q4 + e;
+                        h[r] = (acc1[2 * pr][r] + bv[e]) * gelu_tanh_fast(acc1[2 * pr + 1][r] + bg[e]);
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hb[2 * pr + s2][e] = pack_bf2(h[8 * s2 + 2 * e], h[8 * s2 + 2 * e + 1]);
+            }
+        }
+        // ---- GEMM 2: O^T += W2c . H^T  (the W2 chunk landed several K tiles ago: every vmcnt(0) since covered it)
+        {
+            u32x4_t af[2];
+            af[0] = *(const u32x4_t*)(w2base + (((0 + lhalf) ^ bsw) << 4));
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int it = kk * NB + nb, cur = it & 1;
+                    if (it + 1 < 4 * NB) {
+                        const int nkk = (it + 1) / NB, nnb = (it + 1) % NB;
+                        af[cur ^ 1] = *(const u32x4_t*)(w2base + nnb * 4096 + (((nkk * 2 + lhalf) ^ bsw) << 4));
+                    }
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[cur]), __builtin_bit_cast(bf16x8_t, hb[kk]), acc2[nb], 0, 0, 0);
+                }
+            }
+        }
+        // the W2 buffer and this chunk's bias slot are free once every wave is here
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (c + 1 < NCH) {
+            issue_w2(c + 1);
+            issue_b1(c + 1);
+        }
+    }
+
+    // ---- epilogue: lane (token, half) holds output columns 32*nb + 16*half + r; b2 parked in LDS (the operand stages are dead)
+    float* const b2l = (float*)smem;
+    for (int i = tid; i < C; i += 256) b2l[i] = p.b2[i];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int row = m0 + tok;
+    constexpr int PFD = 4;
+    u32x4_t rq[PFD][2];
+    auto load_res = [&](int nb, u32x4_t* r) {
+        if (p.res && row < p.M) {
+            const u32x4_t* rp = (const u32x4_t*)(p.res + (long long)row * p.ldr + nb * 32 + lhalf * 16);
+            r[0] = rp[0];
+            r[1] = rp[1];
+        }
+    };
+#pragma unroll
+    for (int nb = 0; nb < PFD; ++nb) load_res(nb, rq[nb]);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int col = nb * 32 + lhalf * 16;
+        if (row < p.M) {
+            bf16_t* dst = p.out + (long long)row * p.ldo + col;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float f[8], v[8];
+                const f32x4_t c0 = *(const f32x4_t*)(b2l + col + 8 * h), c1 = *(const f32x4_t*)(b2l + col + 8 * h + 4);
+                if (p.res) unpack16<bf16_t>(rq[nb % PFD][h], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc2[nb][8 * h + e] + (e < 4 ? c0[e] : c1[e - 4]) + (p.res ? f[e] : 0.f);
+                ((u32x4_t*)dst)[h] = pack16<bf16_t>(v);
+            }
+        }
+        if (nb + PFD < NB) load_res(nb + PFD, rq[nb % PFD]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+}  // namespace rf
+
+extern "C" int rf_ffn_geglu(const void* x, int ldx, const void* w1p, const float* b1p, const void* w2q, const float* b2, const void* residual,
+                            int ldr, void* out, int ldo, int M, int C, void* stream) {
+    using namespace rf;
+    RF_CHECK(x && w1p && b1p && w2q && b2 && out && M > 0, "rf_ffn_geglu: bad arguments");
+    RF_CHECK(C == 320, "rf_ffn_geglu: built for C = 320 (the 64x64 level), got %d", C);
+    RF_CHECK(ldx % 8 == 0 && ldo % 8 == 0 && (!residual || ldr % 8 == 0), "rf_ffn_geglu: row pitches must be multiples of 8");
+    RF_CHECK(((uintptr_t)x | (uintptr_t)w1p | (uintptr_t)w2q | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)b1p | (uintptr_t)b2) % 16 == 0,
+             "rf_ffn_geglu: operands must be 16-byte aligned");
+    RF_CHECK((long long)M * ldx * 2 < 0x7fff0000LL, "rf_ffn_geglu: x too large for 31-bit byte offsets");
+    FfnParams p;
+    p.x = (const bf16_t*)x; p.ldx = ldx; p.w1 = (const bf16_t*)w1p; p.b1 = b1p; p.w2 = (const bf16_t*)w2q; p.b2 = b2;
+    p.res = (const bf16_t*)residual; p.ldr = ldr; p.out = (bf16_t*)out; p.ldo = ldo; p.M = M;
+    constexpr int smem = 5 * 16384 + 2 * 16384 + 320 * 128 + 2 * 4 * 512;
+    auto k = ffn_geglu_kernel<320>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+    hipLaunchKernelGGL(k, dim3((M + 127) / 128), dim3(256), smem, (hipStream_t)stream, p);
+    RF_LAUNCH_CHECK("rf_ffn_geglu");
+    return 0;
+}

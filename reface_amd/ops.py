@@ -74,6 +74,30 @@ def pack_geglu(w, b, dtype):
     return wp.to(dtype).contiguous(), bp.float().contiguous()
 
 
+FFN_W2_PERM = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
+
+
+def pack_ffn_w2(w2, dtype=torch.bfloat16):
+    """ff.net.2 weight [C, 4C] -> the hidden-column order rf_ffn_geglu multiplies in (every 16-group: 0-3, 8-11, 4-7, 12-15: the K order a
+    register-fed MFMA B operand implies)."""
+    c, f = w2.shape
+    idx = (torch.arange(f // 16)[:, None] * 16 + torch.tensor(FFN_W2_PERM)[None]).reshape(-1).to(w2.device)
+    return w2[:, idx].to(dtype).contiguous()
+
+
+def ffn_geglu(x, w1p, b1p, w2q, b2, out, *, residual=None, name="ffn_geglu"):
+    """out[M, C] = (GEGLU(x W1^T + b1)) W2^T + b2 (+ residual), one kernel, hidden tensor on chip (C = 320, bf16)."""
+    lib = _lib.load()
+    _require_gpu(x, w1p, b1p, w2q, b2, out, residual)
+    M, Cc = x.shape
+    assert x.dtype == w1p.dtype == w2q.dtype == out.dtype == torch.bfloat16 and b1p.dtype == b2.dtype == torch.float32
+    assert w1p.shape == (8 * Cc, Cc) and w2q.shape == (Cc, 4 * Cc) and w1p.is_contiguous() and w2q.is_contiguous()
+    assert x.stride(1) == 1 and out.stride(1) == 1 and (residual is None or (residual.stride(1) == 1 and residual.dtype == out.dtype))
+    return Launch(lib.rf_ffn_geglu, (_p(x), x.stride(0), _p(w1p), _p(b1p), _p(w2q), _p(b2), _p(residual),
+                                     residual.stride(0) if residual is not None else 0, _p(out), out.stride(0), M, Cc),
+                  (x, w1p, b1p, w2q, b2, out, residual), name)
+
+
 class Fp8Weight:
     """A weight matrix in the fp8 storage of BASELINE configs[4]: ``q`` [N, ldq] uint8 holding OCP e4m3fn bytes (rows zero-padded
     to a multiple of 128), ``scale`` [N] fp32 powers of two; w[n, k] = fp8(q[n, k]) * scale[n]."""

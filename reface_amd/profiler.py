@@ -26,6 +26,14 @@ def gemm_flops(l):
     return 2.0 * d.M * d.N * min(k_real, d.K) * d.batch
 
 
+def ffn_flops(l):
+    """rf_ffn_geglu: 2*M*C*8C (GEGLU projection) + 2*M*4C*C (ff.net.2)."""
+    if l.fn.__name__ != "rf_ffn_geglu":
+        return 0.0
+    M, C_ = l.args[10], l.args[11]
+    return 2.0 * M * C_ * 8 * C_ + 2.0 * M * 4 * C_ * C_
+
+
 def attention_flops(l):
     if l.fn.__name__ != "rf_attention":
         return 0.0
@@ -60,7 +68,7 @@ def summarize(timed):
         f = fam.setdefault(launch_family(l), dict(calls=0, ms=0.0, flops=0.0))
         f["calls"] += 1
         f["ms"] += ms
-        f["flops"] += gemm_flops(l) + attention_flops(l)
+        f["flops"] += gemm_flops(l) + attention_flops(l) + ffn_flops(l)
     for f in fam.values():
         f["tflops_per_s"] = (f["flops"] / (f["ms"] * 1e-3) / 1e12) if f["ms"] > 0 else 0.0
     return fam

@@ -83,6 +83,8 @@ class UNetEngine:
         self.korder_on = os.environ.get("REFACE_KORDER", "0") == "1"
         # GroupNorm statistics come out of the epilogue of the GEMM that produced the tensor wherever its tile plan allows
         self.gn_fuse = os.environ.get("REFACE_GN_FUSE", "1") == "1"
+        # GEGLU + ff.net.2 of the C = 320 transformer blocks as one kernel (bf16 mode)
+        self.ffn_fuse = os.environ.get("REFACE_FFN_FUSE", "1") == "1"
         self.gn_fused = 0
         self.pool = _Pool(device)
         self.tracker = ProducerTracker()
@@ -291,12 +293,19 @@ class UNetEngine:
             ln = self.pool.get((nb * M, c), self.dt)
         self.main.append(ops.layernorm(x1, self.f32(f"{t}.norm3.weight"), self.f32(f"{t}.norm3.bias"), ln, name=f"{t}.norm3"))
         wg, bg = ops.pack_geglu(self.sd[f"{t}.ff.net.0.proj.weight"], self.sd[f"{t}.ff.net.0.proj.bias"], F32)
-        wg = self.gw(wg)
-        gg = self.pool.get((nb * M, 4 * c), self.dt)
-        self.main.append(ops.linear(ln, wg, gg, bg, act=ops.ACT_GEGLU, name=f"{t}.ff.net.0"))
-        x2 = ln
-        self.main.append(ops.linear(gg, self.gw(self.sd[f"{t}.ff.net.2.weight"]), x2, self.f32(f"{t}.ff.net.2.bias"), residual=x1, name=f"{t}.ff.net.2"))
-        self.pool.put(gg)
+        if self.ffn_fuse and c == 320 and self.dt == torch.bfloat16 and not self.w8:
+            # one kernel: the [M, 4C] hidden tensor (168 MB at 64x64) stays in registers (csrc/ffn.hip)
+            x2 = self.pool.get((nb * M, c), self.dt)
+            self.main.append(ops.ffn_geglu(ln, wg.to(self.dt).contiguous(), bg, ops.pack_ffn_w2(self.sd[f"{t}.ff.net.2.weight"], self.dt),
+                                           self.f32(f"{t}.ff.net.2.bias"), x2, residual=x1, name=f"{t}.ff"))
+            self.pool.put(ln)
+        else:
+            wg = self.gw(wg)
+            gg = self.pool.get((nb * M, 4 * c), self.dt)
+            self.main.append(ops.linear(ln, wg, gg, bg, act=ops.ACT_GEGLU, name=f"{t}.ff.net.0"))
+            x2 = ln
+            self.main.append(ops.linear(gg, self.gw(self.sd[f"{t}.ff.net.2.weight"]), x2, self.f32(f"{t}.ff.net.2.bias"), residual=x1, name=f"{t}.ff.net.2"))
+            self.pool.put(gg)
         self.pool.put(x1)
         y = dst if dst is not None else self.pool.get((nb * B, H, W, c), self.dt)
         w_po, b_po = self.gw(self.sd[f"{p}.proj_out.weight"].reshape(c, c)), self.f32(f"{p}.proj_out.bias")

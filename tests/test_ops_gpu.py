@@ -420,3 +420,32 @@ def test_conv_fp8_weights():
     wd = fw.dequant().cpu().reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
     ref = _conv_ref(xr, wd, b, 1, (1, 1, 1, 1), 0)
     check(out, ref, dt)
+
+
+@pytest.mark.parametrize("M", [128, 300, 4096])
+def test_ffn_geglu_fused(M):
+    """rf_ffn_geglu (C = 320): GEGLU projection + ff.net.2 + residual in one kernel, against an fp32 reference on the bf16-rounded operands
+    (with the hidden activations rounded to bf16, as both the fused and the unfused path store / feed them) and against the two unfused
+    rf_conv_gemm launches."""
+    dt, Cc = torch.bfloat16, 320
+    x, xr = q(rnd((M, Cc), 80) * 0.7, dt)
+    w1 = rnd((8 * Cc, Cc), 81) / math.sqrt(Cc)
+    b1 = rnd((8 * Cc,), 82) * 0.5
+    w2 = rnd((Cc, 4 * Cc), 83) / math.sqrt(4 * Cc)
+    b2 = rnd((Cc,), 84)
+    res, rr = q(rnd((M, Cc), 85), dt)
+    w1p, b1p = ops.pack_geglu(w1, b1, dt)
+    out = torch.empty((M, Cc), dtype=dt, device=DEV)
+    ops.ffn_geglu(x, w1p.to(DEV), b1p.to(DEV), ops.pack_ffn_w2(w2.to(DEV), dt), b2.to(DEV), out, residual=res)()
+    # unfused: the same two GEMMs through rf_conv_gemm
+    hid = torch.empty((M, 4 * Cc), dtype=dt, device=DEV)
+    out_u = torch.empty_like(out)
+    ops.linear(x, w1p.to(DEV), hid, b1p.to(DEV), act=ops.ACT_GEGLU)()
+    ops.linear(hid, w2.to(dt).to(DEV), out_u, b2.to(DEV), residual=res)()
+    torch.cuda.synchronize()
+    h = F.linear(xr, w1.to(dt).float(), b1)
+    a, g = h.chunk(2, -1)
+    hid_ref = (a * F.gelu(g, approximate="tanh")).to(dt).float()
+    ref = F.linear(hid_ref, w2.to(dt).float(), b2) + rr
+    check(out, ref, dt)
+    assert (out.float() - out_u.float()).abs().max().item() <= 2.0 ** -6 * max(1.0, ref.abs().max().item())       # <= 2 bf16 ulps apart

@@ -82,6 +82,20 @@ def ln(name, M, c):
     cases.append((name, ops.layernorm(x, g, b, out, name=name), -2.0 * x.numel() * x.element_size()))
 
 
+def ffn(name, M, C):
+    x = r(M, C)
+    w1 = r(8 * C, C, scale=1 / math.sqrt(C))
+    b1 = r(8 * C, dtype=torch.float32)
+    w2 = r(C, 4 * C, scale=1 / math.sqrt(4 * C))
+    b2 = r(C, dtype=torch.float32)
+    res = r(M, C)
+    out = torch.empty(M, C, device=dev, dtype=dt)
+    w1p, b1p = ops.pack_geglu(w1.float(), b1, dt)
+    cases.append((name, ops.ffn_geglu(x, w1p, b1p, ops.pack_ffn_w2(w2, dt), b2, out, residual=res, name=name), 2.0 * M * C * 8 * C + 2.0 * M * 4 * C * C))
+
+
+if dt == torch.bfloat16:
+    ffn("ffn fused 320 @64", Bc * 4096, 320)
 conv("conv3x3 320->320 @64", 320, 320, 64)
 conv("conv3x3 640->640 @32", 640, 640, 32)
 conv("conv3x3 1280->1280 @16", 1280, 1280, 16)
