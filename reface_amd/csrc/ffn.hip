@@ -3,15 +3,16 @@
 // and read back by ff.net.2 in the unfused form -- never leaves the CU.
 //
 // Everything is computed TRANSPOSED, tokens on lanes (the flash-attention trick of attention.hip):
-//   S^T[hidden, tok]  = W1c[hidden, :] . X^T[:, tok]     MFMA A = W1 rows (LDS, streamed), B = X rows (LDS, resident)
+//   S^T[hidden, tok]  = W1c[hidden, :] . X^T[:, tok]     MFMA A = W1 rows (LDS, streamed), B = X rows (registers, resident)
 //   H^T               = value * gelu(gate)               in registers: value / gate blocks have the same (lane, register) map
 //   O^T[n, tok]      += W2[n, hidden] . H^T[hidden, tok]  MFMA A = W2 rows (LDS, streamed), B = H^T straight from registers
 // The K order a register-fed B operand implies (rows 0-3, 8-11 | 4-7, 12-15 of each 16) is absorbed by the host-side column order
 // of W2; the W2 rows of a 32-row block are read in the permuted order of gemm.hip's direct epilogue, so a lane ends with 16
 // contiguous output columns of its token: bias + residual + 16-byte stores straight from registers.
 //
-// Block = 4 waves = 128 tokens, ONE wave per SIMD (up to 512 VGPRs: 160 output + 64 hidden accumulators).  LDS: X tile 80 KB
-// (resident), W1 K-tiles 2 x 16 KB, W2 chunk 40 KB, per-wave bias slots -- 156 KB.  Hidden dimension in chunks of 64 (20 chunks).
+// Block = 4 waves = 128 tokens, ONE wave per SIMD (up to 512 VGPRs: 160 output + 64 hidden accumulators + the wave's 80 registers of
+// X^T fragments, resident for the whole block).  LDS holds weights only: a 4-stage ring of W1 K tiles (64 KB), two W2 chunks (80 KB),
+// per-wave bias slots -- 148 KB.  Hidden dimension in chunks of 64 (20 chunks).
 #include "common.h"
 
 namespace rf {
@@ -33,9 +34,11 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
     constexpr int NB = C / 32;               // 32-row blocks of the output (transposed)
     constexpr int F = 4 * C;                 // hidden width
     constexpr int NCH = F / 64;              // hidden chunks of 64
-    constexpr int XB = CK * 16384, W1B = 16384, W2B = C * 128;
-    constexpr int OFF_W1 = XB, OFF_W2 = XB + 2 * W1B, OFF_B = OFF_W2 + W2B;     // bias slots: [2 stages][4 waves][128 floats]
-    constexpr int NPX = CK * 16 / 4, NPW1 = 4, NPW2 = C / 8 / 4, NPB = 2;        // DMA pieces per wave
+    constexpr int NS1 = 4;                   // W1 ring: three tiles in flight behind the one being multiplied (one wave per SIMD: nobody
+                                             // else covers an L2 round trip, a 2-stage ring stalls ~2k cycles per K tile)
+    constexpr int W1B = 16384, W2B = C * 128;
+    constexpr int OFF_W2 = NS1 * W1B, OFF_B = OFF_W2 + 2 * W2B;                 // bias slots: [2 stages][4 waves][128 floats]
+    constexpr int NPW1 = 4, NPW2 = C / 8 / 4, NPB = 2;                          // DMA pieces per wave
     static_assert(OFF_B + 2 * 4 * 512 <= 160 * 1024, "LDS budget");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -49,44 +52,43 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int m0 = bid * 128;
+    const int tok = wave * 32 + lrow;                     // this lane's token inside the block
+    const int row = m0 + tok;
 
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)(((long long)(p.M - 1) * p.ldx + C) * 2), 0x00020000);
+    // ---- X^T fragments of this wave's 32 tokens: the B operand of GEMM 1, resident in registers (20 k-steps x 16 bytes per lane)
+    u32x4_t xq[CK * 4];
+#pragma unroll
+    for (int s_ = 0; s_ < CK * 4; ++s_) {
+        xq[s_] = u32x4_t{0u, 0u, 0u, 0u};
+        if (row < p.M) xq[s_] = *(const u32x4_t*)(p.x + (long long)row * p.ldx + s_ * 16 + lhalf * 8);
+    }
+
     const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, (unsigned)(2 * F * C * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (unsigned)(C * F * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.b1, 0, (unsigned)(2 * F * 4), 0x00020000);
-    constexpr int OOB = 0x7fffffff;
     // a DMA piece = 8 rows x 128 B written lane-linearly; lane l lands on row (l >> 3), 16-byte position (l & 7) and fetches k-slot
     // (l & 7) ^ swizzle(row): the XOR swizzle lives on the source side
     const int prow = lane >> 3;
-    auto kslot = [&](int row) { return ((lane & 7) ^ ((row >> 1) & 7)) * 16; };
+    auto kslot = [&](int r) { return ((lane & 7) ^ ((r >> 1) & 7)) * 16; };
 
-    // ---- DMA issue helpers (every wave issues the same number of pieces: counted vmcnt waits are wave-uniform)
-    auto issue_x = [&]() {
-#pragma unroll
-        for (int q = 0; q < NPX; ++q) {
-            const int pc = wave + 4 * q;                 // piece index: (K tile, row group)
-            const int kt = pc / 16, row = (pc % 16) * 8 + prow;
-            const int off = (m0 + row < p.M) ? (m0 + row) * p.ldx * 2 + kt * 128 + kslot(row) : OOB;
-            char* dst = smem + kt * 16384 + (pc % 16) * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
-        }
-    };
+    // ---- DMA issue helpers (every wave issues the same number of pieces: the counted vmcnt waits are wave-uniform)
     auto issue_w1 = [&](int g) {                          // global W1 tile index g = chunk * CK + kt
         const int c = g / CK, kt = g - c * CK;
-        char* base = smem + OFF_W1 + (g & 1) * W1B;
+        char* base = smem + (g % NS1) * W1B;
 #pragma unroll
         for (int q = 0; q < NPW1; ++q) {
-            const int rg = wave + 4 * q, row = rg * 8 + prow;                     // row inside the 128-row chunk
-            const int off = (c * 128 + row) * C * 2 + kslot(row);
+            const int rg = wave + 4 * q, r = rg * 8 + prow;                       // row inside the 128-row chunk
+            const int off = (c * 128 + r) * C * 2 + kslot(r);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (__attribute__((address_space(3))) void*)(base + rg * 1024), 16, off, kt * 128, 0, 0);
         }
     };
     auto issue_w2 = [&](int c) {
+        char* base = smem + OFF_W2 + (c & 1) * W2B;
 #pragma unroll
         for (int q = 0; q < NPW2; ++q) {
-            const int rg = wave + 4 * q, row = rg * 8 + prow;
-            const int off = row * F * 2 + kslot(row);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (__attribute__((address_space(3))) void*)(smem + OFF_W2 + rg * 1024), 16, off, c * 128, 0, 0);
+            const int rg = wave + 4 * q, r = rg * 8 + prow;
+            const int off = r * F * 2 + kslot(r);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (__attribute__((address_space(3))) void*)(base + rg * 1024), 16, off, c * 128, 0, 0);
         }
     };
     auto issue_b1 = [&](int c) {                          // this wave's private copy of the chunk's 128 bias values (2 x 64 floats)
@@ -96,10 +98,9 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB1, (__attribute__((address_space(3))) void*)(base + q * 256), 4, (c * 128 + q * 64 + lane) * 4, 0, 0, 0);
     };
 
-    // ---- prologue: X tile, W1 tiles 0 and 1, W2 chunk 0, bias chunk 0
-    issue_x();
-    issue_w1(0);
-    issue_w1(1);
+    // ---- prologue: W1 tiles 0 .. NS1-1, W2 chunk 0, bias chunk 0
+#pragma unroll
+    for (int g = 0; g < NS1; ++g) issue_w1(g);
     issue_w2(0);
     issue_b1(0);
 
@@ -110,49 +111,51 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
         for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
 
     // fragment addressing
-    const int tok = wave * 32 + lrow;                     // this lane's token row inside the X tile
-    const int xsw = (tok >> 1) & 7, wsw = (lrow >> 1) & 7;
+    const int wsw = (lrow >> 1) & 7;
     const int brow = 16 * ((lrow >> 2) & 1) + 4 * (lrow >> 3) + (lrow & 3);     // permuted W2 row (see gemm.hip EPI = 1)
     const int bsw = (brow >> 1) & 7;
-    const char* const xbase = smem + tok * 128;
-    const char* const w2base = smem + OFF_W2 + brow * 128;
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    int g = 0;                                            // global W1 tile counter
     for (int c = 0; c < NCH; ++c) {
         f32x16_t acc1[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[b][r] = 0.f;
+        const bool last = c == NCH - 1;
         // ---- GEMM 1: S^T (128 packed rows x 32 tokens per wave) over K = C
-#pragma unroll 1
-        for (int kt = 0; kt < CK; ++kt, ++g) {
-            const char* const w1base = smem + OFF_W1 + (g & 1) * W1B + lrow * 128;
-            u32x4_t xf[2], wf[2][4];
-            xf[0] = *(const u32x4_t*)(xbase + kt * 16384 + (((0 + lhalf) ^ xsw) << 4));
+#pragma unroll
+        for (int kt = 0; kt < CK; ++kt) {
+            const int g = c * CK + kt;
+            const char* const w1base = smem + (g % NS1) * W1B + lrow * 128;
+            u32x4_t wf[2][4];
 #pragma unroll
             for (int b = 0; b < 4; ++b) wf[0][b] = *(const u32x4_t*)(w1base + b * 4096 + (((0 + lhalf) ^ wsw) << 4));
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int cur = kk & 1, nx = cur ^ 1;
                 if (kk < 3) {
-                    xf[nx] = *(const u32x4_t*)(xbase + kt * 16384 + ((((kk + 1) * 2 + lhalf) ^ xsw) << 4));
 #pragma unroll
                     for (int b = 0; b < 4; ++b) wf[nx][b] = *(const u32x4_t*)(w1base + b * 4096 + ((((kk + 1) * 2 + lhalf) ^ wsw) << 4));
                 }
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
-                    acc1[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[cur][b]), __builtin_bit_cast(bf16x8_t, xf[cur]), acc1[b], 0, 0, 0);
+                    acc1[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[cur][b]), __builtin_bit_cast(bf16x8_t, xq[kt * 4 + kk]), acc1[b], 0, 0, 0);
             }
-            // tile g+1 must have landed (loads complete in order: younger W2 / bias pieces may stay in flight), every wave must be
-            // done with this stage before tile g+2 overwrites it
-            if (kt == 0 && c > 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPW2 + NPB) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (g + 2 < NCH * CK) issue_w1(g + 2);
+            // Tile g+1 must have landed.  Loads complete in order, so it suffices that at most the pieces issued AFTER it are still in
+            // flight: W1(g+2), W1(g+3) (8 pieces) and, for kt = 1..3, the W2 / bias group of the next chunk issued behind W1(g0+4).
+            // The last chunk drains everything (the ring is running empty there).
+            if (last) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else if (kt >= 1 && kt <= 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NPW1 + NPW2 + NPB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NPW1) : "memory");
+            __builtin_amdgcn_s_barrier();                 // every wave is done with tile g: its stage may be refilled
+            if (g + NS1 < NCH * CK) issue_w1(g + NS1);
+            if (kt == 0 && !last) {
+                issue_w2(c + 1);                          // buffer (c+1)&1 was last read by GEMM 2 of chunk c-1 (barrier at its end)
+                issue_b1(c + 1);
+            }
         }
         // ---- GEGLU in registers: h = (value + bv) * gelu(gate + bg), packed to the B fragments of GEMM 2
         u32x4_t hb[4];
@@ -176,8 +179,9 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
                     for (int e = 0; e < 4; ++e) hb[2 * pr + s2][e] = pack_bf2(h[8 * s2 + 2 * e], h[8 * s2 + 2 * e + 1]);
             }
         }
-        // ---- GEMM 2: O^T += W2c . H^T  (the W2 chunk landed several K tiles ago: every vmcnt(0) since covered it)
+        // ---- GEMM 2: O^T += W2c . H^T  (the W2 chunk was issued a whole chunk ago; the waits of K tiles 0 and 4 covered it)
         {
+            const char* const w2base = smem + OFF_W2 + (c & 1) * W2B + brow * 128;
             u32x4_t af[2];
             af[0] = *(const u32x4_t*)(w2base + (((0 + lhalf) ^ bsw) << 4));
 #pragma unroll
@@ -193,13 +197,9 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
                 }
             }
         }
-        // the W2 buffer and this chunk's bias slot are free once every wave is here
+        // this chunk's W2 buffer and bias slot are free once every wave is here (they are refilled at K tile 0 of chunk c+1)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (c + 1 < NCH) {
-            issue_w2(c + 1);
-            issue_b1(c + 1);
-        }
     }
 
     // ---- epilogue: lane (token, half) holds output columns 32*nb + 16*half + r; b2 parked in LDS (the operand stages are dead)
@@ -207,7 +207,6 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
     for (int i = tid; i < C; i += 256) b2l[i] = p.b2[i];
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const int row = m0 + tok;
     constexpr int PFD = 4;
     u32x4_t rq[PFD][2];
     auto load_res = [&](int nb, u32x4_t* r) {
@@ -253,7 +252,7 @@ extern "C" int rf_ffn_geglu(const void* x, int ldx, const void* w1p, const float
     FfnParams p;
     p.x = (const bf16_t*)x; p.ldx = ldx; p.w1 = (const bf16_t*)w1p; p.b1 = b1p; p.w2 = (const bf16_t*)w2q; p.b2 = b2;
     p.res = (const bf16_t*)residual; p.ldr = ldr; p.out = (bf16_t*)out; p.ldo = ldo; p.M = M;
-    constexpr int smem = 5 * 16384 + 2 * 16384 + 320 * 128 + 2 * 4 * 512;
+    constexpr int smem = 4 * 16384 + 2 * 320 * 128 + 2 * 4 * 512;
     auto k = ffn_geglu_kernel<320>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }

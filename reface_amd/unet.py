@@ -83,8 +83,10 @@ class UNetEngine:
         self.korder_on = os.environ.get("REFACE_KORDER", "0") == "1"
         # GroupNorm statistics come out of the epilogue of the GEMM that produced the tensor wherever its tile plan allows
         self.gn_fuse = os.environ.get("REFACE_GN_FUSE", "1") == "1"
-        # GEGLU + ff.net.2 of the C = 320 transformer blocks as one kernel (bf16 mode)
-        self.ffn_fuse = os.environ.get("REFACE_FFN_FUSE", "1") == "1"
+        # GEGLU + ff.net.2 of the C = 320 transformer blocks as one kernel (csrc/ffn.hip, bf16 mode).  Opt-in: correct (tests) but at 219 us
+        # against 139 + 52 us for the two GEMMs on the same box (r02h) -- one wave per SIMD exposes every LDS / barrier wait and
+        # serialises the GEGLU VALU work with the MFMAs; it needs a software-pipelined schedule to pay.
+        self.ffn_fuse = os.environ.get("REFACE_FFN_FUSE", "0") == "1"
         self.gn_fused = 0
         self.pool = _Pool(device)
         self.tracker = ProducerTracker()
