@@ -39,7 +39,7 @@ struct AttnParams {
     int nqb;          // q-blocks (of 128 queries) per (batch, head)
 };
 
-constexpr int KV_TILE = 64;
+constexpr int KV_SUB = 64;          // keys per softmax / MFMA pass (the S^T accumulators of one pass: two 32-key blocks)
 
 // position of key j (0..15) inside its 16-key group in the V^T LDS row, such that lane-half h
 // reads one contiguous 16-byte fragment holding exactly the keys its P registers cover
@@ -49,8 +49,11 @@ template <> __device__ __forceinline__ int vt_pos<float>(int j) { return j; }
 
 // D = head dim (multiple of 8).  STEPS = 16-byte k-steps over D per lane-half pair.  QB = 32-query blocks per wave
 // (QB = 2: each K / V^T fragment read from LDS feeds two MFMAs and the staging / barrier cost per query halves).
-template <typename T, int D, int QB>
+// KV_TILE = keys staged per barrier: 64, or 128 (two passes per stage: half the barriers and staging rounds; the loop is latency-bound --
+// ~6k cycles per wave and 64-key pass against ~1.5k of issued work -- so what is synchronised less often is won).
+template <typename T, int D, int QB, int KV_TILE = 64>
 __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
+    static_assert(KV_TILE % KV_SUB == 0, "stage = whole passes");
     constexpr int VEC = elem<T>::VEC;                 // elements per 16 B
     constexpr int KSTEP = 2 * VEC;                    // d consumed per fragment pair (two lane halves)
     constexpr int STEPS = (D + KSTEP - 1) / KSTEP;
@@ -201,7 +204,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         const char* ldsV = ldsK + KV_TILE * KROW;
         if (t + 1 < ntiles) load_kv(kv0 + KV_TILE);
 
-        // ---- S^T = K Q^T for the two 32-key blocks of this tile (raw, unscaled scores)
+#pragma unroll
+        for (int sub = 0; sub < KV_TILE / KV_SUB; ++sub) {
+        const int kvs = kv0 + sub * KV_SUB;               // first key of this pass
+        if (sub > 0 && kvs >= p.Nk) break;
+        // ---- S^T = K Q^T for the two 32-key blocks of this pass (raw, unscaled scores)
         f32x16_t s[QB][2];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
@@ -213,19 +220,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) {
-                const u32x4_t kf = *(const u32x4_t*)(ldsK + (kb * 32 + lq) * KROW + st * 32 + lh * 16);
+                const u32x4_t kf = *(const u32x4_t*)(ldsK + (sub * KV_SUB + kb * 32 + lq) * KROW + st * 32 + lh * 16);
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) AttnMma<T>::mma(s[qb][kb], kf, qf[qb][st]);
             }
         // ---- online softmax on raw scores (scale > 0): p = exp2(c2 * s - c2 * m); keys of this lane: kb*32 + 8*(r>>2) + 4*lh + (r&3)
-        if (kv0 + KV_TILE > p.Nk) {       // tail tile only: mask keys beyond Nk
+        if (kvs + KV_SUB > p.Nk) {        // tail pass only: mask keys beyond Nk
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (kv0 + kb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3) >= p.Nk) s[qb][kb][r] = -INFINITY;
+                        if (kvs + kb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3) >= p.Nk) s[qb][kb][r] = -INFINITY;
         }
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
                         for (int e = 0; e < 4; ++e) pf[qb][e] = pack_bf2(s[qb][kb][8 * g + 2 * e], s[qb][kb][8 * g + 2 * e + 1]);
 #pragma unroll
                     for (int i = 0; i < DVB; ++i) {
-                        const u32x4_t vf = *(const u32x4_t*)(ldsV + (i * 32 + lq) * VROW + (kb * 32 + g * 16) * 2 + lh * 16);
+                        const u32x4_t vf = *(const u32x4_t*)(ldsV + (i * 32 + lq) * VROW + (sub * KV_SUB + kb * 32 + g * 16) * 2 + lh * 16);
 #pragma unroll
                         for (int qb = 0; qb < QB; ++qb) AttnMma<T>::mma(o[qb][i], vf, pf[qb]);
                     }
@@ -289,13 +296,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
                         for (int e = 0; e < 4; ++e) pf[qb][e] = as_u32(s[qb][kb][4 * g + e]);
 #pragma unroll
                     for (int i = 0; i < DVB; ++i) {
-                        const u32x4_t vf = *(const u32x4_t*)(ldsV + (i * 32 + lq) * VROW + (kb * 32 + g * 8) * 4 + lh * 16);
+                        const u32x4_t vf = *(const u32x4_t*)(ldsV + (i * 32 + lq) * VROW + (sub * KV_SUB + kb * 32 + g * 8) * 4 + lh * 16);
 #pragma unroll
                         for (int qb = 0; qb < QB; ++qb) AttnMma<T>::mma(o[qb][i], vf, pf[qb]);
                     }
                 }
             }
         }
+        }      // passes of this stage
         if (t + 1 < ntiles) {
             if (NS == 1) __syncthreads();                  // single stage: every wave must be done reading tile t
             store_kv(NS == 2 ? ((t + 1) & 1) : 0);          // NS == 2: that stage was last read in iteration t-1
@@ -333,14 +341,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     }
 }
 
-template <typename T, int D, int QB>
+template <typename T, int D, int QB, int KV_TILE = 64>
 static int launch_attn_qb(const AttnParams& p, int B, hipStream_t st) {
     constexpr int VEC = elem<T>::VEC, KSTEP = 2 * VEC, STEPS = (D + KSTEP - 1) / KSTEP, DVB = (D + 31) / 32;
     constexpr int KROW = STEPS * 32 + 16;
     constexpr int VROW = KV_TILE * (int)sizeof(T) + 16;
     constexpr int tile_bytes = KV_TILE * KROW + DVB * 32 * VROW;
     constexpr int smem = (2 * tile_bytes <= 160 * 1024 ? 2 : 1) * tile_bytes;
-    auto k = attention_kernel<T, D, QB>;
+    auto k = attention_kernel<T, D, QB, KV_TILE>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
     AttnParams pp = p;
@@ -356,7 +364,11 @@ static int launch_attn(const AttnParams& p, int B, hipStream_t st) {
     // QB = 2 (two query blocks per wave, every K / V^T fragment feeds two MFMAs) pays for the small head dim when the
     // grid still fills the chip: d=40, N=4096: 687 us vs 739 us; it loses at d=80 (N=1024: 99 us vs 85 us).
     if constexpr (sizeof(T) == 2 && D <= 40) {
-        if ((long long)((p.Nq + 255) / 256) * B * p.heads >= 512) return launch_attn_qb<T, D, 2>(p, B, st);
+        static const int kt = [] { const char* e = getenv("RF_ATTN_KT"); return e ? atoi(e) : 128; }();
+        if ((long long)((p.Nq + 255) / 256) * B * p.heads >= 512) {
+            if (kt == 128 && p.Nk >= 1024) return launch_attn_qb<T, D, 2, 128>(p, B, st);
+            return launch_attn_qb<T, D, 2>(p, B, st);
+        }
     }
     return launch_attn_qb<T, D, 1>(p, B, st);
 }
