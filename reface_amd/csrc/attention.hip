@@ -51,8 +51,10 @@ template <> __device__ __forceinline__ int vt_pos<float>(int j) { return j; }
 // (QB = 2: each K / V^T fragment read from LDS feeds two MFMAs and the staging / barrier cost per query halves).
 // KV_TILE = keys staged per barrier: 64, or 128 (two passes per stage: half the barriers and staging rounds; the loop is latency-bound --
 // ~6k cycles per wave and 64-key pass against ~1.5k of issued work -- so what is synchronised less often is won).
-template <typename T, int D, int QB, int KV_TILE = 64>
-__global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
+// NW = waves per block (4 or 8): with 8, the two waves of every SIMD share ONE staged K / V tile -- the staging work per wave halves.
+template <typename T, int D, int QB, int KV_TILE = 64, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void attention_kernel(const AttnParams p) {
+    constexpr int NT = NW * 64;
     static_assert(KV_TILE % KV_SUB == 0, "stage = whole passes");
     constexpr int VEC = elem<T>::VEC;                 // elements per 16 B
     constexpr int KSTEP = 2 * VEC;                    // d consumed per fragment pair (two lane halves)
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     }
     const int bh = bid / p.nqb, qblk = bid - bh * p.nqb;
     const int b = bh / p.heads, h = bh % p.heads;
-    const int q0 = qblk * (4 * QW) + wave * QW;
+    const int q0 = qblk * (NW * QW) + wave * QW;
     const T* Q = (const T*)p.q + b * p.sq + h * D;
     const T* K = (const T*)p.k + b * p.sk + h * D;
     const T* V = (const T*)p.v + b * p.sv + h * D;
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         }
     }
     // zero the stages once: the pad columns of K / pad rows of V^T are never rewritten
-    for (int i = tid; i < NS * TILE_BYTES / 16; i += 256) ((u32x4_t*)smem)[i] = u32x4_t{0u, 0u, 0u, 0u};
+    for (int i = tid; i < NS * TILE_BYTES / 16; i += NT) ((u32x4_t*)smem)[i] = u32x4_t{0u, 0u, 0u, 0u};
     if constexpr (ONES) {
         __syncthreads();
         if (tid < NS * KV_TILE) {
@@ -131,13 +133,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     //   K : work item = (row r, 16-byte chunk c), row-major image.
     //   V : work item = (key pair pr, chunk c): the two keys 2pr, 2pr+1 are adjacent in the V^T row, so each transposed
     //       element pair is ONE 32-bit LDS store; lanes of a half-wave hold distinct pairs of one chunk => conflict-free.
-    constexpr int NKV = (KV_TILE * VPR + 255) / 256;
-    constexpr int NVP = ((KV_TILE / 2) * VPR + 255) / 256;
+    constexpr int NKV = (KV_TILE * VPR + NT - 1) / NT;
+    constexpr int NVP = ((KV_TILE / 2) * VPR + NT - 1) / NT;
     u32x4_t rk[NKV], rv0[NVP], rv1[NVP];
     auto load_kv = [&](int kv0) {
 #pragma unroll
         for (int u = 0; u < NKV; ++u) {
-            const int idx = tid + u * 256;
+            const int idx = tid + u * NT;
             const int r = idx / VPR, c = idx - r * VPR;
             u32x4_t kk = {0u, 0u, 0u, 0u};
             if (idx < KV_TILE * VPR && kv0 + r < p.Nk) kk = *(const u32x4_t*)(K + (long long)(kv0 + r) * p.ldk + c * VEC);
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         }
 #pragma unroll
         for (int u = 0; u < NVP; ++u) {
-            const int idx = tid + u * 256;
+            const int idx = tid + u * NT;
             const int c = idx / (KV_TILE / 2), pr = idx - c * (KV_TILE / 2);
             u32x4_t a = {0u, 0u, 0u, 0u}, bq = {0u, 0u, 0u, 0u};
             if (idx < (KV_TILE / 2) * VPR) {
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         char* ldsV = ldsK + KV_TILE * KROW;
 #pragma unroll
         for (int u = 0; u < NKV; ++u) {
-            const int idx = tid + u * 256;
+            const int idx = tid + u * NT;
             if (idx < KV_TILE * VPR) {
                 const int r = idx / VPR, c = idx - r * VPR;
                 *(u32x4_t*)(ldsK + r * KROW + c * 16) = rk[u];
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         }
 #pragma unroll
         for (int u = 0; u < NVP; ++u) {
-            const int idx = tid + u * 256;
+            const int idx = tid + u * NT;
             if (idx < (KV_TILE / 2) * VPR) {
                 const int c = idx / (KV_TILE / 2), pr = idx - c * (KV_TILE / 2);
                 const int r = 2 * pr;
@@ -341,20 +343,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     }
 }
 
-template <typename T, int D, int QB, int KV_TILE = 64>
+template <typename T, int D, int QB, int KV_TILE = 64, int NW = 4>
 static int launch_attn_qb(const AttnParams& p, int B, hipStream_t st) {
     constexpr int VEC = elem<T>::VEC, KSTEP = 2 * VEC, STEPS = (D + KSTEP - 1) / KSTEP, DVB = (D + 31) / 32;
     constexpr int KROW = STEPS * 32 + 16;
     constexpr int VROW = KV_TILE * (int)sizeof(T) + 16;
     constexpr int tile_bytes = KV_TILE * KROW + DVB * 32 * VROW;
     constexpr int smem = (2 * tile_bytes <= 160 * 1024 ? 2 : 1) * tile_bytes;
-    auto k = attention_kernel<T, D, QB, KV_TILE>;
+    auto k = attention_kernel<T, D, QB, KV_TILE, NW>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
     AttnParams pp = p;
-    pp.nqb = (p.Nq + 128 * QB - 1) / (128 * QB);
+    pp.nqb = (p.Nq + 32 * NW * QB - 1) / (32 * NW * QB);
     dim3 grid(pp.nqb * B * p.heads);
-    hipLaunchKernelGGL(k, grid, dim3(256), smem, st, pp);
+    hipLaunchKernelGGL(k, grid, dim3(NW * 64), smem, st, pp);
     RF_LAUNCH_CHECK("rf_attention");
     return 0;
 }
@@ -366,6 +368,10 @@ static int launch_attn(const AttnParams& p, int B, hipStream_t st) {
     if constexpr (sizeof(T) == 2 && D <= 40) {
         static const int kt = [] { const char* e = getenv("RF_ATTN_KT"); return e ? atoi(e) : 128; }();
         if ((long long)((p.Nq + 255) / 256) * B * p.heads >= 512) {
+            // 8-wave blocks (both waves of a SIMD on one staged tile) measured 608 vs 586 us at N = 4096: opt-in only (RF_ATTN_NW=8)
+            static const int nw = [] { const char* e = getenv("RF_ATTN_NW"); return e ? atoi(e) : 4; }();
+            if (kt == 128 && p.Nk >= 1024 && nw == 8 && (long long)((p.Nq + 511) / 512) * B * p.heads >= 512)
+                return launch_attn_qb<T, D, 2, 128, 8>(p, B, st);
             if (kt == 128 && p.Nk >= 1024) return launch_attn_qb<T, D, 2, 128>(p, B, st);
             return launch_attn_qb<T, D, 2>(p, B, st);
         }
