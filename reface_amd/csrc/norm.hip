@@ -98,7 +98,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restric
     }
 }
 
-template <typename T, typename TO>
+// NS = channel vectors per thread (1 for C <= 256 * VEC: every UNet / VAE layer but the widest concats): sizing the per-channel scale /
+// shift registers for the worst case (4 slots = 128 registers) halved the occupancy of this HBM-bound pass.
+template <typename T, typename TO, int NS>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restrict__ x, int HW, int C, int ldx, int nchunks,
                                                               const double* __restrict__ partial, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, int do_silu,
@@ -117,10 +119,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
     // so that the small low-resolution launches pay ONE global-memory latency, not three in a row (partials -> gamma/beta -> x)
     const int ppc = (HW + achunks - 1) / achunks;
     const int p0 = blockIdx.x * ppc, p1 = min(HW, p0 + ppc);
-    float gm[GN_SLOTS][VEC], bt[GN_SLOTS][VEC];
-    u32x4_t raw0[GN_SLOTS];
+    float gm[NS][VEC], bt[NS][VEC];
+    u32x4_t raw0[NS];
 #pragma unroll
-    for (int q = 0; q < GN_SLOTS; ++q) {
+    for (int q = 0; q < NS; ++q) {
         const int v = tv + q * TV;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { gm[q][e] = 0.f; bt[q][e] = 0.f; }
@@ -158,9 +160,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
         }
         __syncthreads();
     }
-    float sc[GN_SLOTS][VEC], sh[GN_SLOTS][VEC];
+    float sc[NS][VEC], sh[NS][VEC];
 #pragma unroll
-    for (int q = 0; q < GN_SLOTS; ++q) {
+    for (int q = 0; q < NS; ++q) {
         const int v = tv + q * TV;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -174,15 +176,26 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
         }
     }
     if (pl >= PL) return;
-    for (int p = p0 + pl; p < p1; p += PL) {
-        const T* row = x + ((long long)b * HW + p) * ldx;
-        TO* orow = out + ((long long)b * HW + p) * ldo;
+    // one pixel ahead: the next pixel's vectors are in flight while the current ones are normalised
+    u32x4_t cur[NS];
 #pragma unroll
-        for (int q = 0; q < GN_SLOTS; ++q) {
+    for (int q = 0; q < NS; ++q) cur[q] = raw0[q];
+    for (int p = p0 + pl; p < p1; p += PL) {
+        const T* nrow = x + ((long long)b * HW + p + PL) * ldx;
+        TO* orow = out + ((long long)b * HW + p) * ldo;
+        u32x4_t nxt[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const int v = tv + q * TV;
+            nxt[q] = u32x4_t{0u, 0u, 0u, 0u};
+            if (v < nvec && p + PL < p1) nxt[q] = *(const u32x4_t*)(nrow + v * VEC);
+        }
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
             const int v = tv + q * TV;
             if (v < nvec) {
                 float f[VEC];
-                unpack16<T>(p == p0 + pl ? raw0[q] : *(const u32x4_t*)(row + v * VEC), f);
+                unpack16<T>(cur[q], f);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     float y = f[e] * sc[q][e] + sh[q][e];
@@ -201,6 +214,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
                 }
             }
         }
+#pragma unroll
+        for (int q = 0; q < NS; ++q) cur[q] = nxt[q];
     }
 }
 
@@ -233,9 +248,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     for (int q = 0; q < NV; ++q) {
         const int v = lane + q * 64;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            g[q][e] = v < nvec ? gamma[v * VEC + e] : 0.f;
-            bt[q][e] = v < nvec ? beta[v * VEC + e] : 0.f;
+        for (int e = 0; e < VEC; e += 4) {                 // 16-byte loads (element-wise conditional loads are 2 x VEC load instructions per row)
+            f32x4_t g4 = {0.f, 0.f, 0.f, 0.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+            if (v < nvec) { g4 = *(const f32x4_t*)(gamma + v * VEC + e); b4 = *(const f32x4_t*)(beta + v * VEC + e); }
+            g[q][e] = g4[0]; g[q][e + 1] = g4[1]; g[q][e + 2] = g4[2]; g[q][e + 3] = g4[3];
+            bt[q][e] = b4[0]; bt[q][e + 1] = b4[1]; bt[q][e + 2] = b4[2]; bt[q][e + 3] = b4[3];
         }
     }
     float mean[LN_RPW], rstd[LN_RPW];
@@ -394,12 +411,15 @@ extern "C" int rf_groupnorm_apply(int dtype, const void* x, int B, int HW, int C
     if (achunks < 1) achunks = 1;
     dim3 grid(achunks, B);
     hipStream_t st = (hipStream_t)stream;
-#define GN_APPLY(T, TO) hipLaunchKernelGGL((gn_apply_kernel<T, TO>), grid, dim3(GN_THREADS), 0, st, (const T*)x, HW, C, ldx, nchunks, partial, gamma, beta, eps, silu, (TO*)out, ldo, achunks)
-    if (dtype == RF_F32 && out_dtype == RF_F32) GN_APPLY(float, float);
-    else if (dtype == RF_F32) GN_APPLY(float, bf16_t);
-    else if (out_dtype == RF_F32) GN_APPLY(bf16_t, float);
-    else GN_APPLY(bf16_t, bf16_t);
+    const int ns = (C / (dtype == RF_F32 ? 4 : 8) + GN_THREADS - 1) / GN_THREADS;      // channel vectors per thread
+#define GN_APPLY_(T, TO, NS_) hipLaunchKernelGGL((gn_apply_kernel<T, TO, NS_>), grid, dim3(GN_THREADS), 0, st, (const T*)x, HW, C, ldx, nchunks, partial, gamma, beta, eps, silu, (TO*)out, ldo, achunks)
+#define GN_APPLY(T, TO) { if (ns <= 1) GN_APPLY_(T, TO, 1); else if (ns <= 2) GN_APPLY_(T, TO, 2); else GN_APPLY_(T, TO, GN_SLOTS); }
+    if (dtype == RF_F32 && out_dtype == RF_F32) GN_APPLY(float, float)
+    else if (dtype == RF_F32) GN_APPLY(float, bf16_t)
+    else if (out_dtype == RF_F32) GN_APPLY(bf16_t, float)
+    else GN_APPLY(bf16_t, bf16_t)
 #undef GN_APPLY
+#undef GN_APPLY_
     RF_LAUNCH_CHECK("rf_groupnorm_apply");
     return 0;
 }
