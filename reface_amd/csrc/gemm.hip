@@ -1057,11 +1057,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 // thread -> one fixed 4-column segment and every 4th row, so the fused GroupNorm statistics reduce exactly as in the main epilogue
 // (chunk slot = gn_slot + (row tile within the sample) * column tiles + column tile).
 constexpr int SK_ROWS = 32, SK_COLS = 256;
-template <typename TO>
+// Rows per reduce block: 32, or 8 when 32-row blocks would leave most of the chip idle (M = 1024 x N = 1280 is 160 blocks of 32 rows:
+// 21 us for 39 MB of partial sums = 1.9 TB/s, 34 launches per step).
+static inline int sk_rows_for(int M, int N) { return ((long long)((M + 31) / 32) * ((N + SK_COLS - 1) / SK_COLS) >= 512) ? 32 : 8; }
+template <typename TO, int SKR>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
     const int tid = threadIdx.x;
     const int cl = (tid & 63) * 4, rp = tid >> 6;
-    const int n0 = blockIdx.x * SK_COLS, m0 = blockIdx.y * SK_ROWS;
+    const int n0 = blockIdx.x * SK_COLS, m0 = blockIdx.y * SKR;
     const int col = n0 + cl;
     const bool vec = (p.N & 3) == 0 && p.vec_ok;
     const bool gn_on = p.gn_rows > 0;
@@ -1073,10 +1076,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (p.bias && col + e < p.N) cadd[e] = p.bias[col + e];
-        constexpr int U = 4;          // rows in flight: the partial-sum loads of U rows are issued together (one row at a time
+        constexpr int U = SKR / 4 < 4 ? SKR / 4 : 4;          // rows in flight: the partial-sum loads of U rows are issued together (one row at a time
                                       // serialises the L2 / HBM latency SK_ROWS / 4 times per thread)
 #pragma unroll 1
-        for (int k0 = 0; k0 < SK_ROWS / 4; k0 += U) {
+        for (int k0 = 0; k0 < SKR / 4; k0 += U) {
             float v[U][4];
             bool ok[U];
 #pragma unroll
@@ -1176,7 +1179,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
                 for (int k = lo; k < hi; ++k)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { sa += (double)cs[0][r][k]; sq += (double)cs[1][r][k]; }
-                const int b = m0 / p.gn_rows, mt = (m0 - b * p.gn_rows) / SK_ROWS;
+                const int b = m0 / p.gn_rows, mt = (m0 - b * p.gn_rows) / SKR;
                 double* o = p.gn_part[c] + (((long long)b * p.gn_nch[c] + p.gn_slot[c] + mt * (int)gridDim.x + (int)blockIdx.x) * 32 + g) * 2;
                 o[0] = sa;
                 o[1] = sq;
@@ -1217,7 +1220,8 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     p.splitk = pick_splitk(d, p, (long long)p.tiles_m * p.tiles_n, sizeof(T) == 2 ? 64 : 32);
     if (p.splitk > 1) p.ws = (float*)d->workspace;
     // statistics tiling: the GEMM tile, or the reduce pass's tile when split-K moves the epilogue there
-    const int st_rows = p.splitk > 1 ? SK_ROWS : BM, st_cols = p.splitk > 1 ? SK_COLS : BN;
+    const int skr = sk_rows_for(p.M, p.N);
+    const int st_rows = p.splitk > 1 ? skr : BM, st_cols = p.splitk > 1 ? SK_COLS : BN;
     if (p.plan) { p.plan[0] = st_rows; p.plan[1] = st_cols; p.plan[2] = p.splitk; return 0; }
     if (p.gn_rows > 0) {
         RF_CHECK(p.gn_rows % st_rows == 0 && p.M % p.gn_rows == 0 && d->batch == 1 && d->act != RF_ACT_GEGLU,
@@ -1272,7 +1276,10 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     }
 #undef RF_LAUNCH_VARIANT
     if (p.splitk > 1)
-        hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3((p.N + SK_COLS - 1) / SK_COLS, (p.M + SK_ROWS - 1) / SK_ROWS), dim3(256), 0, st, p);
+    {
+        if (skr == 8) hipLaunchKernelGGL((splitk_reduce_kernel<TO, 8>), dim3((p.N + SK_COLS - 1) / SK_COLS, (p.M + 7) / 8), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((splitk_reduce_kernel<TO, 32>), dim3((p.N + SK_COLS - 1) / SK_COLS, (p.M + 31) / 32), dim3(256), 0, st, p);
+    }
     RF_LAUNCH_CHECK("rf_conv_gemm");
     return 0;
 }
