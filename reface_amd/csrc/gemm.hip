@@ -686,7 +686,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
     if constexpr (EPI == 1) {
         // ---- direct epilogue: lane (row lrow of its 32-row block, half lhalf) holds columns 16*lhalf .. 16*lhalf+15 of every
         // 32-column block of its wave tile.  Host guarantees (launch_typed): N % 16 == 0, 16-byte aligned rows of out / residual /
-        // bias / rowvec, no fused GroupNorm statistics, no PReLU, rowvec uniform per tile (or split-K, whose reduce pass adds it).
+        // bias / rowvec, no PReLU, rowvec uniform per tile, fused GroupNorm statistics only with act NONE.
         TO* const outp = (TO*)p.out + zb * p.sO;
         const TO* const resp = p.residual ? (const TO*)p.residual + zb * p.sR : nullptr;
         constexpr int OV = sizeof(TO) == 2 ? 2 : 4;      // 16-byte vectors per 16 output values (split-K launches never come here: direct
@@ -772,6 +772,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             };
 #pragma unroll
             for (int b = 0; b < PFD; ++b) load_res(b, rq[b]);
+            // Fused GroupNorm statistics (gn_rows > 0): per 32-column block the lane sums its 16 columns over its TM rows (values as stored),
+            // a 5-stage butterfly over the 32 lanes of the half-wave leaves ONE column total per lane (lanes 0-15: sums, 16-31: sums of
+            // squares), the wave rows meet in LDS and 64 threads form the 32 group sums per consumer in fp64 -- same slots, same
+            // consumers as the staged epilogue.
+            const bool gn_on = p.gn_rows > 0;
+            float* const gcs = (float*)(smem + 2048);            // [2][WM][BN] column sums / sums of squares per wave row
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + (wn * TN + j) * 32 + lhalf * 16;
@@ -784,7 +790,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                     const int blk = j * TM + i;
                     const int row = m0 + (wm * TM + i) * 32 + lrow;
                     const u32x4_t* const myr = rq[blk % PFD];
-                    if (row < p.M && cok) {
+                    const bool live = row < p.M && cok;
+                    if (live) {
                         TO* dst = outp + (long long)row * p.ldo + col;
 #pragma unroll
                         for (int h = 0; h < OV; ++h) {
@@ -793,11 +800,70 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                             if (resp) unpack16<TO>(myr[h], f);
 #pragma unroll
                             for (int e = 0; e < E; ++e) v[e] = acc[i][j][h * E + e] * p.alpha + cb[(h * E + e) >> 2][(h * E + e) & 3] + (resp ? f[e] : 0.0f);
-                            if (!(p.dbg & 8)) ((u32x4_t*)dst)[h] = pack16<TO>(v);
+                            const u32x4_t w = pack16<TO>(v);
+                            if (!(p.dbg & 8)) ((u32x4_t*)dst)[h] = w;
+                            if (gn_on) {
+                                float y[E];
+                                unpack16<TO>(w, y);              // the values as stored replace the (dead) accumulators: no extra registers
+#pragma unroll
+                                for (int e = 0; e < E; ++e) acc[i][j][h * E + e] = y[e];
+                            }
                         }
+                    } else if (gn_on) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
                     }
                     if (blk + PFD < NBLK) load_res(blk + PFD, rq[blk % PFD]);
                     __builtin_amdgcn_sched_barrier(0);
+                }
+                float gx[32];                                    // [0, 16): column sums, [16, 32): sums of squares (this lane's rows)
+                if (gn_on) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        float a = 0.f, q = 0.f;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) { a += acc[i][j][k]; q += acc[i][j][k] * acc[i][j][k]; }
+                        gx[k] = a;
+                        gx[16 + k] = q;
+                    }
+                }
+                if (gn_on) {
+                    // butterfly reduce-scatter over the 32 lanes of this half-wave: after the stage with mask m a lane keeps the half of
+                    // its values selected by its own bit m; 16 + 8 + 4 + 2 + 1 exchanges
+#pragma unroll
+                    for (int st = 0; st < 5; ++st) {
+                        const int m = 16 >> st, n = 16 >> st;           // lane mask, values kept after this stage
+                        // (bit select, not ?: -- the compiler turns a select between two array elements into a lane-indexed array
+                        //  access, i.e. a 32-way compare chain per value)
+                        const unsigned up = (lrow & m) ? 0xffffffffu : 0u;
+#pragma unroll
+                        for (int k = 0; k < n; ++k) {
+                            const unsigned a = __float_as_uint(gx[k]), b = __float_as_uint(gx[k + n]);
+                            const float send = __uint_as_float((a & up) | (b & ~up));
+                            const float keep = __uint_as_float((b & up) | (a & ~up));
+                            gx[k] = keep + __shfl_xor(send, m, 64);
+                        }
+                    }
+                    // lane lrow now holds the total of value index lrow: column lrow (sums) / column lrow - 16 (squares)
+                    gcs[((lrow >> 4) * WM + wm) * BN + (wn * TN + j) * 32 + lhalf * 16 + (lrow & 15)] = gx[0];
+                }
+            }
+            if (gn_on) {
+                lds_barrier();
+                if (tid < 64) {
+                    const int c = tid >> 5, g = tid & 31;
+                    if (p.gn_part[c]) {
+                        const int cpg = p.gn_cpg[c], base = p.gn_coff[c] + n0;            // consumer channel of local column 0
+                        const int lo = max(0, g * cpg - base), hi = min(min(BN, p.N - n0), (g + 1) * cpg - base);
+                        double sa = 0.0, sq = 0.0;
+                        for (int k = lo; k < hi; ++k)
+#pragma unroll
+                            for (int r = 0; r < WM; ++r) { sa += (double)gcs[r * BN + k]; sq += (double)gcs[(WM + r) * BN + k]; }
+                        const int b = m0 / p.gn_rows, mt = (m0 - b * p.gn_rows) / BM;
+                        double* o = p.gn_part[c] + (((long long)b * p.gn_nch[c] + p.gn_slot[c] + mt * p.tiles_n + tile_n) * 32 + g) * 2;
+                        o[0] = sa;
+                        o[1] = sq;
+                    }
                 }
             }
         }
@@ -1228,7 +1294,8 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     constexpr bool DIRECT_OK = (WM * WN == 8) || (TM * TN == 5);
     const bool ep_common = p.glds && p.epi2_ok && p.splitk == 1 && (!p.rowvec || p.rows_per_sample % BM == 0) &&
                            (d->act == RF_ACT_NONE || (d->act == RF_ACT_GEGLU && TN % 2 == 0));
-    const bool direct = DIRECT_OK && (epi_env < 0 || epi_env == 1) && ep_common && p.gn_rows == 0;
+    static const int gn_direct = [] { const char* e = getenv("RF_EPI_GN"); return e ? atoi(e) : 1; }();      // 0: fused statistics keep EPI 0
+    const bool direct = DIRECT_OK && (epi_env < 0 || epi_env == 1) && ep_common && (p.gn_rows == 0 || (gn_direct && d->act == RF_ACT_NONE));
     // (packed: measured neutral-to-negative in situ -- proj_out 4096x1280x1280 with fused statistics 37 -> 63 us, the rest within
     //  noise, r02f -- so it is opt-in: RF_EPI=2)
     const bool packed = !direct && PACKED_OK && epi_env == 2 && ep_common;

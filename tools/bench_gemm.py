@@ -21,6 +21,7 @@ ap.add_argument("--bc", type=int, default=16)
 ap.add_argument("--json", default=None)
 ap.add_argument("--sustain", type=float, default=0.0, help="also report the rate sustained over this many seconds (power-managed clocks)")
 ap.add_argument("--korder", type=int, default=0)
+ap.add_argument("--gn", type=int, default=0, help="conv cases also emit the fused GroupNorm statistics of their output")
 args = ap.parse_args()
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 dev = "cuda"
@@ -45,6 +46,8 @@ def conv(name, cin, cout, hw, *, c1=0, stride=1, ups=0):
     res = r(Bc, ho, ho, cout)
     b = r(cout, dtype=torch.float32)
     l = ops.conv2d(x, w, out, b, stride=stride, ups=ups, x2=x2, residual=res, korder=KORDER, name=name)
+    if args.gn:
+        assert ops.fuse_groupnorm_stats(out, [(l, 0, Bc * ho * ho, 0, cout)]) is not None, name
     cases.append((name, l, 2.0 * Bc * ho * ho * cout * 9 * (cin + c1)))
 
 
