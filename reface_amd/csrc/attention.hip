@@ -12,6 +12,8 @@
 // Block = 4 waves = 128 queries of one (batch, head); KV tile = 64 keys.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace rf {
@@ -52,8 +54,10 @@ template <> __device__ __forceinline__ int vt_pos<float>(int j) { return j; }
 // KV_TILE = keys staged per barrier: 64, or 128 (two passes per stage: half the barriers and staging rounds; the loop is latency-bound --
 // ~6k cycles per wave and 64-key pass against ~1.5k of issued work -- so what is synchronised less often is won).
 // NW = waves per block (4 or 8): with 8, the two waves of every SIMD share ONE staged K / V tile -- the staging work per wave halves.
+// Two query blocks per wave at 4 waves: without the second launch-bounds argument the compiler takes 241 + 128 registers (S and O in
+// AGPRs, ~750 v_accvgpr moves per 128 keys, ONE wave per SIMD); capped at 256 it needs 237 and two blocks share a CU.
 template <typename T, int D, int QB, int KV_TILE = 64, int NW = 4>
-__global__ __launch_bounds__(NW * 64) void attention_kernel(const AttnParams p) {
+__global__ __launch_bounds__(NW * 64, (QB == 2 && NW == 4) ? 2 : 1) void attention_kernel(const AttnParams p) {
     constexpr int NT = NW * 64;
     static_assert(KV_TILE % KV_SUB == 0, "stage = whole passes");
     constexpr int VEC = elem<T>::VEC;                 // elements per 16 B
@@ -213,18 +217,15 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const AttnParams p) 
         // ---- S^T = K Q^T for the two 32-key blocks of this pass (raw, unscaled scores)
         f32x16_t s[QB][2];
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[qb][kb][r] = 0.f;
-#pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) {
                 const u32x4_t kf = *(const u32x4_t*)(ldsK + (sub * KV_SUB + kb * 32 + lq) * KROW + st * 32 + lh * 16);
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) AttnMma<T>::mma(s[qb][kb], kf, qf[qb][st]);
+                for (int qb = 0; qb < QB; ++qb) {
+                    if (st == 0) s[qb][kb] = f32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // C = inline 0
+                    AttnMma<T>::mma(s[qb][kb], kf, qf[qb][st]);
+                }
             }
         // ---- online softmax on raw scores (scale > 0): p = exp2(c2 * s - c2 * m); keys of this lane: kb*32 + 8*(r>>2) + 4*lh + (r&3)
         if (kvs + KV_SUB > p.Nk) {        // tail pass only: mask keys beyond Nk
@@ -343,6 +344,546 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const AttnParams p) 
     }
 }
 
+
+// max of a value with its partner lane in the other half of the wave (lane ^ 32): v_permlane32_swap, a VALU operation -- the
+// ds_bpermute of __shfl_xor waits for every LDS read in flight (the prefetched fragments) on the softmax's critical path.
+__device__ __forceinline__ float max_xor32(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(as_u32(v), as_u32(v), false, false);
+    return fmaxf(as_f32(r[0]), as_f32(r[1]));
+}
+
+// ---- d = 40 self-attention over long sequences (bf16): the same transposed formulation, software-pipelined INSIDE every wave ----
+// The generic kernel runs {12 QK^T MFMAs} -> {~150 softmax VALU} -> {16 PV MFMAs} one after the other: matrix pipe and VALU never work
+// for the same wave at the same time (PMC: 31 % matrix busy, 50 % VALU busy, nothing overlapped).  Here the unit of work is 32 keys x
+// 64 queries and every step issues, in ONE basic block each,
+//     region 1:  O^T += V^T P^T of unit u-1   (8 MFMAs)   beside   the running max of unit u          (VALU)
+//     region 2:  S^T  = K Q^T   of unit u+1   (6 MFMAs)   beside   exp2 / pack of unit u -> P^T       (VALU)
+// with two S accumulator sets alternating.  Three LDS stages of 128 keys and ONE barrier per stage (placed after region 1 of a
+// stage's first unit: every wave is then done with the previous stage, whose buffer takes the stage after next); K rows arrive by
+// LDS-DMA as an unpadded 80-byte-row image (5 sixteen-byte slots per row: odd, so the fragment reads are conflict-free; the sixth
+// k-slot of the zero-padded head dim re-reads slot 4 against zero Q), V through registers into the transposed image (48 rows:
+// 40 + the all-ones row that makes the MFMA produce the softmax denominator + zero rows).  Needs Nk % 128 == 0, Nk >= 256.
+template <int D, int KV_TILE>
+__global__ __launch_bounds__(256, 2) void attention_pipe_kernel(const AttnParams p) {
+    typedef bf16_t T;
+    static_assert(D > 32 && D < 48 && D % 8 == 0 && KV_TILE % 64 == 0, "three 16-wide k-steps, a spare V^T row, an even unit count");
+    constexpr int NT = 256, QB = 2, NU = KV_TILE / 32, NSTG = 3;
+    constexpr int VPR = D / 8;                          // 16-byte slots per K / V row
+    constexpr int KROW = D * 2;                         // unpadded K rows
+    constexpr int VROWS = 48, VROW = KV_TILE * 2 + 16;  // V^T rows (dv), row bytes ((VROW / 16) odd)
+    constexpr int K_BYTES = KV_TILE * KROW, STAGE = K_BYTES + VROWS * VROW;
+    constexpr int KDMA = KV_TILE * VPR / 64;            // 1-KiB DMA pieces per K tile
+    static_assert((KV_TILE * VPR) % 64 == 0 && STAGE % 16 == 0, "whole DMA pieces");
+    constexpr int NKD = (KDMA + 3) / 4;                 // pieces per wave
+    constexpr int NVP = ((KV_TILE / 2) * VPR + NT - 1) / NT;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, lh = lane >> 5;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bh = bid / p.nqb, qblk = bid - bh * p.nqb;
+    const int b = bh / p.heads, h = bh % p.heads;
+    const int q0 = qblk * (4 * 32 * QB) + wave * (32 * QB);
+    const T* Q = (const T*)p.q + b * p.sq + h * D;
+    const T* K = (const T*)p.k + b * p.sk + h * D;
+    const T* V = (const T*)p.v + b * p.sv + h * D;
+    T* O = (T*)p.out + b * p.so + h * D;
+
+    u32x4_t qf[QB][3];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qi = q0 + qb * 32 + lq;
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+            const int c = st * 16 + lh * 8;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (qi < p.Nq && c < D) v = *(const u32x4_t*)(Q + (long long)qi * p.ldq + c);
+            qf[qb][st] = v;
+        }
+    }
+    for (int i = tid; i < NSTG * STAGE / 16; i += NT) ((u32x4_t*)smem)[i] = u32x4_t{0u, 0u, 0u, 0u};
+    __syncthreads();
+    for (int i = tid; i < NSTG * KV_TILE; i += NT) {
+        const int stg = i / KV_TILE, kcol = i - stg * KV_TILE;
+        *(T*)(smem + stg * STAGE + K_BYTES + D * VROW + kcol * 2) = (T)0x3f80;       // the ones row
+    }
+
+    // ---- staging
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, (unsigned)((((long long)p.Nk - 1) * p.ldk + D) * 2), 0x00020000);
+    int koff[NKD];                                      // byte offset of this lane's slot in piece wave + 4 i
+#pragma unroll
+    for (int i = 0; i < NKD; ++i) {
+        const int g = (wave + 4 * i) * 64 + lane, row = g / VPR, ch = g - row * VPR;
+        koff[i] = row * p.ldk * 2 + ch * 16;
+    }
+    auto dma_k = [&](int tile, int stage) {
+#pragma unroll
+        for (int i = 0; i < NKD; ++i) {
+            const int piece = wave + 4 * i;
+            if (piece < KDMA) {
+                const int so = tile * (KV_TILE * p.ldk * 2);
+                char* const dst = smem + stage * STAGE + piece * 1024;
+                const int vo = koff[i];          // plain locals only in the builtin's argument list (the host pass drops the kernel stub otherwise)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)dst, 16, vo, so, 0, 0);
+            }
+        }
+    };
+    u32x4_t rv0[NVP], rv1[NVP];
+    auto load_v = [&](int kv0) {
+#pragma unroll
+        for (int u = 0; u < NVP; ++u) {
+            const int idx = tid + u * NT;
+            const int c = idx / (KV_TILE / 2), pr = idx - c * (KV_TILE / 2);
+            if (idx < (KV_TILE / 2) * VPR) {
+                const T* src = V + (long long)(kv0 + 2 * pr) * p.ldv + c * 8;
+                rv0[u] = *(const u32x4_t*)src;
+                rv1[u] = *(const u32x4_t*)(src + p.ldv);
+            }
+        }
+    };
+    auto store_v = [&](int stage) {
+        char* const ldsV = smem + stage * STAGE + K_BYTES;
+#pragma unroll
+        for (int u = 0; u < NVP; ++u) {
+            const int idx = tid + u * NT;
+            if (idx < (KV_TILE / 2) * VPR) {
+                const int c = idx / (KV_TILE / 2), pr = idx - c * (KV_TILE / 2);
+                const int r = 2 * pr;
+                const int pos = (r & ~15) + vt_pos<T>(r & 15);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t x0 = rv0[u][e], x1 = rv1[u][e];
+                    *(uint32_t*)(ldsV + (c * 8 + 2 * e) * VROW + pos * 2) = (x0 & 0xffffu) | (x1 << 16);
+                    *(uint32_t*)(ldsV + (c * 8 + 2 * e + 1) * VROW + pos * 2) = (x0 >> 16) | (x1 & 0xffff0000u);
+                }
+            }
+        }
+    };
+
+    // ---- per-lane LDS offsets of the fragments
+    int kfo[3];                                         // K fragment of k-step st, key lq of unit 0
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+        const int slot = st * 2 + lh;
+        kfo[st] = lq * KROW + (slot < VPR ? slot : VPR - 1) * 16;
+    }
+    int vfo[2];                                         // V^T fragment of row block i, keys 0..15 of unit 0
+    vfo[0] = K_BYTES + lq * VROW + lh * 16;
+    vfo[1] = K_BYTES + (lq < 16 ? 32 + lq : VROWS - 1) * VROW + lh * 16;        // rows >= 48 do not exist: the last (zero) row
+
+    f32x16_t o[QB][2];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][i][r] = 0.f;
+    float m_run[QB] = {-INFINITY, -INFINITY};
+    const float c2 = p.scale_log2e;
+    const float thr = 8.0f / c2;                        // the running max is only raised when a score exceeds it by 2^8 in the exp2 domain
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = p.Nk / KV_TILE;
+    __syncthreads();                                    // zero fill + ones rows done
+    dma_k(0, 0);
+    dma_k(1, 1);
+    load_v(0);
+    store_v(0);
+    load_v(KV_TILE);
+    store_v(1);
+    __syncthreads();
+
+    f32x16_t S[2][QB];
+    u32x4_t pf[QB][2];                                  // P^T of the previous unit: [query block][16-key group]
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) pf[qb][0] = pf[qb][1] = u32x4_t{0u, 0u, 0u, 0u};
+    // S^T of (stage base sb, unit un) -> dst
+#define RF_QK(dst, sb, un)                                                                                      \
+    {                                                                                                           \
+        _Pragma("unroll") for (int st = 0; st < 3; ++st) {                                                      \
+            const u32x4_t kf = *(const u32x4_t*)((sb) + (un) * (32 * KROW) + kfo[st]);                          \
+            _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) {                                                 \
+                if (st == 0) dst[qb] = zero16;                                                                  \
+                AttnMma<T>::mma(dst[qb], kf, qf[qb][st]);                                                       \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+    // O^T += V^T(stage base sb, unit un) pf
+#define RF_PV(sb, un)                                                                                           \
+    {                                                                                                           \
+        _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                           \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                     \
+                const u32x4_t vf = *(const u32x4_t*)((sb) + vfo[i] + ((un) * 32 + g * 16) * 2);                 \
+                _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) AttnMma<T>::mma(o[qb][i], vf, pf[qb][g]);     \
+            }                                                                                                   \
+    }
+    RF_QK(S[0], smem, 0)
+    int sc = 0;                                          // stage of tile t
+    const char* prev_sb = smem;                          // stage / unit of the unit whose P^T sits in pf (first step: P = 0)
+    for (int t = 0; t < ntiles; ++t) {
+        const int sn = sc == NSTG - 1 ? 0 : sc + 1, sn2 = sn == NSTG - 1 ? 0 : sn + 1;
+        const char* const sb = smem + sc * STAGE;
+        const char* const sbn = smem + sn * STAGE;
+#pragma unroll
+        for (int uu = 0; uu < NU; ++uu) {
+            f32x16_t* const cur = S[uu & 1];
+            f32x16_t* const nxt = S[(uu + 1) & 1];
+            // ---- region 1: PV of the previous unit beside the max of this one
+            if (uu == 0) RF_PV(prev_sb, NU - 1) else RF_PV(sb, uu - 1)
+            float m_new[QB];
+            bool moved = false;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float mx = cur[qb][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, cur[qb][r]);
+                mx = max_xor32(mx);
+                m_new[qb] = fmaxf(m_run[qb], mx);
+                moved |= mx > m_run[qb] + thr;
+            }
+            if (uu == 0) {
+                __syncthreads();                         // every wave is past the last read of tile t-1: its stage takes tile t+2
+                if (t + 2 < ntiles) {
+                    dma_k(t + 2, sn2);
+                    load_v((t + 2) * KV_TILE);
+                }
+            }
+            if (__any(moved)) {                          // some query's running max moved (wave-uniform; rare after the first tiles)
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new[qb]) * c2);     // -inf on the first unit -> 0
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[qb][i][r] *= alpha;
+                    m_run[qb] = m_new[qb];
+                }
+            }
+            // ---- region 2: QK^T of the next unit beside exp2 / pack of this one
+            if (uu == NU - 1) RF_QK(nxt, sbn, 0) else RF_QK(nxt, sb, uu + 1)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const float mc = m_run[qb] * c2;
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 8 * g + 2 * e;
+                        const f32x2_t a = __builtin_elementwise_fma(f32x2_t{cur[qb][r], cur[qb][r + 1]}, f32x2_t{c2, c2}, f32x2_t{-mc, -mc});
+                        const float e0 = __builtin_amdgcn_exp2f(a[0]), e1 = __builtin_amdgcn_exp2f(a[1]);
+                        pf[qb][g][e] = pack_bf2(e0, e1);
+                    }
+            }
+            if (uu == NU - 1 && t + 2 < ntiles) store_v(sn2);
+        }
+        prev_sb = sb;
+        sc = sn;
+    }
+    RF_PV(prev_sb, NU - 1)
+#undef RF_QK
+#undef RF_PV
+    // ---- normalise and store: lane holds O[q][dv = i*32 + 8*(r>>2) + 4*lh + (r&3)]; row D of O^T (lane half 0) is the denominator
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float l_tot = __shfl(o[qb][D / 32][((D % 32) / 8) * 4], lq, 64);
+        const float inv = 1.0f / l_tot;
+        const int qi = q0 + qb * 32 + lq;
+        if (qi < p.Nq) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int dv = i * 32 + 8 * g + 4 * lh;
+                    if (dv < D) {
+                        u32x2_t w;
+                        w[0] = pack_bf2(o[qb][i][4 * g] * inv, o[qb][i][4 * g + 1] * inv);
+                        w[1] = pack_bf2(o[qb][i][4 * g + 2] * inv, o[qb][i][4 * g + 3] * inv);
+                        *(u32x2_t*)(O + (long long)qi * p.ldo + dv) = w;
+                    }
+                }
+        }
+    }
+}
+
+
+// ds_read_b64_tr_b16 as inline asm: through the builtin the compiler cannot tell the read from the LDS-DMA writes in flight and puts
+// an s_waitcnt vmcnt(0) in front of it (every tile then waits for the DMA issued a moment earlier).  The asm is invisible to the
+// waitcnt pass, so whoever uses the result waits with tr_wait() first (LDS operations complete in order: the compiler's own counted
+// lgkmcnt waits only become stricter).
+template <int OFF> __device__ __forceinline__ u32x2_t ds_read_tr16(const char* p) {
+    u32x2_t r;
+    const uint32_t a = (uint32_t)(uintptr_t)p;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF));
+    return r;
+}
+
+// ---- the same in-wave pipeline with BOTH operands staged by LDS-DMA ----
+// K and V tiles (64 keys) arrive as unpadded row-major images (80-byte rows) through `buffer_load ... lds`: no staging registers, no
+// VALU, no LDS stores, and a ring of 7 stages (70 KB, two blocks per CU) puts every tile 6 iterations (~2.5 us) ahead of its first use --
+// the register-staged kernels expose the L2 / fabric latency of ONE tile of look-ahead on every tile (removing the K DMA alone from the
+// 3-stage kernel: 585 -> 508 us).  V^T fragments come out of the row-major image with ds_read_b64_tr_b16 (lane i of a 16-lane group
+// receives column i of the [4 keys][16 columns] block the group addresses; tools/tr_probe.py), two reads per MFMA operand; the 24
+// rows of O^T beyond the head dim multiply whatever follows the row and are never stored -- except rows 48..63, whose lanes read a
+// run of ones, so the MFMA also delivers the softmax denominator.  One wave issues a whole tile (10 one-KiB pieces), waves taking turns.
+// The running max moves only when a score exceeds it by 2^8 in the exp2 domain (P <= 256; the O rescale becomes rare).
+template <int D>
+__global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams p) {
+    typedef bf16_t T;
+    static_assert(D > 32 && D < 48 && D % 8 == 0, "three 16-wide k-steps");
+    constexpr int QB = 2, KT = 64, NU = KT / 32, NSTG = 7;
+    constexpr int VPR = D / 8, KROW = D * 2;
+    constexpr int K_BYTES = KT * KROW, STAGE = 2 * K_BYTES;
+    constexpr int ONES_OFF = NSTG * STAGE, ONES_BYTES = (KT - 8) * KROW + 128;     // a run of bf16 ones (see the V^T fragments below)
+    constexpr int PIECES = K_BYTES / 1024;              // one-KiB DMA pieces per operand tile
+    static_assert(K_BYTES % 1024 == 0 && NU == 2, "whole DMA pieces; two units per tile");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, lh = lane >> 5;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bh = bid / p.nqb, qblk = bid - bh * p.nqb;
+    const int b = bh / p.heads, h = bh % p.heads;
+    const int q0 = qblk * (4 * 32 * QB) + wave * (32 * QB);
+    const T* Q = (const T*)p.q + b * p.sq + h * D;
+    const T* K = (const T*)p.k + b * p.sk + h * D;
+    const T* V = (const T*)p.v + b * p.sv + h * D;
+    T* O = (T*)p.out + b * p.so + h * D;
+
+    u32x4_t qf[QB][3];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qi = q0 + qb * 32 + lq;
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+            const int c = st * 16 + lh * 8;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (qi < p.Nq && c < D) v = *(const u32x4_t*)(Q + (long long)qi * p.ldq + c);
+            qf[qb][st] = v;
+        }
+    }
+
+    for (int i = tid; i < ONES_BYTES / 4; i += 256) ((uint32_t*)(smem + ONES_OFF))[i] = 0x3f803f80u;
+    // ---- staging: tile X is issued by wave X % 4
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, (unsigned)((((long long)p.Nk - 1) * p.ldk + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, (unsigned)((((long long)p.Nk - 1) * p.ldv + D) * 2), 0x00020000);
+    auto dma_tile = [&](int tile, int stage) {
+#pragma unroll
+        for (int pc = 0; pc < PIECES; ++pc) {
+            const int g = pc * 64 + lane, row = g / VPR, ch = g - row * VPR;
+            const int vk = row * p.ldk * 2 + ch * 16, vv = row * p.ldv * 2 + ch * 16;
+            const int sk = tile * (KT * p.ldk * 2), sv = tile * (KT * p.ldv * 2);
+            char* const dk = smem + stage * STAGE + pc * 1024;
+            char* const dv = dk + K_BYTES;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)dk, 16, vk, sk, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void*)dv, 16, vv, sv, 0, 0);
+        }
+    };
+
+    // ---- per-lane LDS offsets of the fragments (unit 0 of a stage)
+    int kfo[3];
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+        const int slot = st * 2 + lh;
+        kfo[st] = lq * KROW + (slot < VPR ? slot : VPR - 1) * 16;
+    }
+    // V^T fragment = two transposing reads of [4 keys][16 columns]: keys 4 lh + (l16 >> 2) (+ 8), columns 16 * ((lane >> 4) & 1) + 4 (l16 & 3)
+    const int l16 = lane & 15;
+    const int vfo = K_BYTES + (4 * lh + (l16 >> 2)) * KROW + (((lane >> 4) & 1) * 16 + (l16 & 3) * 4) * 2;
+    // Rows 48..63 of O^T (lanes 16..31 of the second row block) have no V column: their reads go to the run of ones instead, so that
+    // those rows of the MFMA accumulate sum_k P[k, q] -- the softmax denominator, at no VALU cost.
+    const bool ones_lane = ((lane >> 4) & 1) != 0;
+    const char* const ones_ptr = smem + ONES_OFF - 64;
+
+    f32x16_t o[QB][2];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][i][r] = 0.f;
+    float m_run[QB] = {-INFINITY, -INFINITY};
+    const float c2 = p.scale_log2e;
+    const float thr = 8.0f / c2;                        // the running max is only raised when a score exceeds it by 2^8 in the exp2 domain
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = p.Nk / KT;                       // >= NSTG (dispatch)
+#pragma unroll
+    for (int x = 0; x < NSTG - 1; ++x)
+        if ((x & 3) == wave) dma_tile(x, x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16_t S[2][QB];
+    u32x4_t pf[QB][2];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) pf[qb][0] = pf[qb][1] = u32x4_t{0u, 0u, 0u, 0u};
+    typedef short s16x4_t __attribute__((ext_vector_type(4)));
+    // Fragments are read one region ahead of the MFMAs that use them (the LDS latency would otherwise sit in front of every group).
+    u32x4_t kf[3], vf[2][2];
+#define RF_LOAD_KF(sb, un)                                                                                      \
+    {                                                                                                           \
+        _Pragma("unroll") for (int st = 0; st < 3; ++st) kf[st] = *(const u32x4_t*)((sb) + (un) * (32 * KROW) + kfo[st]);             \
+    }
+#define RF_LOAD_VF1(sb, un, g, i)                                                                               \
+    {                                                                                                           \
+        const char* const vb = ((i) == 1 && ones_lane) ? ones_ptr : (sb) + vfo;                                 \
+        const u32x2_t l2 = ds_read_tr16<((un) * 32 + (g) * 16) * KROW + (i) * 64>(vb);                          \
+        const u32x2_t h2 = ds_read_tr16<((un) * 32 + (g) * 16 + 8) * KROW + (i) * 64>(vb);                      \
+        vf[g][i] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};                                                         \
+    }
+#define RF_LOAD_VF(sb, un) RF_LOAD_VF1(sb, un, 0, 0) RF_LOAD_VF1(sb, un, 0, 1) RF_LOAD_VF1(sb, un, 1, 0) RF_LOAD_VF1(sb, un, 1, 1)
+#define RF_WAIT_VF() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[1][0]), "+v"(vf[1][1]));
+#define RF_QK(dst)                                                                                              \
+    {                                                                                                           \
+        _Pragma("unroll") for (int st = 0; st < 3; ++st)                                                        \
+            _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) {                                                 \
+                if (st == 0) dst[qb] = zero16;                                                                  \
+                AttnMma<T>::mma(dst[qb], kf[st], qf[qb][st]);                                                   \
+            }                                                                                                   \
+    }
+#define RF_PV()                                                                                                 \
+    {                                                                                                           \
+        _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                           \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                       \
+                _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) AttnMma<T>::mma(o[qb][i], vf[g][i], pf[qb][g]);                    \
+    }
+    RF_LOAD_KF(smem, 0)
+    RF_QK(S[0])
+    RF_LOAD_VF(smem, 0)                                  // the first step multiplies P = 0 with tile 0's own V rows
+    int sc = 0;                                          // stage of tile t
+    for (int t = 0; t < ntiles; ++t) {
+        const int sn = sc == NSTG - 1 ? 0 : sc + 1;
+        const int sp = sc == 0 ? NSTG - 1 : sc - 1;      // stage of tile t-1: takes tile t + NSTG - 1
+        const char* const sb = smem + sc * STAGE;
+        const char* const sbn = smem + sn * STAGE;
+        auto unit = [&](auto UU) {
+            constexpr int uu = decltype(UU)::value;           // compile-time: it selects immediates of the inline-asm reads
+            f32x16_t* const cur = S[uu & 1];
+            f32x16_t* const nxt = S[(uu + 1) & 1];
+            // ---- region 1: PV of the previous unit beside the max of this one
+            if (uu == NU - 1) RF_LOAD_KF(sbn, 0) else RF_LOAD_KF(sb, uu + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            RF_WAIT_VF()
+            RF_PV()
+            float m_new[QB];
+            bool moved = false;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float mx = cur[qb][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, cur[qb][r]);
+                mx = max_xor32(mx);
+                m_new[qb] = fmaxf(m_run[qb], mx);
+                moved |= mx > m_run[qb] + thr;
+            }
+            if (uu == 0) {
+                // tile t+1 (read from this iteration's second half on) was issued by wave (t+1) % 4, which has since issued tile t+5 only
+                if (((t + 1) & 3) == wave) {
+                    if (t + 5 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();                         // every wave is past the last read of tile t-1: its stage takes tile t+6
+                if (((t + NSTG - 1) & 3) == wave && t + NSTG - 1 < ntiles) dma_tile(t + NSTG - 1, sp);
+            }
+            if (__any(moved)) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new[qb]) * c2);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[qb][i][r] *= alpha;
+                    m_run[qb] = m_new[qb];
+                }
+            }
+            // ---- region 2: QK^T of the next unit beside exp2 / pack of this one
+            RF_LOAD_VF(sb, uu)
+            __builtin_amdgcn_sched_barrier(0);
+            RF_QK(nxt)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const float mc = m_run[qb] * c2;
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 8 * g + 2 * e;
+                        const f32x2_t a = __builtin_elementwise_fma(f32x2_t{cur[qb][r], cur[qb][r + 1]}, f32x2_t{c2, c2}, f32x2_t{-mc, -mc});
+                        const float e0 = __builtin_amdgcn_exp2f(a[0]), e1 = __builtin_amdgcn_exp2f(a[1]);
+                        pf[qb][g][e] = pack_bf2(e0, e1);
+                    }
+            }
+        };
+        unit(std::integral_constant<int, 0>{});
+        unit(std::integral_constant<int, 1>{});
+        sc = sn;
+    }
+    RF_WAIT_VF()
+    RF_PV()
+#undef RF_WAIT_VF
+#undef RF_LOAD_KF
+#undef RF_LOAD_VF
+#undef RF_LOAD_VF1
+#undef RF_QK
+#undef RF_PV
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float l_tot = __shfl(o[qb][1][8], lq, 64);          // row 48 of O^T: lane half 0, register 8
+        const float inv = 1.0f / l_tot;
+        const int qi = q0 + qb * 32 + lq;
+        if (qi < p.Nq) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int dv = i * 32 + 8 * g + 4 * lh;
+                    if (dv < D) {
+                        u32x2_t w;
+                        w[0] = pack_bf2(o[qb][i][4 * g] * inv, o[qb][i][4 * g + 1] * inv);
+                        w[1] = pack_bf2(o[qb][i][4 * g + 2] * inv, o[qb][i][4 * g + 3] * inv);
+                        *(u32x2_t*)(O + (long long)qi * p.ldo + dv) = w;
+                    }
+                }
+        }
+    }
+}
+
+template <int D>
+static int launch_attn_dma(const AttnParams& p, int B, hipStream_t st) {
+    constexpr int smem = 7 * (2 * 64 * D * 2) + (64 - 8) * D * 2 + 128;      // stages + the run of ones
+    auto k = attention_dma_kernel<D>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+    AttnParams pp = p;
+    pp.nqb = (p.Nq + 255) / 256;
+    hipLaunchKernelGGL(k, dim3(pp.nqb * B * p.heads), dim3(256), smem, st, pp);
+    RF_LAUNCH_CHECK("rf_attention");
+    return 0;
+}
+
+template <int D, int KV_TILE>
+static int launch_attn_pipe(const AttnParams& p, int B, hipStream_t st) {
+    constexpr int smem = 3 * (KV_TILE * D * 2 + 48 * (KV_TILE * 2 + 16));
+    auto k = attention_pipe_kernel<D, KV_TILE>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+    AttnParams pp = p;
+    pp.nqb = (p.Nq + 255) / 256;
+    hipLaunchKernelGGL(k, dim3(pp.nqb * B * p.heads), dim3(256), smem, st, pp);
+    RF_LAUNCH_CHECK("rf_attention");
+    return 0;
+}
+
 template <typename T, int D, int QB, int KV_TILE = 64, int NW = 4>
 static int launch_attn_qb(const AttnParams& p, int B, hipStream_t st) {
     constexpr int VEC = elem<T>::VEC, KSTEP = 2 * VEC, STEPS = (D + KSTEP - 1) / KSTEP, DVB = (D + 31) / 32;
@@ -368,6 +909,13 @@ static int launch_attn(const AttnParams& p, int B, hipStream_t st) {
     if constexpr (sizeof(T) == 2 && D <= 40) {
         static const int kt = [] { const char* e = getenv("RF_ATTN_KT"); return e ? atoi(e) : 128; }();
         if ((long long)((p.Nq + 255) / 256) * B * p.heads >= 512) {
+            // long sequences of whole tiles: the in-wave software-pipelined kernels (RF_ATTN_PIPE=2, default: both operands by LDS-DMA;
+            // 1: K by DMA, V through registers; 0: the generic kernel).  Same box, N = 4096: 533 / 543 / 607 us.
+            static const int pipe = [] { const char* e = getenv("RF_ATTN_PIPE"); return e ? atoi(e) : 2; }();
+            if constexpr (D == 40) {
+                if (pipe == 2 && p.Nk % 64 == 0 && p.Nk >= 1024) return launch_attn_dma<D>(p, B, st);
+                if (pipe && p.Nk % 128 == 0 && p.Nk >= 1024) return launch_attn_pipe<D, 128>(p, B, st);
+            }
             // 8-wave blocks (both waves of a SIMD on one staged tile) measured 608 vs 586 us at N = 4096: opt-in only (RF_ATTN_NW=8)
             static const int nw = [] { const char* e = getenv("RF_ATTN_NW"); return e ? atoi(e) : 4; }();
             if (kt == 128 && p.Nk >= 1024 && nw == 8 && (long long)((p.Nq + 511) / 512) * B * p.heads >= 512)

@@ -7,9 +7,9 @@ unit=$1; src=$2; tag=$3
 mkdir -p $ROOT/reface_amd/lib/alt
 extra=""
 [ "$unit" = attention ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $extra -I$ROOT/reface_amd/csrc -I$ROOT/include -c $src -o $ROOT/reface_amd/lib/alt/$tag.$unit.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $extra $VARIANT_DEFS -I$ROOT/reface_amd/csrc -I$ROOT/include -c $src -o $ROOT/reface_amd/lib/alt/$tag.$unit.o
 objs=""
-for u in gemm norm attention elementwise encoder; do
+for u in gemm norm attention elementwise encoder ffn; do
   if [ $u = $unit ]; then objs="$objs $ROOT/reface_amd/lib/alt/$tag.$unit.o"; else objs="$objs $ROOT/reface_amd/lib/$u.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/reface_amd/lib/alt/$tag.so $objs
