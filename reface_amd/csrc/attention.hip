@@ -629,7 +629,7 @@ template <int OFF> __device__ __forceinline__ u32x2_t ds_read_tr16(const char* p
 // 3-stage kernel: 585 -> 508 us).  V^T fragments come out of the row-major image with ds_read_b64_tr_b16 (lane i of a 16-lane group
 // receives column i of the [4 keys][16 columns] block the group addresses; tools/tr_probe.py), two reads per MFMA operand; the 24
 // rows of O^T beyond the head dim multiply whatever follows the row and are never stored -- except rows 48..63, whose lanes read a
-// run of ones, so the MFMA also delivers the softmax denominator.  One wave issues a whole tile (10 one-KiB pieces), waves taking turns.
+// run of ones, so the MFMA also delivers the softmax denominator.  Every wave issues two or three of a tile's ten one-KiB pieces.
 // The running max moves only when a score exceeds it by 2^8 in the exp2 domain (P <= 256; the O rescale becomes rare).
 template <int D>
 __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams p) {
@@ -643,7 +643,8 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
     static_assert(K_BYTES % 1024 == 0 && NU == 2, "whole DMA pieces; two units per tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 31, lh = lane >> 5;
     int bid = blockIdx.x;
     {
@@ -676,17 +677,26 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
     // ---- staging: tile X is issued by wave X % 4
     const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, (unsigned)((((long long)p.Nk - 1) * p.ldk + D) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, (unsigned)((((long long)p.Nk - 1) * p.ldv + D) * 2), 0x00020000);
+    // Every wave issues its share of every tile: K piece `wave` and V piece `wave` (pieces 0..3), waves 0 / 1 also K / V piece 4.
+    // The per-lane source offsets do not depend on the tile.
+    int offA, offB, offC;
+    {
+        const int g = wave * 64 + lane, row = g / VPR, ch = g - row * VPR;
+        offA = row * p.ldk * 2 + ch * 16;
+        offB = row * p.ldv * 2 + ch * 16;
+        const int g4 = 4 * 64 + lane, row4 = g4 / VPR, ch4 = g4 - row4 * VPR;
+        offC = row4 * (wave == 0 ? p.ldk : p.ldv) * 2 + ch4 * 16;
+    }
     auto dma_tile = [&](int tile, int stage) {
-#pragma unroll
-        for (int pc = 0; pc < PIECES; ++pc) {
-            const int g = pc * 64 + lane, row = g / VPR, ch = g - row * VPR;
-            const int vk = row * p.ldk * 2 + ch * 16, vv = row * p.ldv * 2 + ch * 16;
-            const int sk = tile * (KT * p.ldk * 2), sv = tile * (KT * p.ldv * 2);
-            char* const dk = smem + stage * STAGE + pc * 1024;
-            char* const dv = dk + K_BYTES;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)dk, 16, vk, sk, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void*)dv, 16, vv, sv, 0, 0);
-        }
+        const int sk = tile * (KT * p.ldk * 2), sv = tile * (KT * p.ldv * 2);
+        char* const dk = smem + stage * STAGE + wave * 1024;
+        char* const dv = dk + K_BYTES;
+        char* const dk4 = smem + stage * STAGE + 4 * 1024;
+        char* const dv4 = dk4 + K_BYTES;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)dk, 16, offA, sk, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void*)dv, 16, offB, sv, 0, 0);
+        if (wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)dk4, 16, offC, sk, 0, 0);
+        if (wave == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void*)dv4, 16, offC, sv, 0, 0);
     };
 
     // ---- per-lane LDS offsets of the fragments (unit 0 of a stage)
@@ -718,8 +728,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
 
     const int ntiles = p.Nk / KT;                       // >= NSTG (dispatch)
 #pragma unroll
-    for (int x = 0; x < NSTG - 1; ++x)
-        if ((x & 3) == wave) dma_tile(x, x);
+    for (int x = 0; x < NSTG - 1; ++x) dma_tile(x, x);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -743,6 +752,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
     }
 #define RF_LOAD_VF(sb, un) RF_LOAD_VF1(sb, un, 0, 0) RF_LOAD_VF1(sb, un, 0, 1) RF_LOAD_VF1(sb, un, 1, 0) RF_LOAD_VF1(sb, un, 1, 1)
 #define RF_WAIT_VF() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[1][0]), "+v"(vf[1][1]));
+#define RF_WAIT_KF() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]));
 #define RF_QK(dst)                                                                                              \
     {                                                                                                           \
         _Pragma("unroll") for (int st = 0; st < 3; ++st)                                                        \
@@ -758,6 +768,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
                 _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) AttnMma<T>::mma(o[qb][i], vf[g][i], pf[qb][g]);                    \
     }
     RF_LOAD_KF(smem, 0)
+    RF_WAIT_KF()
     RF_QK(S[0])
     RF_LOAD_VF(smem, 0)                                  // the first step multiplies P = 0 with tile 0's own V rows
     int sc = 0;                                          // stage of tile t
@@ -771,9 +782,9 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
             f32x16_t* const cur = S[uu & 1];
             f32x16_t* const nxt = S[(uu + 1) & 1];
             // ---- region 1: PV of the previous unit beside the max of this one
+            RF_WAIT_VF()                                   // issued a region ago: no stall -- and nothing younger is in flight yet
             if (uu == NU - 1) RF_LOAD_KF(sbn, 0) else RF_LOAD_KF(sb, uu + 1)
             __builtin_amdgcn_sched_barrier(0);
-            RF_WAIT_VF()
             RF_PV()
             float m_new[QB];
             bool moved = false;
@@ -787,15 +798,14 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
                 moved |= mx > m_run[qb] + thr;
             }
             if (uu == 0) {
-                // tile t+1 (read from this iteration's second half on) was issued by wave (t+1) % 4, which has since issued tile t+5 only
-                if (((t + 1) & 3) == wave) {
-                    if (t + 5 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
+                // tile t+1 (read from this iteration's second half on) must have landed: this wave has tiles t+2 .. t+5 behind it, two or
+                // three pieces each -- "at most 8 outstanding" covers both (for the 3-piece waves it also waits for tile t+2)
+                if (t + 5 < ntiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();                         // every wave is past the last read of tile t-1: its stage takes tile t+6
-                if (((t + NSTG - 1) & 3) == wave && t + NSTG - 1 < ntiles) dma_tile(t + NSTG - 1, sp);
+                if (t + NSTG - 1 < ntiles) dma_tile(t + NSTG - 1, sp);
             }
-            if (__any(moved)) {
+            if (__builtin_expect(__any(moved), 0)) {      // out of line: the common path falls through
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
                     const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new[qb]) * c2);
@@ -807,6 +817,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
                 }
             }
             // ---- region 2: QK^T of the next unit beside exp2 / pack of this one
+            RF_WAIT_KF()                                   // before the (asm) V reads go out: a counted wait would otherwise cover them too
             RF_LOAD_VF(sb, uu)
             __builtin_amdgcn_sched_barrier(0);
             RF_QK(nxt)
@@ -818,8 +829,9 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 8 * g + 2 * e;
-                        const f32x2_t a = __builtin_elementwise_fma(f32x2_t{cur[qb][r], cur[qb][r + 1]}, f32x2_t{c2, c2}, f32x2_t{-mc, -mc});
-                        const float e0 = __builtin_amdgcn_exp2f(a[0]), e1 = __builtin_amdgcn_exp2f(a[1]);
+                        // scalar FMAs: a packed-f32 VALU operation issued beside MFMAs costs ~20 cycles more than the two it replaces
+                        const float a0 = __builtin_fmaf(cur[qb][r], c2, -mc), a1 = __builtin_fmaf(cur[qb][r + 1], c2, -mc);
+                        const float e0 = __builtin_amdgcn_exp2f(a0), e1 = __builtin_amdgcn_exp2f(a1);
                         pf[qb][g][e] = pack_bf2(e0, e1);
                     }
             }
@@ -831,6 +843,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
     RF_WAIT_VF()
     RF_PV()
 #undef RF_WAIT_VF
+#undef RF_WAIT_KF
 #undef RF_LOAD_KF
 #undef RF_LOAD_VF
 #undef RF_LOAD_VF1
@@ -866,7 +879,9 @@ static int launch_attn_dma(const AttnParams& p, int B, hipStream_t st) {
     if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
     AttnParams pp = p;
     pp.nqb = (p.Nq + 255) / 256;
-    hipLaunchKernelGGL(k, dim3(pp.nqb * B * p.heads), dim3(256), smem, st, pp);
+    static const int pad = [] { const char* e = getenv("RF_ATTN_SMEM_PAD"); return e ? atoi(e) : 0; }();      // experiment: one block per CU
+    if (pad) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem + pad);
+    hipLaunchKernelGGL(k, dim3(pp.nqb * B * p.heads), dim3(256), smem + pad, st, pp);
     RF_LAUNCH_CHECK("rf_attention");
     return 0;
 }

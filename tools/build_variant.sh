@@ -6,7 +6,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 unit=$1; src=$2; tag=$3
 mkdir -p $ROOT/reface_amd/lib/alt
 extra=""
-[ "$unit" = attention ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
+[ "$unit" = attention ] && extra="-mllvm -amdgpu-mfma-vgpr-form -fno-slp-vectorize"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $extra $VARIANT_DEFS -I$ROOT/reface_amd/csrc -I$ROOT/include -c $src -o $ROOT/reface_amd/lib/alt/$tag.$unit.o
 objs=""
 for u in gemm norm attention elementwise encoder ffn; do
