@@ -358,258 +358,9 @@ __device__ __forceinline__ float max_xor32(float v) {
 // 64 queries and every step issues, in ONE basic block each,
 //     region 1:  O^T += V^T P^T of unit u-1   (8 MFMAs)   beside   the running max of unit u          (VALU)
 //     region 2:  S^T  = K Q^T   of unit u+1   (6 MFMAs)   beside   exp2 / pack of unit u -> P^T       (VALU)
-// with two S accumulator sets alternating.  Three LDS stages of 128 keys and ONE barrier per stage (placed after region 1 of a
-// stage's first unit: every wave is then done with the previous stage, whose buffer takes the stage after next); K rows arrive by
-// LDS-DMA as an unpadded 80-byte-row image (5 sixteen-byte slots per row: odd, so the fragment reads are conflict-free; the sixth
-// k-slot of the zero-padded head dim re-reads slot 4 against zero Q), V through registers into the transposed image (48 rows:
-// 40 + the all-ones row that makes the MFMA produce the softmax denominator + zero rows).  Needs Nk % 128 == 0, Nk >= 256.
-template <int D, int KV_TILE>
-__global__ __launch_bounds__(256, 2) void attention_pipe_kernel(const AttnParams p) {
-    typedef bf16_t T;
-    static_assert(D > 32 && D < 48 && D % 8 == 0 && KV_TILE % 64 == 0, "three 16-wide k-steps, a spare V^T row, an even unit count");
-    constexpr int NT = 256, QB = 2, NU = KV_TILE / 32, NSTG = 3;
-    constexpr int VPR = D / 8;                          // 16-byte slots per K / V row
-    constexpr int KROW = D * 2;                         // unpadded K rows
-    constexpr int VROWS = 48, VROW = KV_TILE * 2 + 16;  // V^T rows (dv), row bytes ((VROW / 16) odd)
-    constexpr int K_BYTES = KV_TILE * KROW, STAGE = K_BYTES + VROWS * VROW;
-    constexpr int KDMA = KV_TILE * VPR / 64;            // 1-KiB DMA pieces per K tile
-    static_assert((KV_TILE * VPR) % 64 == 0 && STAGE % 16 == 0, "whole DMA pieces");
-    constexpr int NKD = (KDMA + 3) / 4;                 // pieces per wave
-    constexpr int NVP = ((KV_TILE / 2) * VPR + NT - 1) / NT;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lq = lane & 31, lh = lane >> 5;
-    int bid = blockIdx.x;
-    {
-        const int nwg = gridDim.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int bh = bid / p.nqb, qblk = bid - bh * p.nqb;
-    const int b = bh / p.heads, h = bh % p.heads;
-    const int q0 = qblk * (4 * 32 * QB) + wave * (32 * QB);
-    const T* Q = (const T*)p.q + b * p.sq + h * D;
-    const T* K = (const T*)p.k + b * p.sk + h * D;
-    const T* V = (const T*)p.v + b * p.sv + h * D;
-    T* O = (T*)p.out + b * p.so + h * D;
-
-    u32x4_t qf[QB][3];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const int qi = q0 + qb * 32 + lq;
-#pragma unroll
-        for (int st = 0; st < 3; ++st) {
-            const int c = st * 16 + lh * 8;
-            u32x4_t v = {0u, 0u, 0u, 0u};
-            if (qi < p.Nq && c < D) v = *(const u32x4_t*)(Q + (long long)qi * p.ldq + c);
-            qf[qb][st] = v;
-        }
-    }
-    for (int i = tid; i < NSTG * STAGE / 16; i += NT) ((u32x4_t*)smem)[i] = u32x4_t{0u, 0u, 0u, 0u};
-    __syncthreads();
-    for (int i = tid; i < NSTG * KV_TILE; i += NT) {
-        const int stg = i / KV_TILE, kcol = i - stg * KV_TILE;
-        *(T*)(smem + stg * STAGE + K_BYTES + D * VROW + kcol * 2) = (T)0x3f80;       // the ones row
-    }
-
-    // ---- staging
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, (unsigned)((((long long)p.Nk - 1) * p.ldk + D) * 2), 0x00020000);
-    int koff[NKD];                                      // byte offset of this lane's slot in piece wave + 4 i
-#pragma unroll
-    for (int i = 0; i < NKD; ++i) {
-        const int g = (wave + 4 * i) * 64 + lane, row = g / VPR, ch = g - row * VPR;
-        koff[i] = row * p.ldk * 2 + ch * 16;
-    }
-    auto dma_k = [&](int tile, int stage) {
-#pragma unroll
-        for (int i = 0; i < NKD; ++i) {
-            const int piece = wave + 4 * i;
-            if (piece < KDMA) {
-                const int so = tile * (KV_TILE * p.ldk * 2);
-                char* const dst = smem + stage * STAGE + piece * 1024;
-                const int vo = koff[i];          // plain locals only in the builtin's argument list (the host pass drops the kernel stub otherwise)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)dst, 16, vo, so, 0, 0);
-            }
-        }
-    };
-    u32x4_t rv0[NVP], rv1[NVP];
-    auto load_v = [&](int kv0) {
-#pragma unroll
-        for (int u = 0; u < NVP; ++u) {
-            const int idx = tid + u * NT;
-            const int c = idx / (KV_TILE / 2), pr = idx - c * (KV_TILE / 2);
-            if (idx < (KV_TILE / 2) * VPR) {
-                const T* src = V + (long long)(kv0 + 2 * pr) * p.ldv + c * 8;
-                rv0[u] = *(const u32x4_t*)src;
-                rv1[u] = *(const u32x4_t*)(src + p.ldv);
-            }
-        }
-    };
-    auto store_v = [&](int stage) {
-        char* const ldsV = smem + stage * STAGE + K_BYTES;
-#pragma unroll
-        for (int u = 0; u < NVP; ++u) {
-            const int idx = tid + u * NT;
-            if (idx < (KV_TILE / 2) * VPR) {
-                const int c = idx / (KV_TILE / 2), pr = idx - c * (KV_TILE / 2);
-                const int r = 2 * pr;
-                const int pos = (r & ~15) + vt_pos<T>(r & 15);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t x0 = rv0[u][e], x1 = rv1[u][e];
-                    *(uint32_t*)(ldsV + (c * 8 + 2 * e) * VROW + pos * 2) = (x0 & 0xffffu) | (x1 << 16);
-                    *(uint32_t*)(ldsV + (c * 8 + 2 * e + 1) * VROW + pos * 2) = (x0 >> 16) | (x1 & 0xffff0000u);
-                }
-            }
-        }
-    };
-
-    // ---- per-lane LDS offsets of the fragments
-    int kfo[3];                                         // K fragment of k-step st, key lq of unit 0
-#pragma unroll
-    for (int st = 0; st < 3; ++st) {
-        const int slot = st * 2 + lh;
-        kfo[st] = lq * KROW + (slot < VPR ? slot : VPR - 1) * 16;
-    }
-    int vfo[2];                                         // V^T fragment of row block i, keys 0..15 of unit 0
-    vfo[0] = K_BYTES + lq * VROW + lh * 16;
-    vfo[1] = K_BYTES + (lq < 16 ? 32 + lq : VROWS - 1) * VROW + lh * 16;        // rows >= 48 do not exist: the last (zero) row
-
-    f32x16_t o[QB][2];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[qb][i][r] = 0.f;
-    float m_run[QB] = {-INFINITY, -INFINITY};
-    const float c2 = p.scale_log2e;
-    const float thr = 8.0f / c2;                        // the running max is only raised when a score exceeds it by 2^8 in the exp2 domain
-    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-    const int ntiles = p.Nk / KV_TILE;
-    __syncthreads();                                    // zero fill + ones rows done
-    dma_k(0, 0);
-    dma_k(1, 1);
-    load_v(0);
-    store_v(0);
-    load_v(KV_TILE);
-    store_v(1);
-    __syncthreads();
-
-    f32x16_t S[2][QB];
-    u32x4_t pf[QB][2];                                  // P^T of the previous unit: [query block][16-key group]
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) pf[qb][0] = pf[qb][1] = u32x4_t{0u, 0u, 0u, 0u};
-    // S^T of (stage base sb, unit un) -> dst
-#define RF_QK(dst, sb, un)                                                                                      \
-    {                                                                                                           \
-        _Pragma("unroll") for (int st = 0; st < 3; ++st) {                                                      \
-            const u32x4_t kf = *(const u32x4_t*)((sb) + (un) * (32 * KROW) + kfo[st]);                          \
-            _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) {                                                 \
-                if (st == 0) dst[qb] = zero16;                                                                  \
-                AttnMma<T>::mma(dst[qb], kf, qf[qb][st]);                                                       \
-            }                                                                                                   \
-        }                                                                                                       \
-    }
-    // O^T += V^T(stage base sb, unit un) pf
-#define RF_PV(sb, un)                                                                                           \
-    {                                                                                                           \
-        _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                           \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                     \
-                const u32x4_t vf = *(const u32x4_t*)((sb) + vfo[i] + ((un) * 32 + g * 16) * 2);                 \
-                _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) AttnMma<T>::mma(o[qb][i], vf, pf[qb][g]);     \
-            }                                                                                                   \
-    }
-    RF_QK(S[0], smem, 0)
-    int sc = 0;                                          // stage of tile t
-    const char* prev_sb = smem;                          // stage / unit of the unit whose P^T sits in pf (first step: P = 0)
-    for (int t = 0; t < ntiles; ++t) {
-        const int sn = sc == NSTG - 1 ? 0 : sc + 1, sn2 = sn == NSTG - 1 ? 0 : sn + 1;
-        const char* const sb = smem + sc * STAGE;
-        const char* const sbn = smem + sn * STAGE;
-#pragma unroll
-        for (int uu = 0; uu < NU; ++uu) {
-            f32x16_t* const cur = S[uu & 1];
-            f32x16_t* const nxt = S[(uu + 1) & 1];
-            // ---- region 1: PV of the previous unit beside the max of this one
-            if (uu == 0) RF_PV(prev_sb, NU - 1) else RF_PV(sb, uu - 1)
-            float m_new[QB];
-            bool moved = false;
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                float mx = cur[qb][0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, cur[qb][r]);
-                mx = max_xor32(mx);
-                m_new[qb] = fmaxf(m_run[qb], mx);
-                moved |= mx > m_run[qb] + thr;
-            }
-            if (uu == 0) {
-                __syncthreads();                         // every wave is past the last read of tile t-1: its stage takes tile t+2
-                if (t + 2 < ntiles) {
-                    dma_k(t + 2, sn2);
-                    load_v((t + 2) * KV_TILE);
-                }
-            }
-            if (__any(moved)) {                          // some query's running max moved (wave-uniform; rare after the first tiles)
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) {
-                    const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new[qb]) * c2);     // -inf on the first unit -> 0
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) o[qb][i][r] *= alpha;
-                    m_run[qb] = m_new[qb];
-                }
-            }
-            // ---- region 2: QK^T of the next unit beside exp2 / pack of this one
-            if (uu == NU - 1) RF_QK(nxt, sbn, 0) else RF_QK(nxt, sb, uu + 1)
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                const float mc = m_run[qb] * c2;
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 8 * g + 2 * e;
-                        const f32x2_t a = __builtin_elementwise_fma(f32x2_t{cur[qb][r], cur[qb][r + 1]}, f32x2_t{c2, c2}, f32x2_t{-mc, -mc});
-                        const float e0 = __builtin_amdgcn_exp2f(a[0]), e1 = __builtin_amdgcn_exp2f(a[1]);
-                        pf[qb][g][e] = pack_bf2(e0, e1);
-                    }
-            }
-            if (uu == NU - 1 && t + 2 < ntiles) store_v(sn2);
-        }
-        prev_sb = sb;
-        sc = sn;
-    }
-    RF_PV(prev_sb, NU - 1)
-#undef RF_QK
-#undef RF_PV
-    // ---- normalise and store: lane holds O[q][dv = i*32 + 8*(r>>2) + 4*lh + (r&3)]; row D of O^T (lane half 0) is the denominator
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const float l_tot = __shfl(o[qb][D / 32][((D % 32) / 8) * 4], lq, 64);
-        const float inv = 1.0f / l_tot;
-        const int qi = q0 + qb * 32 + lq;
-        if (qi < p.Nq) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int dv = i * 32 + 8 * g + 4 * lh;
-                    if (dv < D) {
-                        u32x2_t w;
-                        w[0] = pack_bf2(o[qb][i][4 * g] * inv, o[qb][i][4 * g + 1] * inv);
-                        w[1] = pack_bf2(o[qb][i][4 * g + 2] * inv, o[qb][i][4 * g + 3] * inv);
-                        *(u32x2_t*)(O + (long long)qi * p.ldo + dv) = w;
-                    }
-                }
-        }
-    }
-}
-
+// with two S accumulator sets alternating (tools/mfma_valu_probe.py: up to 5 VALU operations between two MFMAs of a wave are free,
+// beyond that the group costs its VALU time + ~21 cycles per MFMA).  A first version staged V through registers into a transposed
+// image (3 stages of 128 keys): 543 us at N = 4096 against 607 us for the generic kernel and 533 us for the kernel below.
 
 // ds_read_b64_tr_b16 as inline asm: through the builtin the compiler cannot tell the read from the LDS-DMA writes in flight and puts
 // an s_waitcnt vmcnt(0) in front of it (every tile then waits for the DMA issued a moment earlier).  The asm is invisible to the
@@ -624,9 +375,8 @@ template <int OFF> __device__ __forceinline__ u32x2_t ds_read_tr16(const char* p
 
 // ---- the same in-wave pipeline with BOTH operands staged by LDS-DMA ----
 // K and V tiles (64 keys) arrive as unpadded row-major images (80-byte rows) through `buffer_load ... lds`: no staging registers, no
-// VALU, no LDS stores, and a ring of 7 stages (70 KB, two blocks per CU) puts every tile 6 iterations (~2.5 us) ahead of its first use --
-// the register-staged kernels expose the L2 / fabric latency of ONE tile of look-ahead on every tile (removing the K DMA alone from the
-// 3-stage kernel: 585 -> 508 us).  V^T fragments come out of the row-major image with ds_read_b64_tr_b16 (lane i of a 16-lane group
+// VALU, no LDS stores, and a ring of 7 stages (70 KB, two blocks per CU) puts every tile 6 iterations (~2.5 us) ahead of its first use.
+// V^T fragments come out of the row-major image with ds_read_b64_tr_b16 (lane i of a 16-lane group
 // receives column i of the [4 keys][16 columns] block the group addresses; tools/tr_probe.py), two reads per MFMA operand; the 24
 // rows of O^T beyond the head dim multiply whatever follows the row and are never stored -- except rows 48..63, whose lanes read a
 // run of ones, so the MFMA also delivers the softmax denominator.  Every wave issues two or three of a tile's ten one-KiB pieces.
@@ -886,19 +636,6 @@ static int launch_attn_dma(const AttnParams& p, int B, hipStream_t st) {
     return 0;
 }
 
-template <int D, int KV_TILE>
-static int launch_attn_pipe(const AttnParams& p, int B, hipStream_t st) {
-    constexpr int smem = 3 * (KV_TILE * D * 2 + 48 * (KV_TILE * 2 + 16));
-    auto k = attention_pipe_kernel<D, KV_TILE>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
-    AttnParams pp = p;
-    pp.nqb = (p.Nq + 255) / 256;
-    hipLaunchKernelGGL(k, dim3(pp.nqb * B * p.heads), dim3(256), smem, st, pp);
-    RF_LAUNCH_CHECK("rf_attention");
-    return 0;
-}
-
 template <typename T, int D, int QB, int KV_TILE = 64, int NW = 4>
 static int launch_attn_qb(const AttnParams& p, int B, hipStream_t st) {
     constexpr int VEC = elem<T>::VEC, KSTEP = 2 * VEC, STEPS = (D + KSTEP - 1) / KSTEP, DVB = (D + 31) / 32;
@@ -924,12 +661,10 @@ static int launch_attn(const AttnParams& p, int B, hipStream_t st) {
     if constexpr (sizeof(T) == 2 && D <= 40) {
         static const int kt = [] { const char* e = getenv("RF_ATTN_KT"); return e ? atoi(e) : 128; }();
         if ((long long)((p.Nq + 255) / 256) * B * p.heads >= 512) {
-            // long sequences of whole tiles: the in-wave software-pipelined kernels (RF_ATTN_PIPE=2, default: both operands by LDS-DMA;
-            // 1: K by DMA, V through registers; 0: the generic kernel).  Same box, N = 4096: 533 / 543 / 607 us.
-            static const int pipe = [] { const char* e = getenv("RF_ATTN_PIPE"); return e ? atoi(e) : 2; }();
+            // long sequences of whole 64-key tiles: the in-wave software-pipelined kernel (RF_ATTN_PIPE=0: the generic one)
+            static const int pipe = [] { const char* e = getenv("RF_ATTN_PIPE"); return e ? atoi(e) : 1; }();
             if constexpr (D == 40) {
-                if (pipe == 2 && p.Nk % 64 == 0 && p.Nk >= 1024) return launch_attn_dma<D>(p, B, st);
-                if (pipe && p.Nk % 128 == 0 && p.Nk >= 1024) return launch_attn_pipe<D, 128>(p, B, st);
+                if (pipe && p.Nk % 64 == 0 && p.Nk >= 1024) return launch_attn_dma<D>(p, B, st);
             }
             // 8-wave blocks (both waves of a SIMD on one staged tile) measured 608 vs 586 us at N = 4096: opt-in only (RF_ATTN_NW=8)
             static const int nw = [] { const char* e = getenv("RF_ATTN_NW"); return e ? atoi(e) : 4; }();

@@ -433,7 +433,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         };
         // one k-step: its MFMAs, the fetch of the next step's fragments (k-step 3 fetches from the other stage, after the
         // barrier; on the last tile that fetch reads stale bytes that are never used) and a third of the next tile's pieces
-        auto phase = [&](auto KK, int stage, bool more) {
+        auto phase = [&](auto KK, int stage, bool more, bool deep) {
             constexpr int kk = decltype(KK)::value;
             constexpr int cur = kk & 1, nx = cur ^ 1;
             constexpr int fbc = ROT ? 0 : cur, fbn = ROT ? 0 : nx;
@@ -452,7 +452,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             if (kk == 3) {
                 // own pieces of the next tile have landed and every fragment of this tile is in registers; past the barrier
                 // that holds for all waves: this stage may be overwritten (tile kt+2) and the other stage may be read
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                // (NST > 2: tiles kt+2 .. kt+NST-1 stay in flight behind the one that must have landed -- `deep` says all of them exist)
+                if (NST > 2 && deep) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * NP) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
 #pragma unroll
@@ -478,9 +480,20 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         };
         using std::integral_constant;
         if (nk > 0) {
-            // prologue: tile 0 lands, its first fragments are fetched, the issue state points at tile 1
+            // prologue: tile 0 lands, its first fragments are fetched, the issue state points at the next tile to issue (tile NST)
             issue_pieces(0, 0, AV);               // (its W pieces are already in flight)
-            if (nk > 1) {
+            if constexpr (NST > 2) {
+                static_assert(!W8, "the deep ring is for bf16 / fp32 weights");
+#pragma unroll
+                for (int s = 1; s < NST; ++s)
+                    if (s < nk) {
+                        next_tile();
+                        issue_pieces(s, 0, NP);
+                    }
+                if (nk > NST) next_tile();
+                if (nk >= NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * NP) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if (nk > 1) {
                 next_tile();
                 issue_pieces(1, 0, NP);
                 if (nk > 2) next_tile();
@@ -495,13 +508,32 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
             for (int j = 0; j < TN; ++j) load_b(0, j, curB + j * 4096 + (fkb[0] ^ curPar));
         }
+        if constexpr (NST > 2) {
+            // ring of NST stages: tile kt is multiplied out of stage kt % NST while tiles kt+1 .. kt+NST-1 are in LDS or in flight; the
+            // stage it frees takes tile kt+NST.  For launches of at most one block per CU, where no second block covers the latency
+            // of the single tile of look-ahead that two stages give.
+            const char* const baseA = curA;
+            int sc = 0, so = 1;                   // stages of the tile being multiplied / of the next one
+            for (int kt = 0; kt < nk; ++kt) {
+                const bool more = kt + NST < nk, deep = kt + NST - 1 < nk;
+                phase(integral_constant<int, 0>{}, sc, more, deep);
+                phase(integral_constant<int, 1>{}, sc, more, deep);
+                phase(integral_constant<int, 2>{}, sc, more, deep);
+                phase(integral_constant<int, 3>{}, sc, more, deep);
+                if (kt + NST + 1 < nk) next_tile();
+                sc = so;
+                so = so + 1 == NST ? 0 : so + 1;
+                curA = othA; othA = baseA + so * (BM * 128);
+                curB = othB; othB = wbase + so * (BN * 128);
+            }
+        } else {
         for (int kt = 0; kt < nk; ++kt) {
             const int stage = kt & 1;
             const bool more = kt + 2 < nk;
-            phase(integral_constant<int, 0>{}, stage, more);
-            phase(integral_constant<int, 1>{}, stage, more);
-            phase(integral_constant<int, 2>{}, stage, more);
-            phase(integral_constant<int, 3>{}, stage, more);
+            phase(integral_constant<int, 0>{}, stage, more, false);
+            phase(integral_constant<int, 1>{}, stage, more, false);
+            phase(integral_constant<int, 2>{}, stage, more, false);
+            phase(integral_constant<int, 3>{}, stage, more, false);
             if (kt + 3 < nk) next_tile();
             const char* t = curA; curA = othA; othA = t;
             if constexpr (W8) {
@@ -512,6 +544,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             } else {
                 t = curB; curB = othB; othB = t;
             }
+        }
         }
         __syncthreads();
     } else {
@@ -1259,7 +1292,10 @@ static int pick_splitk(const rf_conv_gemm_desc* d, const GemmParams& p, long lon
 template <typename T, typename TO, int WM, int WN, int TM, int TN, bool W8 = false>
 static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr int NST = 2;            // LDS stages of the direct-to-LDS main loop (3 stages at 1 block/CU measured slower)
+    constexpr int NST = 2;            // LDS stages of the direct-to-LDS main loop (3 stages of the big tiles at 1 block/CU measured slower)
+    // The 4-wave 128x160 tile also exists with a ring of 4 stages (147 KB: one block per CU), for grids of at most one block per CU
+    constexpr bool DEEP_OK = WM * WN == 4 && TM * TN == 5 && !W8;
+    constexpr int NSTD = DEEP_OK ? 4 : 2;
     constexpr int NCH = (BM * BN * 4 > 96 * 1024) ? WM : 1;
     constexpr int smem_ml = NST * (BM + BN) * 128, smem_ep = (BM / NCH) * BN * 4;
     constexpr int smem = smem_ml > smem_ep ? smem_ml : smem_ep;
@@ -1304,12 +1340,22 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
 #define RF_LAUNCH_VARIANT(CONV_, GLDS_, EPI_)                                                                                   \
     {                                                                                                                            \
         constexpr int E_ = (EPI_ == 2 && PACKED_OK) ? 2 : ((EPI_ == 1 && DIRECT_OK) ? 1 : 0);                                   \
-        auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NST : 2), E_, (W8 && GLDS_)>;                   \
-        static bool attr = false;                                                                                                \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem_pk > smem ? smem_pk : smem); attr = true; } \
-        hipLaunchKernelGGL(k, grid, block, smem_l, st, p);                                                                       \
+        if (GLDS_ && deep) {                                                                                                     \
+            auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NSTD : 2), E_, (W8 && GLDS_)>;              \
+            static bool attr = false;                                                                                            \
+            if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem_deep); attr = true; } \
+            hipLaunchKernelGGL(k, grid, block, smem_deep, st, p);                                                                \
+        } else {                                                                                                                 \
+            auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NST : 2), E_, (W8 && GLDS_)>;               \
+            static bool attr = false;                                                                                            \
+            if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem_pk > smem ? smem_pk : smem); attr = true; } \
+            hipLaunchKernelGGL(k, grid, block, smem_l, st, p);                                                                   \
+        }                                                                                                                        \
     }
     const int esel = packed ? 2 : (direct ? 1 : 0);
+    static const int deep_env = [] { const char* e = getenv("RF_GEMM_DEEP"); return e ? atoi(e) : 0; }();        // largest grid (blocks) that takes the ring; off by default: 4096x1280x5120 68.3 -> 66.7 us alone, GEMM family 12.63 -> 12.69 ms in situ
+    constexpr int smem_deep = NSTD * (BM + BN) * 128 > smem ? NSTD * (BM + BN) * 128 : smem;
+    const bool deep = DEEP_OK && p.glds && !packed && (long long)grid.x * grid.y * grid.z <= deep_env;
     if (W8) RF_CHECK(p.glds, "rf_conv_gemm: fp8 weights need the direct-to-LDS main loop (one source, K and channel count multiples of 64)");
     if (conv && p.glds) {
         if (esel == 2) RF_LAUNCH_VARIANT(true, true, 2)
@@ -1365,11 +1411,12 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
         const long long nt = n320 ? N / 320 : (n256 ? N / 256 : 0);
         if (nt > 0) {
             if (mt256 * nt >= 192) return n320 ? launch_cfg<T, TO, 4, 2, 2, 5, W8>(d, p, conv, st) : launch_cfg<T, TO, 4, 2, 2, 4, W8>(d, p, conv, st);
+            // K up to ~90 tiles: two co-resident 4-wave 128x160 blocks per CU (each other's prologue / epilogue cover) beat one
+            // 8-wave 128x320 block in situ (sweep: -1.2 % per batch at 6000, worse again from 11520); RF_SHORTK overrides.  Also when K is
+            // too short for split-K to bring the 128x320 grid to size (4096 x 1280 x 1280: 23 us, against 26 us on 128x128 tiles).
+            static const int shortk = [] { const char* e = getenv("RF_SHORTK"); return e ? atoi(e) : 6000; }();
+            if (n320 && p.K <= shortk && mt128 * (N / 160) >= 256) return launch_cfg<T, TO, 4, 1, 1, 5, W8>(d, p, conv, st);
             if (mt128 * nt * pick_splitk(d, p, mt128 * nt, bk) >= 192) {
-                // K up to ~90 tiles: two co-resident 4-wave 128x160 blocks per CU (each other's prologue / epilogue cover) beat one
-                // 8-wave 128x320 block in situ (sweep: -1.2 % per batch at 6000, worse again from 11520); RF_SHORTK overrides
-                static const int shortk = [] { const char* e = getenv("RF_SHORTK"); return e ? atoi(e) : 6000; }();
-                if (n320 && p.K <= shortk && mt128 * (N / 160) >= 256) return launch_cfg<T, TO, 4, 1, 1, 5, W8>(d, p, conv, st);
                 return n320 ? launch_cfg<T, TO, 4, 2, 1, 5, W8>(d, p, conv, st) : launch_cfg<T, TO, 4, 2, 1, 4, W8>(d, p, conv, st);
             }
         }

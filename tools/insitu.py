@@ -22,10 +22,10 @@ dur = [d / len(segs) for d in dur]
 iso = json.load(open(sys.argv[2]))["step_launches"]
 merged = []
 for k in range(L):
-    n = names[segs[0][0] + k]
+    n = names[segs[-1][0] + k]
     if "splitk_reduce" in n:
         merged[-1][1] += dur[k]
-    elif n.startswith("void rf::") or "rf::" in n:
+    elif "rf::" in n or "gn_finalize_kernel" in n:
         merged.append([n, dur[k]])
 assert len(merged) == len(iso), (len(merged), len(iso))
 print(f"step: {sum(dur):.1f} us in-situ over {len(segs)} steps, {L} kernels/step")
