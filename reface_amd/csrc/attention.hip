@@ -419,7 +419,12 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
             const int c = st * 16 + lh * 8;
             u32x4_t v = {0u, 0u, 0u, 0u};
             if (qi < p.Nq && c < D) v = *(const u32x4_t*)(Q + (long long)qi * p.ldq + c);
-            qf[qb][st] = v;
+            // Q carries scale * log2(e): the scores come out of the MFMA in the exp2 domain (one bf16 rounding of q * c, once)
+            float f[8];
+            unpack16<T>(v, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] *= p.scale_log2e;
+            qf[qb][st] = pack16<T>(f);
         }
     }
 
@@ -463,6 +468,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
     // those rows of the MFMA accumulate sum_k P[k, q] -- the softmax denominator, at no VALU cost.
     const bool ones_lane = ((lane >> 4) & 1) != 0;
     const char* const ones_ptr = smem + ONES_OFF - 64;
+    const char* const ones_k = smem + ONES_OFF;          // 16 bytes of ones: the K fragment of the padded k-slot (see m_run)
 
     f32x16_t o[QB][2];
 #pragma unroll
@@ -471,11 +477,13 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[qb][i][r] = 0.f;
-    float m_run[QB] = {-INFINITY, -INFINITY};
-    const float c2 = p.scale_log2e;
-    const float thr = 8.0f / c2;                        // the running max is only raised when a score exceeds it by 2^8 in the exp2 domain
+    // Softmax reference point m_run (exp2 domain; set from the first unit, afterwards only raised, and only when a score exceeds it
+    // by `thr`: P = 2^(s - m_run) <= 2^8).  The subtraction rides in the MFMA: the zero-padded k-slot of the head dim (d = 40..47, lane
+    // half 1 of the third k-step) multiplies a K fragment of ONES with a Q fragment whose first element is -m_run, so the accumulators
+    // hold s - m_run and the exponentials need neither a subtraction nor a scale.  m_run is kept bf16-representable for that.
+    float m_run[QB] = {0.f, 0.f};
+    constexpr float thr = 8.0f;
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
     const int ntiles = p.Nk / KT;                       // >= NSTG (dispatch)
 #pragma unroll
     for (int x = 0; x < NSTG - 1; ++x) dma_tile(x, x);
@@ -491,7 +499,8 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
     u32x4_t kf[3], vf[2][2];
 #define RF_LOAD_KF(sb, un)                                                                                      \
     {                                                                                                           \
-        _Pragma("unroll") for (int st = 0; st < 3; ++st) kf[st] = *(const u32x4_t*)((sb) + (un) * (32 * KROW) + kfo[st]);             \
+        _Pragma("unroll") for (int st = 0; st < 2; ++st) kf[st] = *(const u32x4_t*)((sb) + (un) * (32 * KROW) + kfo[st]);             \
+        kf[2] = *(const u32x4_t*)(lh ? ones_k : (sb) + (un) * (32 * KROW) + kfo[2]);                            \
     }
 #define RF_LOAD_VF1(sb, un, g, i)                                                                               \
     {                                                                                                           \
@@ -536,17 +545,17 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
             if (uu == NU - 1) RF_LOAD_KF(sbn, 0) else RF_LOAD_KF(sb, uu + 1)
             __builtin_amdgcn_sched_barrier(0);
             RF_PV()
-            float m_new[QB];
+            float mx[QB];                                   // max of the relative scores s - m_run of this unit
             bool moved = false;
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
-                float mx = cur[qb][0];
+                float m = cur[qb][0];
 #pragma unroll
-                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, cur[qb][r]);
-                mx = max_xor32(mx);
-                m_new[qb] = fmaxf(m_run[qb], mx);
-                moved |= mx > m_run[qb] + thr;
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, cur[qb][r]);
+                mx[qb] = max_xor32(m);
+                moved |= mx[qb] > thr;
             }
+            moved |= (t == 0 && uu == 0);
             if (uu == 0) {
                 // tile t+1 (read from this iteration's second half on) must have landed: this wave has tiles t+2 .. t+5 behind it, two or
                 // three pieces each -- "at most 8 outstanding" covers both (for the 3-piece waves it also waits for tile t+2)
@@ -558,12 +567,20 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
             if (__builtin_expect(__any(moved), 0)) {      // out of line: the common path falls through
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
-                    const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new[qb]) * c2);
+                    // new reference: this unit's max (the first unit may also lower it), rounded UP to a bf16 value
+                    const float target = m_run[qb] + ((t == 0 && uu == 0) ? mx[qb] : fmaxf(mx[qb], 0.f));
+                    const uint32_t tb = as_u32(target);
+                    const float m_new = as_f32(target >= 0.f ? ((tb + 0xffffu) & 0xffff0000u) : (tb & 0xffff0000u));
+                    const float delta = m_new - m_run[qb];
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) o[qb][i][r] *= alpha;
-                    m_run[qb] = m_new[qb];
+                    m_run[qb] = m_new;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cur[qb][r] -= delta;          // this unit's scores were taken against the old reference
+                    if (lh) qf[qb][2][0] = (as_u32(-m_new) >> 16);                // lane half 1 of k-step 2: [-m_run, 0, ...] (exact: bf16 value)
                 }
             }
             // ---- region 2: QK^T of the next unit beside exp2 / pack of this one
@@ -573,15 +590,12 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
             RF_QK(nxt)
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
-                const float mc = m_run[qb] * c2;
 #pragma unroll
                 for (int g = 0; g < 2; ++g)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 8 * g + 2 * e;
-                        // scalar FMAs: a packed-f32 VALU operation issued beside MFMAs costs ~20 cycles more than the two it replaces
-                        const float a0 = __builtin_fmaf(cur[qb][r], c2, -mc), a1 = __builtin_fmaf(cur[qb][r + 1], c2, -mc);
-                        const float e0 = __builtin_amdgcn_exp2f(a0), e1 = __builtin_amdgcn_exp2f(a1);
+                        const float e0 = __builtin_amdgcn_exp2f(cur[qb][r]), e1 = __builtin_amdgcn_exp2f(cur[qb][r + 1]);
                         pf[qb][g][e] = pack_bf2(e0, e1);
                     }
             }
