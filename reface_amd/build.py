@@ -15,8 +15,7 @@ SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "encoder.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 # per-file extras.  attention: keep MFMA accumulators in VGPRs -- the online softmax reads every score and rescales O each
 # tile, and with AGPR accumulators hipcc emitted ~160 v_accvgpr_read/write per KV tile (40 % of the loop's VALU work).
-# -fno-slp-vectorize: the pipelined kernels keep their f32 FMAs scalar on purpose (packed f32 VALU beside MFMAs is slower).
-EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 

@@ -46,6 +46,7 @@ struct GemmParams {
     int splitk;      // > 1: blockIdx.z owns a K range and writes raw fp32 partial sums to `ws` (epilogue in splitk_reduce_kernel)
     float* ws;       // [splitk][M][N] fp32
     // fused GroupNorm statistics of `out` (rf_conv_gemm_desc.gn_*): up to two consumers with their own channel grouping
+    int mfast;             // tile order inside an XCD's run: 0 N-fastest, 1 M-fastest
     int gn_rows;
     double* gn_part[2];
     int gn_cpg[2], gn_coff[2], gn_slot[2], gn_nch[2];
@@ -143,7 +144,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+    // (mfast: M-fastest runs -- the M-tiles that share a W panel hit the same L2; chosen per launch by estimated traffic, launch_cfg)
+    const int tile_m = p.mfast ? bid % p.tiles_m : bid / p.tiles_n, tile_n = p.mfast ? bid / p.tiles_m : bid % p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const long long zb = blockIdx.y;
@@ -1301,6 +1303,18 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     constexpr int smem = smem_ml > smem_ep ? smem_ml : smem_ep;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
+    {
+        // Tile order inside each XCD's contiguous run of tiles (8 XCDs, one L2 each): the run touches m_x A panels and n_x W panels.
+        // N-fastest keeps an A panel in one L2 (large images); M-fastest keeps a W panel there -- at the 8x8 / 16x16 levels W is the big
+        // operand and N-fastest makes every XCD stream ALL of it (1024 x 1280 x 11520: 239 MB instead of 69 MB through the fabric).
+        static const int mf_env = [] { const char* e = getenv("RF_GEMM_MFAST"); return e ? atoi(e) : -1; }();
+        const long long tiles = (long long)p.tiles_m * p.tiles_n, run = (tiles + 7) / 8;
+        const double a_panel = (double)BM * (conv ? p.Ctot : p.K) * sizeof(T), w_panel = (double)BN * p.K * (W8 ? 1 : (int)sizeof(T));
+        const double n_mx = (double)((run + p.tiles_n - 1) / p.tiles_n + (run % p.tiles_n ? 1 : 0)), n_nx = (double)(run < p.tiles_n ? run : p.tiles_n);
+        const double m_mx = (double)(run < p.tiles_m ? run : p.tiles_m), m_nx = (double)((run + p.tiles_m - 1) / p.tiles_m + (run % p.tiles_m ? 1 : 0));
+        const double cost_n = n_mx * a_panel + n_nx * w_panel, cost_m = m_mx * a_panel + m_nx * w_panel;
+        p.mfast = mf_env >= 0 ? mf_env : (cost_m < 0.8 * cost_n ? 1 : 0);
+    }
     // split-K for launches that cannot fill the chip: each z-slice owns a K range, partial sums go through the caller's workspace
     p.splitk = pick_splitk(d, p, (long long)p.tiles_m * p.tiles_n, sizeof(T) == 2 ? 64 : 32);
     if (p.splitk > 1) p.ws = (float*)d->workspace;
