@@ -353,11 +353,11 @@ def main():
         from reface_amd import profiler
         plan = list(sampler._plans.values())[0]
         log(f"[bench] UNet launches per DDIM step: {len(plan['step'])} (GroupNorm statistics fused into GEMM epilogues: {plan['eng'].gn_fused} of 61)")
-        timed_l = profiler.time_launches(plan["step"], reps=3)
+        timed_l = profiler.time_launches(plan["step"], reps=5)
         fam = profiler.summarize(timed_l)
         step_ms = sum(ms for _, ms in timed_l)
         dec = vae._engine("dec", B, h, h)
-        dtimed = profiler.time_launches(dec.launches, reps=2)
+        dtimed = profiler.time_launches(dec.launches, reps=3)
         dfam = profiler.summarize(dtimed)
         dec_ms = sum(ms for _, ms in dtimed)
         key = {"bf16": "rf_conv_gemm[bf16]", "f32": "rf_conv_gemm[f32]", "fp8": "rf_conv_gemm[fp8w]"}[dname]

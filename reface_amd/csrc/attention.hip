@@ -419,12 +419,17 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
             const int c = st * 16 + lh * 8;
             u32x4_t v = {0u, 0u, 0u, 0u};
             if (qi < p.Nq && c < D) v = *(const u32x4_t*)(Q + (long long)qi * p.ldq + c);
-            // Q carries scale * log2(e): the scores come out of the MFMA in the exp2 domain (one bf16 rounding of q * c, once)
-            float f[8];
-            unpack16<T>(v, f);
+            // Q carries scale * log2(e): the scores come out of the MFMA in the exp2 domain.  That is one more bf16 rounding of
+            // q * c (a 2^-9-relative perturbation of the logits) unless the caller already folded the factor into q (scale = ln 2,
+            // what the UNet does through the to_q weights): then this is a multiplication by exactly 1 and is skipped.
+            if (p.scale_log2e != 1.0f) {
+                float f[8];
+                unpack16<T>(v, f);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] *= p.scale_log2e;
-            qf[qb][st] = pack16<T>(f);
+                for (int e = 0; e < 8; ++e) f[e] *= p.scale_log2e;
+                v = pack16<T>(f);
+            }
+            qf[qb][st] = v;
         }
     }
 
@@ -723,6 +728,7 @@ extern "C" int rf_attention(int dtype, const void* q, const void* k, const void*
     p.heads = heads; p.d = d; p.Nq = Nq; p.Nk = Nk; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.sq = sq; p.sk = sk; p.sv = sv; p.so = so;
     p.scale_log2e = scale * 1.4426950408889634f;
+    if (fabsf(p.scale_log2e - 1.0f) < 1e-6f) p.scale_log2e = 1.0f;       // scale = ln 2: the caller's scores are already in the exp2 domain
     if (dtype == RF_F32) return dispatch_attn<float>(p, B, (hipStream_t)stream);
     return dispatch_attn<bf16_t>(p, B, (hipStream_t)stream);
 }

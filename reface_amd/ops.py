@@ -12,6 +12,11 @@ from . import _lib
 from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_PRELU, ACT_QUICK_GELU, ACT_RELU, ACT_SIGMOID, ACT_SILU, RF_BF16, RF_F32,
                    RF_FP8_E4M3, ConvGemmDesc)
 
+# Attention scores in the exp2 domain: the UNet folds d^-0.5 * log2(e) into the to_q weights and calls rf_attention with scale = ln 2
+# (the kernels then multiply by exactly 1: no second rounding of q * scale to bf16 in the pipelined d = 40 kernel).
+LOG2E = 1.4426950408889634
+LN2 = 0.6931471805599453
+
 
 def code(dt):
     if dt == torch.float32:

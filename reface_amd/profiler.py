@@ -42,22 +42,32 @@ def attention_flops(l):
     return 4.0 * B * heads * Nq * Nk * d
 
 
-def time_launches(launches, reps=3, warmup=1):
-    """Time every launch individually (HIP events on the current torch stream, which is the stream
-    the launches run on).  Returns a list of (launch, mean_ms)."""
+def time_launches(launches, reps=5, warmup=1):
+    """Time every launch of a launch list (HIP events on the current torch stream, which is the stream the launches run on).
+
+    The list is run as a whole, in order, `warmup` + `reps` times -- every launch follows its real predecessor, so caches are in
+    the state they have inside the step -- with ONE event between consecutive launches: a launch's time is the interval between the
+    event before it and the event after it (the intervals of a pass add up to the pass), and the MEDIAN over the passes is reported
+    (a mean over three back-to-back repetitions of one launch moved by 13 % between two runs on one box when clocks dipped, and
+    ran 4-8 % ahead of the in-graph durations rocprofv3 shows because the operands of a repeated launch stay cached).
+    Returns a list of (launch, ms)."""
     stream = torch.cuda.current_stream()
     sp = stream.cuda_stream
+    for _ in range(warmup):
+        for l in launches:
+            l(sp)
+    n = len(launches)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(n + 1)] for _ in range(reps)]
+    for r in range(reps):
+        ev[r][0].record(stream)
+        for i, l in enumerate(launches):
+            l(sp)
+            ev[r][i + 1].record(stream)
+    torch.cuda.synchronize()
     out = []
-    for l in launches:
-        for _ in range(warmup):
-            l(sp)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for s, e in ev:
-            s.record(stream)
-            l(sp)
-            e.record(stream)
-        torch.cuda.synchronize()
-        out.append((l, sum(s.elapsed_time(e) for s, e in ev) / reps))
+    for i, l in enumerate(launches):
+        ts = sorted(ev[r][i].elapsed_time(ev[r][i + 1]) for r in range(reps))
+        out.append((l, ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])))
     return out
 
 

@@ -275,12 +275,15 @@ class UNetEngine:
         ln = self.pool.get((M, c), self.dt)
         self.main.append(ops.layernorm(tok, self.f32(f"{t}.norm1.weight"), self.f32(f"{t}.norm1.bias"), ln, name=f"{t}.norm1"))
         qkv = self.pool.get((M, 3 * c), self.dt)
-        wqkv = torch.cat([self.sd[f"{t}.attn1.to_q.weight"], self.sd[f"{t}.attn1.to_k.weight"], self.sd[f"{t}.attn1.to_v.weight"]], 0)
+        # to_q carries d^-0.5 * log2(e): the scores reach the attention kernels in the exp2 domain (scale = ln 2 below) -- the product
+        # is rounded to the storage type once, as a weight, instead of the kernel re-rounding q * scale
+        wqkv = torch.cat([self.sd[f"{t}.attn1.to_q.weight"].float() * (d ** -0.5 * ops.LOG2E), self.sd[f"{t}.attn1.to_k.weight"].float(),
+                          self.sd[f"{t}.attn1.to_v.weight"].float()], 0)
         self.main.append(ops.linear(ln, self.gw(wqkv), qkv, None, name=f"{t}.attn1.qkv"))
         att = ln    # reuse the LayerNorm buffer for the attention output
         q3 = qkv.view(B, H * W, 3 * c)
         self.main.append(ops.attention(q3[..., :c], q3[..., c:2 * c], q3[..., 2 * c:], att.view(B, H * W, c), heads=heads,
-                                       scale=d ** -0.5, name=f"{t}.attn1"))
+                                       scale=ops.LN2, name=f"{t}.attn1"))
         x1 = self.pool.get((nb * M, c), self.dt)
         # attn1 out-projection + residual + the (token-independent) cross-attention output; with pair=True one launch per CFG
         # half: same A and residual, that half's context vectors

@@ -257,6 +257,46 @@ def test_attention_spike_forces_rescale():
     check(out, ref, torch.float32)
 
 
+def _attn_ref(qr, kr, vr, heads, d, scale):
+    B, Nq, Nk = qr.shape[0], qr.shape[1], kr.shape[1]
+    sp = lambda t, n: t.reshape(B, n, heads, d).transpose(1, 2).double()
+    att = torch.softmax(sp(qr, Nq) @ sp(kr, Nk).transpose(-1, -2) * scale, -1)
+    return (att @ sp(vr, Nk)).transpose(1, 2).reshape(B, Nq, heads * d).float()
+
+
+@pytest.mark.parametrize("Nq,Nk,mode", [(4096, 4096, "plain"), (4000, 1088, "plain"), (3900, 1024, "hot"), (4096, 1152, "cold"), (4096, 1024, "late")])
+def test_attention_d40_pipelined_kernel(Nq, Nk, mode):
+    """attention_dma_kernel (bf16, d = 40, Nk a multiple of 64 >= 1024, grid >= 512 blocks): ragged query count, a key count that is not
+    a multiple of 128, scores far above 2^8 in the exp2 domain (the thresholded running max must move, more than once), scores that
+    are all very negative (the first unit has to LOWER the reference point from 0) and a dominant key in the last tile."""
+    B, heads, d = 4, 8, 40
+    Cc = heads * d
+    qx, kx, vx = rnd((B, Nq, Cc), 41), rnd((B, Nk, Cc), 42), rnd((B, Nk, Cc), 43)
+    scale = d ** -0.5
+    if mode == "hot":
+        # logits in the tens (exp2 domain): several moves of the thresholded running max.  q arrives PRE-SCALED (scale = ln 2), the way
+        # the UNet calls the kernel: with a plain scale the kernel rounds q * scale * log2(e) to bf16 once more, a 2^-9-relative
+        # perturbation of the logits that peaked softmaxes turn into percent-level differences (covered by "plain" at unit variance)
+        qx *= 2.5 * 2.5 * scale * ops.LOG2E
+        scale = ops.LN2
+    elif mode == "cold":
+        kx = -qx[:, :1].repeat(1, Nk, 1) * 3.0 + 0.1 * kx     # every key anti-aligned with query 0 ...
+        qx = qx[:, :1].repeat(1, Nq, 1) * 3.0 + 0.1 * qx      # ... and every query close to it: all scores << 0
+    elif mode == "late":
+        kx[:, Nk - 3] = qx[:, 7] * 4.0                       # one key of the last tile dominates query 7
+    qd, qr = q(qx, torch.bfloat16)
+    kd, kr = q(kx, torch.bfloat16)
+    vd, vr = q(vx, torch.bfloat16)
+    out = torch.empty((B, Nq, Cc), dtype=torch.bfloat16, device=DEV)
+    ops.attention(qd, kd, vd, out, heads=heads, scale=scale)()
+    torch.cuda.synchronize()
+    ref = _attn_ref(qr, kr, vr, heads, d, scale)
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    assert err.max() < 3e-2 and (err.norm() / ref.norm()) < 8e-3, f"{mode}: max {err.max():.3e} rel {err.norm() / ref.norm():.3e}"
+
+
 def test_softmax_rows():
     x = rnd((37, 4096), 30) * 3
     xd = x.to(DEV)
