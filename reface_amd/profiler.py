@@ -47,7 +47,8 @@ def time_launches(launches, reps=5, warmup=1):
 
     The list is run as a whole, in order, `warmup` + `reps` times -- every launch follows its real predecessor, so caches are in
     the state they have inside the step -- with ONE event between consecutive launches: a launch's time is the interval between the
-    event before it and the event after it (the intervals of a pass add up to the pass), and the MEDIAN over the passes is reported
+    event before it and the event after it minus the cost of an empty interval (two events with nothing between, measured in
+    the same passes), and the MEDIAN over the passes is reported
     (a mean over three back-to-back repetitions of one launch moved by 13 % between two runs on one box when clocks dipped, and
     ran 4-8 % ahead of the in-graph durations rocprofv3 shows because the operands of a repeated launch stay cached).
     Returns a list of (launch, ms)."""
@@ -57,17 +58,23 @@ def time_launches(launches, reps=5, warmup=1):
         for l in launches:
             l(sp)
     n = len(launches)
+    med = lambda ts: sorted(ts)[len(ts) // 2] if len(ts) % 2 else 0.5 * (sorted(ts)[len(ts) // 2 - 1] + sorted(ts)[len(ts) // 2])
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(n + 1)] for _ in range(reps)]
+    null = [[torch.cuda.Event(enable_timing=True) for _ in range(9)] for _ in range(reps)]
     for r in range(reps):
+        for e in null[r]:                 # empty intervals: what one event record costs on the stream (subtracted below)
+            e.record(stream)
         ev[r][0].record(stream)
         for i, l in enumerate(launches):
             l(sp)
             ev[r][i + 1].record(stream)
     torch.cuda.synchronize()
+    gap = med([null[r][j].elapsed_time(null[r][j + 1]) for r in range(reps) for j in range(8)])
     out = []
     for i, l in enumerate(launches):
-        ts = sorted(ev[r][i].elapsed_time(ev[r][i + 1]) for r in range(reps))
-        out.append((l, ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])))
+        t = med([ev[r][i].elapsed_time(ev[r][i + 1]) for r in range(reps)])
+        out.append((l, max(t - gap, 0.5 * t)))
+    time_launches.last_gap_ms = gap
     return out
 
 
