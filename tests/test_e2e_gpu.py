@@ -199,6 +199,34 @@ def test_cli_swap_selected(tmp_path):
     assert r2.returncode != 0 and "stage 1" in (r2.stderr + r2.stdout)
 
 
+def test_cli_swap_video(tmp_path):
+    """the video caller's sampling stage (inference_swap_video.py:504-700) on the tree its stage 1 leaves: one source on every
+    frame crop, whole batches only (drop_last), swapped crops at 1024^2 in model_outputs/."""
+    import json
+    import shutil
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_host_cpu import _prepared_swap_tree
+    base, out = tmp_path / "base", tmp_path / "out"
+    _prepared_swap_tree(str(base), n_tar=5, n_src=1)
+    os.rename(base / "target_cropped", base / "clipcropped_face")
+    os.rename(base / "mask_frames", base / "clipmask_frames")
+    (out / "temp_results").mkdir(parents=True)
+    shutil.copy(base / "source_cropped" / "0.png", out / "temp_results" / "me.png")
+    shutil.copy(base / "source_mask" / "0.png", out / "temp_results" / "me.jpg")          # (the reference saves the label map under the source's own file name)
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "inference_swap_video.py"), "--outdir", str(out), "--Base_dir", str(base), "--target_video",
+           "videos/clip.mp4", "--src_image", "faces/me.jpg", "--config", os.path.join(ROOT, "tests", "configs", "reface_small.yaml"), "--ckpt", "none",
+           "--n_samples", "2", "--ddim_steps", "4", "--scale", "3.5", "--precision", "bf16", "--num_workers", "0", "--clip_vision_config",
+           json.dumps(SMALL_CLIP)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert sorted(os.listdir(out / "model_outputs")) == [f"{i:012d}.png" for i in range(4)]          # 5 frames, batches of 2, drop_last
+    from PIL import Image
+    im = np.asarray(Image.open(out / "model_outputs" / "000000000003.png"))
+    assert im.shape == (1024, 1024, 3) and im.std() > 1.0
+    r2 = subprocess.run(cmd[:6] + ["--target_video", "videos/other.mp4"] + cmd[8:], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r2.returncode != 0 and "stage 1" in (r2.stderr + r2.stdout)
+
+
 def test_device_prep_matches_host(tmp_path):
     """SURVEY 8f.1 (second half): the dataset's tensors built on the GPU from uint8 arrays (reface_amd/prep.py, rf_u8_to_norm /
     rf_label_mask / rf_mul_mask / rf_bilinear_resize) are bit-identical to the host path of the same reader (target, keep-mask,

@@ -446,3 +446,21 @@ def test_swap_selected_cli_surface(tmp_path):
     assert ref <= flags, ref - flags
     d = cli.build_parser().parse_args([])
     assert (d.ddim_steps, d.n_samples, d.scale, d.precision, d.Base_dir) == (50, 12, 5, "autocast", "results_video")
+
+
+def test_swap_video_cli_surface(tmp_path):
+    """the video caller keeps the reference's flag surface and the on-disk names its stage 1 writes (inference_swap_video.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import importlib
+    cli = importlib.import_module("inference_swap_video")
+    flags = {a.option_strings[0] for a in cli.build_parser()._actions if a.option_strings}
+    ref = {"--prompt", "--outdir", "--Base_dir", "--skip_grid", "--skip_save", "--ddim_steps", "--plms", "--laion400m", "--fixed_code",
+           "--Start_from_target", "--only_target_crop", "--target_start_noise_t", "--ddim_eta", "--n_iter", "--H", "--W", "--C", "--f",
+           "--n_samples", "--n_rows", "--scale", "--target_video", "--src_image", "--src_image_mask", "--from-file", "--config", "--ckpt",
+           "--seed", "--rank", "--precision", "--faceParser_name", "--faceParsing_ckpt", "--segnext_config", "--save_vis", "--seg12"}
+    assert ref <= flags, ref - flags
+    d = cli.build_parser().parse_args([])
+    assert (d.ddim_steps, d.n_samples, d.scale, d.precision, d.fixed_code, d.target_video) == (50, 10, 5, "autocast", True, "examples/faceswap/Andy2.mp4")
+    opt = cli.build_parser().parse_args(["--Base_dir", "B", "--outdir", "O", "--target_video", "x/clip7.mp4", "--src_image", "y/face.jpg"])
+    assert cli.prepared_paths(opt) == {"frames": os.path.join("B", "clip7cropped_face"), "masks": os.path.join("B", "clip7mask_frames"),
+                                       "src": os.path.join("O", "temp_results", "face.png"), "src_mask": os.path.join("O", "temp_results", "face.jpg")}
