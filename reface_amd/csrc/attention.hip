@@ -381,16 +381,18 @@ template <int OFF> __device__ __forceinline__ u32x2_t ds_read_tr16(const char* p
 // rows of O^T beyond the head dim multiply whatever follows the row and are never stored -- except rows 48..63, whose lanes read a
 // run of ones, so the MFMA also delivers the softmax denominator.  Every wave issues two or three of a tile's ten one-KiB pieces.
 // The running max moves only when a score exceeds it by 2^8 in the exp2 domain (P <= 256; the O rescale becomes rare).
-template <int D>
+template <int D, int KT>
 __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams p) {
     typedef bf16_t T;
     static_assert(D > 32 && D < 48 && D % 8 == 0, "three 16-wide k-steps");
-    constexpr int QB = 2, KT = 64, NU = KT / 32, NSTG = 7;
+    // KT keys per stage and barrier: 64 (ring of 7) or 128 (ring of 3; half the barriers) -- both ~70 KB, two blocks per CU
+    constexpr int QB = 2, NU = KT / 32, NSTG = KT == 64 ? 7 : 3;
     constexpr int VPR = D / 8, KROW = D * 2;
     constexpr int K_BYTES = KT * KROW, STAGE = 2 * K_BYTES;
     constexpr int ONES_OFF = NSTG * STAGE, ONES_BYTES = (KT - 8) * KROW + 128;     // a run of bf16 ones (see the V^T fragments below)
     constexpr int PIECES = K_BYTES / 1024;              // one-KiB DMA pieces per operand tile
-    static_assert(K_BYTES % 1024 == 0 && NU == 2, "whole DMA pieces; two units per tile");
+    static_assert(K_BYTES % 1024 == 0 && (NU == 2 || NU == 4), "whole DMA pieces; two or four units per tile");
+    constexpr int NP = 2 * PIECES, SLOTS = (NP + 3) / 4;          // pieces of a tile (K then V, contiguous in the stage), per wave
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -437,26 +439,26 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
     // ---- staging: tile X is issued by wave X % 4
     const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, (unsigned)((((long long)p.Nk - 1) * p.ldk + D) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, (unsigned)((((long long)p.Nk - 1) * p.ldv + D) * 2), 0x00020000);
-    // Every wave issues its share of every tile: K piece `wave` and V piece `wave` (pieces 0..3), waves 0 / 1 also K / V piece 4.
-    // The per-lane source offsets do not depend on the tile.
-    int offA, offB, offC;
-    {
-        const int g = wave * 64 + lane, row = g / VPR, ch = g - row * VPR;
-        offA = row * p.ldk * 2 + ch * 16;
-        offB = row * p.ldv * 2 + ch * 16;
-        const int g4 = 4 * 64 + lane, row4 = g4 / VPR, ch4 = g4 - row4 * VPR;
-        offC = row4 * (wave == 0 ? p.ldk : p.ldv) * 2 + ch4 * 16;
+    // Every wave issues its share of every tile: pieces wave, wave + 4, ... of the NP one-KiB pieces (K pieces first, V pieces
+    // behind them, in stage order).  The per-lane source offsets do not depend on the tile.
+    int off[SLOTS];
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+        const int pc = wave + 4 * i, g = (pc % PIECES) * 64 + lane, row = g / VPR, ch = g - row * VPR;
+        off[i] = row * (pc < PIECES ? p.ldk : p.ldv) * 2 + ch * 16;
     }
     auto dma_tile = [&](int tile, int stage) {
         const int sk = tile * (KT * p.ldk * 2), sv = tile * (KT * p.ldv * 2);
-        char* const dk = smem + stage * STAGE + wave * 1024;
-        char* const dv = dk + K_BYTES;
-        char* const dk4 = smem + stage * STAGE + 4 * 1024;
-        char* const dv4 = dk4 + K_BYTES;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)dk, 16, offA, sk, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void*)dv, 16, offB, sv, 0, 0);
-        if (wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)dk4, 16, offC, sk, 0, 0);
-        if (wave == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void*)dv4, 16, offC, sv, 0, 0);
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int pc = wave + 4 * i;                  // wave-uniform
+            if (pc < NP) {
+                char* const dst = smem + stage * STAGE + pc * 1024;
+                const int vo = off[i];
+                if (pc < PIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)dst, 16, vo, sk, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void*)dst, 16, vo, sv, 0, 0);
+            }
+        }
     };
 
     // ---- per-lane LDS offsets of the fragments (unit 0 of a stage)
@@ -562,11 +564,11 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
             }
             moved |= (t == 0 && uu == 0);
             if (uu == 0) {
-                // tile t+1 (read from this iteration's second half on) must have landed: this wave has tiles t+2 .. t+5 behind it, two or
-                // three pieces each -- "at most 8 outstanding" covers both (for the 3-piece waves it also waits for tile t+2)
-                if (t + 5 < ntiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                // tile t+1 (read from this iteration's last unit on) must have landed: behind it this wave has tiles t+2 .. t+NSTG-2 in
+                // flight, NP / 4 or NP / 4 + 1 pieces each -- "at most (NSTG - 3) * (NP / 4) outstanding" covers both
+                if (t + NSTG - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 3) * (NP / 4)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();                         // every wave is past the last read of tile t-1: its stage takes tile t+6
+                __syncthreads();                         // every wave is past the last read of tile t-1: its stage takes tile t+NSTG-1
                 if (t + NSTG - 1 < ntiles) dma_tile(t + NSTG - 1, sp);
             }
             if (__builtin_expect(__any(moved), 0)) {      // out of line: the common path falls through
@@ -607,6 +609,10 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
         };
         unit(std::integral_constant<int, 0>{});
         unit(std::integral_constant<int, 1>{});
+        if constexpr (NU == 4) {
+            unit(std::integral_constant<int, 2>{});
+            unit(std::integral_constant<int, 3>{});
+        }
         sc = sn;
     }
     RF_WAIT_VF()
@@ -640,10 +646,10 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
     }
 }
 
-template <int D>
+template <int D, int KT>
 static int launch_attn_dma(const AttnParams& p, int B, hipStream_t st) {
-    constexpr int smem = 7 * (2 * 64 * D * 2) + (64 - 8) * D * 2 + 128;      // stages + the run of ones
-    auto k = attention_dma_kernel<D>;
+    constexpr int smem = (KT == 64 ? 7 : 3) * (2 * KT * D * 2) + (KT - 8) * D * 2 + 128;      // stages + the run of ones
+    auto k = attention_dma_kernel<D, KT>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
     AttnParams pp = p;
@@ -683,7 +689,9 @@ static int launch_attn(const AttnParams& p, int B, hipStream_t st) {
             // long sequences of whole 64-key tiles: the in-wave software-pipelined kernel (RF_ATTN_PIPE=0: the generic one)
             static const int pipe = [] { const char* e = getenv("RF_ATTN_PIPE"); return e ? atoi(e) : 1; }();
             if constexpr (D == 40) {
-                if (pipe && p.Nk % 64 == 0 && p.Nk >= 1024) return launch_attn_dma<D>(p, B, st);
+                static const int kt128 = [] { const char* e = getenv("RF_ATTN_KT128"); return e ? atoi(e) : 1; }();
+                if (pipe && kt128 && p.Nk % 128 == 0 && p.Nk >= 1024) return launch_attn_dma<D, 128>(p, B, st);
+                if (pipe && p.Nk % 64 == 0 && p.Nk >= 1024) return launch_attn_dma<D, 64>(p, B, st);
             }
             // 8-wave blocks (both waves of a SIMD on one staged tile) measured 608 vs 586 us at N = 4096: opt-in only (RF_ATTN_NW=8)
             static const int nw = [] { const char* e = getenv("RF_ATTN_NW"); return e ? atoi(e) : 4; }();

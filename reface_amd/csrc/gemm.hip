@@ -1424,7 +1424,13 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
         const bool n320 = d->act != RF_ACT_GEGLU && N % 320 == 0, n256 = N % 256 == 0 && !n320;
         const long long nt = n320 ? N / 320 : (n256 ? N / 256 : 0);
         if (nt > 0) {
-            if (mt256 * nt >= 192) return n320 ? launch_cfg<T, TO, 4, 2, 2, 5, W8>(d, p, conv, st) : launch_cfg<T, TO, 4, 2, 2, 4, W8>(d, p, conv, st);
+            if (mt256 * nt >= 192) {
+                // wave quantisation: 288 tiles of 256 rows (M = 73728, the 96x96 level at B = 4) are two rounds with the second one
+                // 12 % full; quarter-size tiles at two blocks per CU fill the tail (768^2 bench: GEMM family 17.32 -> 16.77 ms per step)
+                const double rounds = (double)(mt256 * nt) / 256.0;
+                if (n320 && rounds / (double)((mt256 * nt + 255) / 256) < 0.6) return launch_cfg<T, TO, 4, 1, 1, 5, W8>(d, p, conv, st);
+                return n320 ? launch_cfg<T, TO, 4, 2, 2, 5, W8>(d, p, conv, st) : launch_cfg<T, TO, 4, 2, 2, 4, W8>(d, p, conv, st);
+            }
             // K up to ~90 tiles: two co-resident 4-wave 128x160 blocks per CU (each other's prologue / epilogue cover) beat one
             // 8-wave 128x320 block in situ (sweep: -1.2 % per batch at 6000, worse again from 11520); RF_SHORTK overrides.  Also when K is
             // too short for split-K to bring the 128x320 grid to size (4096 x 1280 x 1280: 23 us, against 26 us on 128x128 tiles).
