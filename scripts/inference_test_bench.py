@@ -222,31 +222,65 @@ def main(argv=None):
                 t_host = target.cpu()
                 yield t_host, t_host, kw, ids
 
+    def stage_out(slot, tensors):
+        """Enqueue the device -> host copies of one batch into the slot's pinned buffers (allocated on first use), then the slot's event."""
+        bufs, ev = slot
+        out = {}
+        for name, t in tensors.items():
+            if not t.is_cuda:
+                out[name] = t
+                continue
+            if name not in bufs or bufs[name].shape[0] < t.shape[0] or bufs[name].shape[1:] != t.shape[1:]:
+                bufs[name] = torch.empty(t.shape, dtype=torch.float32).pin_memory()
+            bufs[name][:t.shape[0]].copy_(t, non_blocking=True)
+            out[name] = bufs[name][:t.shape[0]]
+        ev.record()
+        return out
+
+    def flush(pending):
+        """The batch whose copies were enqueued one iteration ago: wait for them, hand the arrays to the PNG writer thread."""
+        ids, slot, out = pending
+        slot[1].synchronize()
+        writer.submit(ids, out["x"].numpy().copy(), out["target"].float().numpy(), out["inpaint"].float().numpy().copy(),
+                      out["mask"].float().numpy().copy(), out["ref"].numpy().copy())
+
+    pending = None
+    timing = os.environ.get("RF_CLI_TIMING") == "1"      # per-batch host phases on stderr: loader / enqueue / flush (ms)
+    t_mark = time.perf_counter()
     with torch.no_grad(), model.ema_scope():
         for (test_batch, prior, test_model_kwargs, segment_id_batch), lm136 in with_landmark_prefetch(unpack(loader)):
+            t_load = time.perf_counter()
             if opt.Start_from_target:                   # inference_test_bench.py:414-435: noised target (or prior) latent as x_T
                 start_code = runner.start_from_target(prior)      # `use_prior = True` is hard-wired in the reference (:402, :424-429)
-            test_model_kwargs = {n: test_model_kwargs[n].to(device, non_blocking=True) for n in test_model_kwargs}
+            kw_in = test_model_kwargs                   # as the loader (host) or the device prep (GPU) made them
+            test_model_kwargs = {n: kw_in[n].to(device, non_blocking=True) for n in kw_in}
             B = test_batch.shape[0]
-            inpaint_image, inpaint_mask = test_model_kwargs["inpaint_image"], test_model_kwargs["inpaint_mask"]
             ref = test_model_kwargs["ref_imgs"].squeeze(1)
             x_img, _ = runner.run_batch(test_batch, test_model_kwargs, ref, start_code=start_code, landmarks136=lm136)
-            slot = host[n_batches % 2]                  # double-buffered pinned host staging: D2H of batch i overlaps batch i+1
-            if slot is None or slot[0].shape[0] < B:
-                slot = host[n_batches % 2] = (torch.empty(x_img.shape, dtype=torch.float32).pin_memory(), torch.cuda.Event())
-            else:
-                slot[1].synchronize()                   # the copy that last used this slot has landed (two batches ago)
-            slot[0][:B].copy_(x_img, non_blocking=True)
+            # Two host staging slots: the copies of batch i are enqueued right behind its kernels, the host then enqueues batch i+1
+            # and only afterwards waits for batch i's copies and hands them to the writer thread -- the GPU goes from one batch
+            # straight into the next while the host converts / saves the previous one (tools/cli_idle.sh).
+            slot = host[n_batches % 2]
+            if slot is None:
+                slot = host[n_batches % 2] = ({}, torch.cuda.Event())
             n_done += B
             n_batches += 1
             if not opt.skip_save:
-                ref_np = runner.resized_reference(ref, opt.H, opt.W).cpu().numpy()
-                slot[1].record()
-                slot[1].synchronize()
-                writer.submit(list(segment_id_batch), slot[0][:B].numpy().copy(), test_batch.float().numpy(), inpaint_image.cpu().numpy(),
-                              inpaint_mask.float().cpu().numpy(), ref_np)
+                out = stage_out(slot, {"x": x_img, "ref": runner.resized_reference(ref, opt.H, opt.W), "target": test_batch,
+                                       "inpaint": kw_in["inpaint_image"], "mask": kw_in["inpaint_mask"]})
+                t_enq = time.perf_counter()
+                if pending is not None:
+                    flush(pending)
+                pending = (list(segment_id_batch), slot, out)
+                if timing:
+                    t_now = time.perf_counter()
+                    print(f"[cli] batch {n_batches}: loader {1e3 * (t_load - t_mark):.0f} ms, enqueue {1e3 * (t_enq - t_load):.0f} ms, "
+                          f"flush of the previous batch {1e3 * (t_now - t_enq):.0f} ms", file=sys.stderr, flush=True)
+                    t_mark = t_now
             else:
                 slot[1].record()
+        if pending is not None:
+            flush(pending)
     if writer is not None:
         writer.close()
     torch.cuda.synchronize()
