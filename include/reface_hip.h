@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-enum { RF_F32 = 0, RF_BF16 = 1, RF_FP8_E4M3 = 2 /* OCP e4m3fn weights (rf_conv_gemm_desc.w_dtype only) */ };
+enum { RF_F32 = 0, RF_BF16 = 1, RF_FP8_E4M3 = 2 /* OCP e4m3fn weights (rf_conv_gemm_desc.w_dtype only) */,
+       RF_BF16X3 = 3 /* split-bf16 operand pairs, see rf_conv_gemm_desc.dtype and rf_split_bf16 */ };
 
 /* epilogue activations of rf_conv_gemm */
 enum { RF_ACT_NONE = 0, RF_ACT_GEGLU = 1, RF_ACT_SILU = 2, RF_ACT_QUICK_GELU = 3, RF_ACT_GELU = 4,
@@ -52,7 +53,11 @@ int rf_version(void);
  * (model.py:60-79,97-121,155-174) and bmm in the VAE AttnBlock (model.py:186-198).
  */
 typedef struct rf_conv_gemm_desc {
-    int32_t dtype;        /* RF_F32 | RF_BF16: element type of src0/src1/W */
+    /* dtype RF_BF16X3: every fp32 operand value x is stored as the bf16 pair hi = bf16(x), lo = bf16(x - hi) -- a src0 pixel is */
+    /* [C0 hi | C0 lo] (ld0 >= 2 C0), a W row holds per 64-element K tile [64 hi | 64 lo | 64 hi] (3 K bf16; ldw >= 3 K) -- and a product is */
+    /* accumulated in fp32 as hi hi + hi lo + lo hi on the bf16 MFMA (relative error 2^-16 per product; out_dtype RF_F32, one source, */
+    /* K and C0 multiples of 64, K / C0 / ld0 given in REAL elements): the fast form of the fp32 VAE convolutions (model.py:60-121). */
+    int32_t dtype;        /* RF_F32 | RF_BF16: element type of src0/src1/W; RF_BF16X3: split-bf16 pairs (above) */
     int32_t out_dtype;    /* element type of out and residual */
     int32_t M, N, K;      /* GEMM view; K = KH*KW*(C0+C1) (may be padded up to a multiple of 8) */
     const void* src0;
@@ -167,6 +172,10 @@ int rf_ddim_update(const float* eps, int ld_eps, int cfg, float scale, float* im
 int rf_nchw_to_nhwc(const float* x, int B, int C, int HW, int out_dtype, void* out, int Cpad, void* stream);
 int rf_nhwc_to_nchw(int dtype, const void* x, int B, int C, int HW, int ldx, float* out, void* stream);
 int rf_cast(int in_dtype, const void* x, int out_dtype, void* out, int64_t n, void* stream);
+/* fp32 [M, C] (row pitch ldx) -> split-bf16 pairs [M][C hi | C lo] (row pitch ldo >= 2C, bf16): hi = bf16(x), lo = bf16(x - hi), the
+ * RF_BF16X3 operand form of rf_conv_gemm.  rf_groupnorm_apply writes the same form directly with out_dtype = RF_BF16X3; this pass is for
+ * tensors that reach a convolution without a normalisation in between (VAE Upsample conv / nin_shortcut, model.py:53-57,117-121). */
+int rf_split_bf16(const float* x, int64_t M, int C, int ldx, void* out, int ldo, void* stream);
 /* sinusoidal timestep embedding [n, dim] = [cos(t f) | sin(t f)] (util.py:151-166); freqs [dim/2] fp32 */
 int rf_timestep_embedding(const float* t, int n, int dim, const float* freqs, float* out, void* stream);
 /* KL-VAE posterior sample (distributions.py:24-37, ddpm.py:857): moments NCHW [B, 2C, HW] = (mean | logvar),

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # REFACE_HIP_LIB selects another build of the same library (A/B kernel experiments); there is still no non-HIP fallback.
 LIB_PATH = os.environ.get("REFACE_HIP_LIB") or os.path.join(HERE, "lib", "libreface_hip.so")
 
-RF_F32, RF_BF16, RF_FP8_E4M3 = 0, 1, 2
+RF_F32, RF_BF16, RF_FP8_E4M3, RF_BF16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_PRELU = 0, 1, 2, 3, 4, 5, 6, 7
 
 
@@ -62,6 +62,7 @@ _SIGS = {
     "rf_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "rf_nhwc_to_nchw": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "rf_cast": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "rf_split_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "rf_timestep_embedding": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rf_silu_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rf_to_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

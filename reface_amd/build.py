@@ -59,5 +59,9 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
+    if "--print-flags" in sys.argv:          # tools/build_variant.sh: the ONE source of the per-unit compile flags
+        unit = sys.argv[sys.argv.index("--print-flags") + 1]
+        print(" ".join(FLAGS + EXTRA_FLAGS.get(unit + ".hip", [])))
+        sys.exit(0)
     build(force="--force" in sys.argv)
     print(LIB)

@@ -654,7 +654,7 @@ static int launch_attn_dma(const AttnParams& p, int B, hipStream_t st) {
     if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
     AttnParams pp = p;
     pp.nqb = (p.Nq + 255) / 256;
-    static const int pad = [] { const char* e = getenv("RF_ATTN_SMEM_PAD"); return e ? atoi(e) : 0; }();      // experiment: one block per CU
+    static const int pad = tune_env("RF_ATTN_SMEM_PAD", 0);      // experiment: one block per CU
     if (pad) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem + pad);
     hipLaunchKernelGGL(k, dim3(pp.nqb * B * p.heads), dim3(256), smem + pad, st, pp);
     RF_LAUNCH_CHECK("rf_attention");
@@ -684,17 +684,17 @@ static int launch_attn(const AttnParams& p, int B, hipStream_t st) {
     // QB = 2 (two query blocks per wave, every K / V^T fragment feeds two MFMAs) pays for the small head dim when the
     // grid still fills the chip: d=40, N=4096: 687 us vs 739 us; it loses at d=80 (N=1024: 99 us vs 85 us).
     if constexpr (sizeof(T) == 2 && D <= 40) {
-        static const int kt = [] { const char* e = getenv("RF_ATTN_KT"); return e ? atoi(e) : 128; }();
+        static const int kt = tune_env("RF_ATTN_KT", 128);
         if ((long long)((p.Nq + 255) / 256) * B * p.heads >= 512) {
             // long sequences of whole 64-key tiles: the in-wave software-pipelined kernel (RF_ATTN_PIPE=0: the generic one)
-            static const int pipe = [] { const char* e = getenv("RF_ATTN_PIPE"); return e ? atoi(e) : 1; }();
+            static const int pipe = tune_env("RF_ATTN_PIPE", 1);
             if constexpr (D == 40) {
-                static const int kt128 = [] { const char* e = getenv("RF_ATTN_KT128"); return e ? atoi(e) : 1; }();
+                static const int kt128 = tune_env("RF_ATTN_KT128", 1);
                 if (pipe && kt128 && p.Nk % 128 == 0 && p.Nk >= 1024) return launch_attn_dma<D, 128>(p, B, st);
                 if (pipe && p.Nk % 64 == 0 && p.Nk >= 1024) return launch_attn_dma<D, 64>(p, B, st);
             }
             // 8-wave blocks (both waves of a SIMD on one staged tile) measured 608 vs 586 us at N = 4096: opt-in only (RF_ATTN_NW=8)
-            static const int nw = [] { const char* e = getenv("RF_ATTN_NW"); return e ? atoi(e) : 4; }();
+            static const int nw = tune_env("RF_ATTN_NW", 4);
             if (kt == 128 && p.Nk >= 1024 && nw == 8 && (long long)((p.Nq + 511) / 512) * B * p.heads >= 512)
                 return launch_attn_qb<T, D, 2, 128, 8>(p, B, st);
             if (kt == 128 && p.Nk >= 1024) return launch_attn_qb<T, D, 2, 128>(p, B, st);

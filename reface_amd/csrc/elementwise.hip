@@ -80,6 +80,22 @@ __global__ void cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, long l
     if (i < n) st<TO>(y + i, elem<TI>::load(x + i));
 }
 
+// fp32 [M, C] (row pitch ldx) -> split-bf16 pairs [M][C hi | C lo] (row pitch ldo): the RF_BF16X3 operand form of a tensor that no
+// normalisation pass rewrites on its way into a convolution (residual stream -> Upsample conv / nin_shortcut, model.py:53-57,117-121)
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, long long M, int C, int ldx, bf16_t* __restrict__ out, int ldo) {
+    const int vpr = C >> 2;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * vpr) return;
+    const long long r = i / vpr;
+    const int c = (int)(i - r * vpr) * 4;
+    const f32x4_t v = *(const f32x4_t*)(x + r * ldx + c);
+    const float f[4] = {v[0], v[1], v[2], v[3]};
+    u32x2_t h, l;
+    split4_bf16(f, h, l);
+    *(u32x2_t*)(out + r * ldo + c) = h;
+    *(u32x2_t*)(out + r * ldo + C + c) = l;
+}
+
 // util.py:151-166; `freqs` [dim/2] = exp(-ln(max_period) * k / half) is a host-built fp32 table
 __global__ void timestep_embedding_kernel(const float* __restrict__ t, int n, int dim, const float* __restrict__ freqs, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,6 +218,15 @@ extern "C" int rf_cast(int in_dtype, const void* x, int out_dtype, void* out, in
     else if (in_dtype == RF_BF16 && out_dtype == RF_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), grid1d(n), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, (long long)n);
     else RF_CHECK(false, "rf_cast: bad dtypes %d -> %d", in_dtype, out_dtype);
     RF_LAUNCH_CHECK("rf_cast");
+    return 0;
+}
+
+extern "C" int rf_split_bf16(const float* x, int64_t M, int C, int ldx, void* out, int ldo, void* stream) {
+    RF_CHECK(x && out && M > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldo >= 2 * C, "rf_split_bf16: bad arguments M=%lld C=%d ldx=%d ldo=%d",
+             (long long)M, C, ldx, ldo);
+    RF_CHECK((((uintptr_t)x | (uintptr_t)out) & 15) == 0, "rf_split_bf16: operands must be 16-byte aligned");
+    hipLaunchKernelGGL(split_bf16_kernel, grid1d((long long)M * (C / 4)), dim3(256), 0, (hipStream_t)stream, x, (long long)M, C, ldx, (bf16_t*)out, ldo);
+    RF_LAUNCH_CHECK("rf_split_bf16");
     return 0;
 }
 

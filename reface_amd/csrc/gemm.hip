@@ -54,6 +54,9 @@ struct GemmParams {
     int epi2_ok;     // host only: operand alignment / feature set allow the direct (register -> global) epilogue
     int dbg;         // RF_GEMM_DBG (timing experiments only): bit 0 = skip the epilogue, bit 1 = skip the main loop
     const float* wscale;   // W8 kernels: per-output-channel power-of-two scale of the fp8 (e4m3fn) weights
+    int x3;          // split-bf16 operands (RF_BF16X3): K counts VIRTUAL tiles, three per real 64-element K tile -- (A hi, W hi), (A hi, W lo),
+                     // (A lo, W hi); W rows hold them in that order, the A lo plane lies lo_off bytes behind the hi plane of the same pixel
+    int lo_off;
 };
 
 // 8 fp8 (e4m3fn) weights -> 8 bf16, times the row's power-of-two scale: v_cvt_scalef32_pk_bf16_fp8, one instruction per pair (exact:
@@ -261,10 +264,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    int nk = (p.dbg & 2) ? 0 : (p.K + BK - 1) / BK;
+    int nk = (RF_DBG(p, 2)) ? 0 : (p.K + BK - 1) / BK;
     int kb0_tiles = 0;       // first K tile of this block (split-K)
     if (p.splitk > 1) {          // this block's K-tile range [kb0, kb0 + nk)
-        const int per = (nk + p.splitk - 1) / p.splitk;
+        int per = (nk + p.splitk - 1) / p.splitk;
+        if (p.x3) per = (per + 2) / 3 * 3;
         const int kb0 = blockIdx.z * per;
         nk = max(0, min(nk, kb0 + per) - kb0);
         kb0_tiles = kb0;
@@ -350,17 +354,27 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         const int tpt = CONV ? p.Ctot / BK : 1;     // K tiles per tap
         // korder 1 (channel-chunk-major K): the KH*KW taps of one BK-channel chunk are consecutive tiles, so the ~BM x 128 B of A
         // that a block touches per chunk stay L2-resident across the taps (tap-major K sweeps all channels between reuses)
-        int it = kb0_tiles, ity = 0, itx = 0, ic = 0;
+        // X3OK: the split-bf16 mode (bf16 operand pairs, fp32 output) -- `it` counts virtual tiles (the W side), `ia` the real A tile,
+        // `ph` the pass (0: hi x hi, 1: hi x lo, 2: lo x hi) of the tile being issued
+        constexpr bool X3OK = sizeof(T) == 2 && sizeof(TO) == 4 && !W8 && NST == 2;
+        const bool x3 = X3OK && p.x3;
+        int it = kb0_tiles, ity = 0, itx = 0, ic = 0, ph = 0;
+        int ia = x3 ? kb0_tiles / 3 : kb0_tiles;          // (split-K ranges of the split mode start on a multiple of 3)
         if (CONV) {
             const int ntap = p.KH * p.KW;
-            const int tap = p.korder ? it % ntap : it / tpt;
-            ic = p.korder ? it / ntap : it - tap * tpt;
+            const int tap = p.korder ? ia % ntap : ia / tpt;
+            ic = p.korder ? ia / ntap : ia - tap * tpt;
             ity = tap / p.KW;
             itx = tap - ity * p.KW;
             set_tap(ity, itx);
         }
         auto next_tile = [&]() {     // advance the issue state by one K tile
             ++it;
+            if (X3OK && x3) {
+                if (++ph != 3) return;
+                ph = 0;
+            }
+            ++ia;
             if (CONV) {
                 if (p.korder) {
                     if (++itx == p.KW) { itx = 0; if (++ity == p.KH) { ity = 0; ++ic; } }
@@ -376,7 +390,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         auto issue_pieces = [&](int buf, int q0, int q1) {
             char* a = ldsA + buf * BM * 128 + wave_u * 1024;
             char* b = ldsB + w_stage<W8>(it, buf) * BN * 128 + wave_u * 1024;
-            const int soA = (CONV ? ic : it) * 128, soB = w_soff<W8>(it);
+            const int soA = (CONV ? ic : ia) * 128 + ((X3OK && ph == 2) ? p.lo_off : 0), soB = w_soff<W8>(it);
             if (W8 && (it & 1) && q1 > AV) q1 = AV;          // odd tile: its W half arrived with the even tile before it
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
@@ -562,7 +576,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         }
     }
 
-    if (p.dbg & 1) {          // timing experiment: no epilogue (keep the accumulators observable)
+    if (RF_DBG(p, 1)) {          // timing experiment: no epilogue (keep the accumulators observable)
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -680,11 +694,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { gsum[e] += a[e]; gsq[e] += a[e] * a[e]; }
                 }
-                if (p.dbg & 4) {          // experiment: two 8-byte stores instead of one 16-byte store
+                if (RF_DBG(p, 4)) {          // experiment: two 8-byte stores instead of one 16-byte store
                     u32x2_t* d2 = (u32x2_t*)(outp + (long long)row * p.ldo + col);
                     d2[0] = u32x2_t{w[0], w[1]};
                     d2[1] = u32x2_t{w[2], w[3]};
-                } else if (!(p.dbg & 8)) {
+                } else if (!(RF_DBG(p, 8))) {
                     *(u32x4_t*)(outp + (long long)row * p.ldo + col) = w;
                 }
             }
@@ -727,8 +741,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         constexpr int OV = sizeof(TO) == 2 ? 2 : 4;      // 16-byte vectors per 16 output values (split-K launches never come here: direct
                                                          // fp32 partial rows measured slower than the staged ones, 61.7 vs 56.3 us)
         auto store16 = [&](TO* dst, const float* v) {
-            if (p.dbg & 8) return;                                                          // experiment: no global stores
-            if (p.dbg & 16) dst = (TO*)p.out + (((dst - (TO*)p.out) * (long long)sizeof(TO)) & 0xFFFFF) / (long long)sizeof(TO);   // experiment: all stores into 1 MB
+            if (RF_DBG(p, 8)) return;                                                          // experiment: no global stores
+            if (RF_DBG(p, 16)) dst = (TO*)p.out + (((dst - (TO*)p.out) * (long long)sizeof(TO)) & 0xFFFFF) / (long long)sizeof(TO);   // experiment: all stores into 1 MB
             if constexpr (sizeof(TO) == 2) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -836,7 +850,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
                             for (int e = 0; e < E; ++e) v[e] = acc[i][j][h * E + e] * p.alpha + cb[(h * E + e) >> 2][(h * E + e) & 3] + (resp ? f[e] : 0.0f);
                             const u32x4_t w = pack16<TO>(v);
-                            if (!(p.dbg & 8)) ((u32x4_t*)dst)[h] = w;
+                            if (!(RF_DBG(p, 8))) ((u32x4_t*)dst)[h] = w;
                             if (gn_on) {
                                 float y[E];
                                 unpack16<TO>(w, y);              // the values as stored replace the (dead) accumulators: no extra registers
@@ -1307,7 +1321,7 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
         // Tile order inside each XCD's contiguous run of tiles (8 XCDs, one L2 each): the run touches m_x A panels and n_x W panels.
         // N-fastest keeps an A panel in one L2 (large images); M-fastest keeps a W panel there -- at the 8x8 / 16x16 levels W is the big
         // operand and N-fastest makes every XCD stream ALL of it (1024 x 1280 x 11520: 239 MB instead of 69 MB through the fabric).
-        static const int mf_env = [] { const char* e = getenv("RF_GEMM_MFAST"); return e ? atoi(e) : -1; }();
+        static const int mf_env = tune_env("RF_GEMM_MFAST", -1);
         const long long tiles = (long long)p.tiles_m * p.tiles_n, run = (tiles + 7) / 8;
         const double a_panel = (double)BM * (conv ? p.Ctot : p.K) * sizeof(T), w_panel = (double)BN * p.K * (W8 ? 1 : (int)sizeof(T));
         const double n_mx = (double)((run + p.tiles_n - 1) / p.tiles_n + (run % p.tiles_n ? 1 : 0)), n_nx = (double)(run < p.tiles_n ? run : p.tiles_n);
@@ -1321,6 +1335,7 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     // statistics tiling: the GEMM tile, or the reduce pass's tile when split-K moves the epilogue there
     const int skr = sk_rows_for(p.M, p.N);
     const int st_rows = p.splitk > 1 ? skr : BM, st_cols = p.splitk > 1 ? SK_COLS : BN;
+    if (W8) RF_CHECK(p.glds, "rf_conv_gemm: fp8 weights need the direct-to-LDS main loop (one source, K and channel count multiples of 64)");
     if (p.plan) { p.plan[0] = st_rows; p.plan[1] = st_cols; p.plan[2] = p.splitk; return 0; }
     if (p.gn_rows > 0) {
         RF_CHECK(p.gn_rows % st_rows == 0 && p.M % p.gn_rows == 0 && d->batch == 1 && d->act != RF_ACT_GEGLU,
@@ -1339,12 +1354,12 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     //   EPI 0, fp32 tile staged in row chunks: everything else (split-K partials, per-row timestep vectors, activations other than
     //          GEGLU, fp32 output with statistics, unaligned shapes).
     // RF_EPI=0 forces EPI 0, RF_EPI=1 / 2 allow only that fast form (A/B runs).
-    static const int epi_env = [] { const char* e = getenv("RF_EPI"); return e ? atoi(e) : -1; }();
+    static const int epi_env = tune_env("RF_EPI", -1);
     constexpr bool PACKED_OK = sizeof(TO) == 2;
     constexpr bool DIRECT_OK = (WM * WN == 8) || (TM * TN == 5);
     const bool ep_common = p.glds && p.epi2_ok && p.splitk == 1 && (!p.rowvec || p.rows_per_sample % BM == 0) &&
                            (d->act == RF_ACT_NONE || (d->act == RF_ACT_GEGLU && TN % 2 == 0));
-    static const int gn_direct = [] { const char* e = getenv("RF_EPI_GN"); return e ? atoi(e) : 1; }();      // 0: fused statistics keep EPI 0
+    static const int gn_direct = tune_env("RF_EPI_GN", 1);      // 0: fused statistics keep EPI 0
     const bool direct = DIRECT_OK && (epi_env < 0 || epi_env == 1) && ep_common && (p.gn_rows == 0 || (gn_direct && d->act == RF_ACT_NONE));
     // (packed: measured neutral-to-negative in situ -- proj_out 4096x1280x1280 with fused statistics 37 -> 63 us, the rest within
     //  noise, r02f -- so it is opt-in: RF_EPI=2)
@@ -1367,10 +1382,9 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
         }                                                                                                                        \
     }
     const int esel = packed ? 2 : (direct ? 1 : 0);
-    static const int deep_env = [] { const char* e = getenv("RF_GEMM_DEEP"); return e ? atoi(e) : 0; }();        // largest grid (blocks) that takes the ring; off by default: 4096x1280x5120 68.3 -> 66.7 us alone, GEMM family 12.63 -> 12.69 ms in situ
+    static const int deep_env = tune_env("RF_GEMM_DEEP", 0);        // largest grid (blocks) that takes the ring; off by default: 4096x1280x5120 68.3 -> 66.7 us alone, GEMM family 12.63 -> 12.69 ms in situ
     constexpr int smem_deep = NSTD * (BM + BN) * 128 > smem ? NSTD * (BM + BN) * 128 : smem;
-    const bool deep = DEEP_OK && p.glds && !packed && (long long)grid.x * grid.y * grid.z <= deep_env;
-    if (W8) RF_CHECK(p.glds, "rf_conv_gemm: fp8 weights need the direct-to-LDS main loop (one source, K and channel count multiples of 64)");
+    const bool deep = DEEP_OK && p.glds && !packed && !p.x3 && (long long)grid.x * grid.y * grid.z <= deep_env;
     if (conv && p.glds) {
         if (esel == 2) RF_LAUNCH_VARIANT(true, true, 2)
         else if (esel == 1) RF_LAUNCH_VARIANT(true, true, 1)
@@ -1398,11 +1412,11 @@ template <typename T, typename TO, bool W8 = false>
 static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipStream_t st) {
     const int N = p.N;
     {   // experiments: RF_GEMM_CFG=<0..6> forces one tile configuration (GEGLU still needs an even TN)
-        static const int forced_all = [] { const char* e = getenv("RF_GEMM_CFG"); return e ? atoi(e) : -1; }();
-        static const int small_k = [] { const char* e = getenv("RF_SMALLK_K"); return e ? atoi(e) : 0; }();          // K <= this ...
-        static const int small_cfg = [] { const char* e = getenv("RF_SMALLK_CFG"); return e ? atoi(e) : -1; }();     // ... uses this config
-        static const int m_exact = [] { const char* e = getenv("RF_MCFG_M"); return e ? atoi(e) : 0; }();               // M == this ...
-        static const int m_cfg = [] { const char* e = getenv("RF_MCFG_CFG"); return e ? atoi(e) : -1; }();              // ... uses this config
+        static const int forced_all = tune_env("RF_GEMM_CFG", -1);
+        static const int small_k = tune_env("RF_SMALLK_K", 0);          // K <= this ...
+        static const int small_cfg = tune_env("RF_SMALLK_CFG", -1);     // ... uses this config
+        static const int m_exact = tune_env("RF_MCFG_M", 0);               // M == this ...
+        static const int m_cfg = tune_env("RF_MCFG_CFG", -1);              // ... uses this config
         const int forced = forced_all >= 0 ? forced_all : (p.M == m_exact ? m_cfg : (p.K <= small_k ? small_cfg : -1));
         const bool g = d->act == RF_ACT_GEGLU;
         switch (forced) {
@@ -1434,7 +1448,7 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
             // K up to ~90 tiles: two co-resident 4-wave 128x160 blocks per CU (each other's prologue / epilogue cover) beat one
             // 8-wave 128x320 block in situ (sweep: -1.2 % per batch at 6000, worse again from 11520); RF_SHORTK overrides.  Also when K is
             // too short for split-K to bring the 128x320 grid to size (4096 x 1280 x 1280: 23 us, against 26 us on 128x128 tiles).
-            static const int shortk = [] { const char* e = getenv("RF_SHORTK"); return e ? atoi(e) : 6000; }();
+            static const int shortk = tune_env("RF_SHORTK", 6000);
             if (n320 && p.K <= shortk && mt128 * (N / 160) >= 256) return launch_cfg<T, TO, 4, 1, 1, 5, W8>(d, p, conv, st);
             if (mt128 * nt * pick_splitk(d, p, mt128 * nt, bk) >= 192) {
                 return n320 ? launch_cfg<T, TO, 4, 2, 1, 5, W8>(d, p, conv, st) : launch_cfg<T, TO, 4, 2, 1, 4, W8>(d, p, conv, st);
@@ -1453,7 +1467,10 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
 static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
     using namespace rf;
     RF_CHECK(d != nullptr, "rf_conv_gemm: null descriptor");
-    RF_CHECK(d->dtype == RF_F32 || d->dtype == RF_BF16, "rf_conv_gemm: bad dtype %d", d->dtype);
+    const bool x3 = d->dtype == RF_BF16X3;
+    RF_CHECK(d->dtype == RF_F32 || d->dtype == RF_BF16 || x3, "rf_conv_gemm: bad dtype %d", d->dtype);
+    RF_CHECK(!x3 || (d->out_dtype == RF_F32 && d->w_dtype == 0 && d->korder == 0 && d->C1 == 0 && d->batch == 1 && d->ld0 >= 2 * d->C0),
+             "rf_conv_gemm: split-bf16 operands need fp32 output, one source with pixel pitch >= 2*C0, batch 1, tap-major K");
     RF_CHECK(d->out_dtype == RF_F32 || d->out_dtype == RF_BF16, "rf_conv_gemm: bad out_dtype %d", d->out_dtype);
     const int vec = d->dtype == RF_F32 ? 4 : 8;
     const int ctot = d->C0 + d->C1;
@@ -1466,7 +1483,7 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
     RF_CHECK(d->w_dtype == 0 || w8, "rf_conv_gemm: bad w_dtype %d", d->w_dtype);
     RF_CHECK(!w8 || (d->dtype == RF_BF16 && d->wscale && d->ldw % 128 == 0 && d->ldw >= d->K && d->batch == 1 && d->korder == 0),
              "rf_conv_gemm: fp8 weights need bf16 activations, wscale, batch 1 and ldw (bytes) a multiple of 128 >= K (ldw=%d K=%d)", d->ldw, d->K);
-    RF_CHECK(w8 || d->ldw == 0 || (d->ldw >= d->K && d->ldw % vec == 0), "rf_conv_gemm: bad ldw=%d", d->ldw);
+    RF_CHECK(w8 || d->ldw == 0 || (d->ldw >= (x3 ? 3 : 1) * d->K && d->ldw % vec == 0), "rf_conv_gemm: bad ldw=%d", d->ldw);
     RF_CHECK(d->KH >= 1 && d->KW >= 1 && d->stride >= 1, "rf_conv_gemm: bad window");
     RF_CHECK(d->KH * d->KW * ctot <= d->K && d->K < d->KH * d->KW * ctot + 8 * vec,
              "rf_conv_gemm: K=%d inconsistent with KH*KW*(C0+C1)=%d", d->K, d->KH * d->KW * ctot);
@@ -1486,7 +1503,7 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
     p.C0 = d->C0; p.Ctot = ctot; p.ld0 = d->ld0; p.ld1 = d->ld1;
     p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout;
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.ups = d->ups;
-    p.W = d->W; p.ldw = d->ldw > 0 ? d->ldw : d->K; p.bias = d->bias; p.rowvec = d->rowvec; p.rows_per_sample = d->rows_per_sample; p.ldv = d->ldv;
+    p.W = d->W; p.ldw = d->ldw > 0 ? d->ldw : (x3 ? 3 : 1) * d->K; p.bias = d->bias; p.rowvec = d->rowvec; p.rows_per_sample = d->rows_per_sample; p.ldv = d->ldv;
     p.residual = d->residual; p.ldr = d->ldr; p.act = d->act; p.act_vec = d->act_vec; p.out = d->out; p.ldo = d->ldo; p.alpha = d->alpha;
     p.sA = d->sA; p.sW = d->sW; p.sO = d->sO; p.sR = d->sR;
     p.gn_rows = (d->gn_part0 || d->gn_part1) ? d->gn_rows : 0;
@@ -1494,7 +1511,7 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
     p.gn_part[1] = d->gn_part1; p.gn_cpg[1] = d->gn_cpg1; p.gn_coff[1] = d->gn_coff1; p.gn_slot[1] = d->gn_slot1; p.gn_nch[1] = d->gn_nchunks1;
     p.plan = plan;
     {
-        static const int dbg = [] { const char* e = getenv("RF_GEMM_DBG"); return e ? atoi(e) : 0; }();
+        static const int dbg = tune_env("RF_GEMM_DBG", 0);
         p.dbg = dbg;
     }
     RF_CHECK(!(d->gn_part0 || d->gn_part1) || d->gn_rows > 0, "rf_conv_gemm: gn_part set but gn_rows = %d", d->gn_rows);
@@ -1519,8 +1536,8 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
         // direct-to-LDS main loop needs one source, 31-bit byte offsets ...
         const long long es = d->dtype == RF_F32 ? 4 : 2;
         const long long rows_a = conv ? (long long)(d->M / (d->Hout * d->Wout)) * d->Hin * d->Win : d->M;
-        const long long ab = ((rows_a - 1) * d->ld0 + (conv ? d->C0 : d->K)) * es;
-        const long long wb = w8 ? (long long)d->N * p.ldw : ((long long)(d->N - 1) * p.ldw + d->K) * es;
+        const long long ab = ((rows_a - 1) * d->ld0 + (conv ? d->C0 : d->K) + (x3 ? d->C0 : 0)) * es;
+        const long long wb = w8 ? (long long)d->N * p.ldw : ((long long)(d->N - 1) * p.ldw + (x3 ? 3 : 1) * d->K) * es;
         // ... and K tiles that never straddle a filter tap (uniform K offset per tile; rows packed as sample:12 | oy:10 | ox:10)
         const int bk = (int)(128 / es);
         const bool uniform = d->K % bk == 0 && (!conv || (ctot % bk == 0 && d->K == d->KH * d->KW * ctot &&
@@ -1529,6 +1546,12 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
         p.korder = d->korder;
         p.a_bytes = (unsigned)(p.glds ? ab : 0);
         p.w_bytes = (unsigned)(p.glds ? wb : 0);
+        p.x3 = x3 ? 1 : 0;
+        p.lo_off = x3 ? d->C0 * 2 : 0;
+        if (x3) {
+            RF_CHECK(p.glds && (conv || d->C0 == d->K), "rf_conv_gemm: split-bf16 operands need the direct-to-LDS main loop (K and channel count multiples of 64) and C0 == K for plain GEMMs");
+            p.K = 3 * d->K;          // virtual K: three passes per real K tile
+        }
     }
     hipStream_t st = (hipStream_t)stream;
     p.wscale = d->wscale;
@@ -1536,6 +1559,7 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
         if (d->out_dtype == RF_F32) return launch_typed<bf16_t, float, true>(d, p, conv, st);
         return launch_typed<bf16_t, bf16_t, true>(d, p, conv, st);
     }
+    if (x3) return launch_typed<bf16_t, float>(d, p, conv, st);
     if (d->dtype == RF_F32) {
         if (d->out_dtype == RF_F32) return launch_typed<float, float>(d, p, conv, st);
         return launch_typed<float, bf16_t>(d, p, conv, st);

@@ -104,7 +104,7 @@ template <typename T, typename TO, int NS>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restrict__ x, int HW, int C, int ldx, int nchunks,
                                                               const double* __restrict__ partial, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, int do_silu,
-                                                              TO* __restrict__ out, int ldo, int achunks) {
+                                                              TO* __restrict__ out, int ldo, int achunks, int split) {
     constexpr int VEC = elem<T>::VEC;
     const int nvec = C / VEC;
     const int TV = nvec < GN_THREADS ? nvec : GN_THREADS;
@@ -207,10 +207,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
                     *(u32x4_t*)(orow + v * VEC) = pack16<float>(f);
                     *(u32x4_t*)(orow + v * VEC + 4) = pack16<float>(f + 4);
                 } else {                                     // fp32 in -> bf16 out: half vector
-                    u32x2_t h;
-                    h[0] = pack_bf2(f[0], f[1]);
-                    h[1] = pack_bf2(f[2], f[3]);
+                    u32x2_t h, l;
+                    split4_bf16(f, h, l);
                     *(u32x2_t*)(orow + v * VEC) = h;
+                    if (split) *(u32x2_t*)(orow + C + v * VEC) = l;      // RF_BF16X3: the lo plane of the pixel lies C elements behind
                 }
             }
         }
@@ -402,7 +402,9 @@ extern "C" int rf_groupnorm_apply(int dtype, const void* x, int B, int HW, int C
     if (gn_check("rf_groupnorm_apply", dtype, C, ldx, nchunks)) return 1;
     RF_CHECK(x && partial && gamma && beta && out && B > 0 && HW > 0, "rf_groupnorm_apply: bad arguments");
     RF_CHECK((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "rf_groupnorm_apply: gamma / beta must be 16-byte aligned");
-    RF_CHECK(out_dtype == RF_F32 || out_dtype == RF_BF16, "rf_groupnorm_apply: bad out_dtype");
+    const int split = out_dtype == RF_BF16X3 ? 1 : 0;      // [C hi | C lo] bf16 pairs per pixel (ldo >= 2C), fp32 input
+    RF_CHECK(out_dtype == RF_F32 || out_dtype == RF_BF16 || split, "rf_groupnorm_apply: bad out_dtype");
+    RF_CHECK(!split || (dtype == RF_F32 && ldo >= 2 * C), "rf_groupnorm_apply: split-bf16 output needs fp32 input and ldo >= 2C");
     RF_CHECK(ldo % 8 == 0, "rf_groupnorm_apply: ldo=%d must be a multiple of 8", ldo);
     // blocks of >= ~16 pixels, about 4 blocks per CU in total
     int achunks = (1024 + B - 1) / B;
@@ -412,7 +414,7 @@ extern "C" int rf_groupnorm_apply(int dtype, const void* x, int B, int HW, int C
     dim3 grid(achunks, B);
     hipStream_t st = (hipStream_t)stream;
     const int ns = (C / (dtype == RF_F32 ? 4 : 8) + GN_THREADS - 1) / GN_THREADS;      // channel vectors per thread
-#define GN_APPLY_(T, TO, NS_) hipLaunchKernelGGL((gn_apply_kernel<T, TO, NS_>), grid, dim3(GN_THREADS), 0, st, (const T*)x, HW, C, ldx, nchunks, partial, gamma, beta, eps, silu, (TO*)out, ldo, achunks)
+#define GN_APPLY_(T, TO, NS_) hipLaunchKernelGGL((gn_apply_kernel<T, TO, NS_>), grid, dim3(GN_THREADS), 0, st, (const T*)x, HW, C, ldx, nchunks, partial, gamma, beta, eps, silu, (TO*)out, ldo, achunks, split)
 #define GN_APPLY(T, TO) { if (ns <= 1) GN_APPLY_(T, TO, 1); else if (ns <= 2) GN_APPLY_(T, TO, 2); else GN_APPLY_(T, TO, GN_SLOTS); }
     if (dtype == RF_F32 && out_dtype == RF_F32) GN_APPLY(float, float)
     else if (dtype == RF_F32) GN_APPLY(float, bf16_t)

@@ -5,11 +5,12 @@ hot path is a HIP kernel from libreface_hip.so.  Activations are channels-last t
 ([B, H, W, C] or [M, C]) in fp32 or bf16; biases / norm affine parameters stay fp32.
 """
 import ctypes as C
+import threading
 
 import torch
 
 from . import _lib
-from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_PRELU, ACT_QUICK_GELU, ACT_RELU, ACT_SIGMOID, ACT_SILU, RF_BF16, RF_F32,
+from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_PRELU, ACT_QUICK_GELU, ACT_RELU, ACT_SIGMOID, ACT_SILU, RF_BF16, RF_BF16X3, RF_F32,
                    RF_FP8_E4M3, ConvGemmDesc)
 
 # Attention scores in the exp2 domain: the UNet folds d^-0.5 * log2(e) into the to_q weights and calls rf_attention with scale = ln 2
@@ -64,6 +65,33 @@ def pack_conv_weight(w, dtype, cin_pad=None, korder=0):
         assert cp % bk == 0
         wp = wp.reshape(co, kh * kw, cp // bk, bk).permute(0, 2, 1, 3)
     return wp.reshape(co, kh * kw * cp).to(dtype).contiguous()
+
+
+def pack_x3(w2d):
+    """fp32 GEMM weight [N, K] (K a multiple of 64, already in rf_conv_gemm's K order) -> the split-bf16 operand of the RF_BF16X3 mode:
+    [N, 3K] bf16, per 64-element K tile [64 hi | 64 lo | 64 hi] with hi = bf16(w), lo = bf16(w - hi)."""
+    n, k = w2d.shape
+    assert k % 64 == 0, k
+    w = w2d.float()
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    h3, l3 = hi.reshape(n, k // 64, 64), lo.reshape(n, k // 64, 64)
+    return torch.stack([h3, l3, h3], dim=2).reshape(n, 3 * k).contiguous()
+
+
+def x3_eligible(K, cin=None):
+    """The split-bf16 mode runs on the direct-to-LDS main loop: K (and the channel count of a convolution) multiples of 64."""
+    return K % 64 == 0 and (cin is None or cin % 64 == 0)
+
+
+def split_bf16(x, out, name="split_bf16"):
+    """x fp32 [..., C] (uniform pixel pitch) -> out bf16 [..., 2C] = [hi | lo] per pixel (rf_split_bf16)."""
+    lib = _lib.load()
+    _require_gpu(x, out)
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    assert x.dtype == torch.float32 and out.dtype == torch.bfloat16 and out.shape[-1] == 2 * Cc and x.stride(-1) == 1 and out.stride(-1) == 1
+    return Launch(lib.rf_split_bf16, (_p(x), M, Cc, x.stride(-2), _p(out), out.stride(-2)), (x, out), name)
 
 
 def pack_geglu(w, b, dtype):
@@ -157,23 +185,31 @@ class Launch:
 
 _WORKSPACES = {}
 SPLITK_WORKSPACE_BYTES = 96 << 20
-_SCOPE = []          # innermost engine workspace (workspace_scope)
+_TLS = threading.local()          # per-thread stack of engine workspaces (workspace_scope): the CLI builds / runs engines from helper threads
+
+
+def _scope_stack():
+    st = getattr(_TLS, "stack", None)
+    if st is None:
+        st = _TLS.stack = []
+    return st
 
 
 class workspace_scope:
     """Launches prepared inside the scope use `ws` as their split-K scratch.  Each engine (UNet, VAE encoder / decoder, CLIP,
     ArcFace) owns one: launch lists of different engines may then run concurrently on different streams without sharing
-    partial-sum memory; inside one engine the launches are serialised on a stream."""
+    partial-sum memory; inside one engine the launches are serialised on a stream.  The scope is thread-local: an engine built lazily on
+    a helper thread (landmark prefetch, PNG writer) never sees another thread's open scope."""
 
     def __init__(self, ws):
         self.ws = ws
 
     def __enter__(self):
-        _SCOPE.append(self.ws)
+        _scope_stack().append(self.ws)
         return self.ws
 
     def __exit__(self, *a):
-        _SCOPE.pop()
+        _scope_stack().pop()
 
 
 def new_workspace(device, nbytes=SPLITK_WORKSPACE_BYTES):
@@ -182,8 +218,9 @@ def new_workspace(device, nbytes=SPLITK_WORKSPACE_BYTES):
 
 def _default_workspace(device):
     """Split-K scratch of launches prepared outside any engine: one fp32 buffer per device -- single-stream use only."""
-    if _SCOPE:
-        return _SCOPE[-1]
+    st = _scope_stack()
+    if st:
+        return st[-1]
     ws = _WORKSPACES.get(device)
     if ws is None:
         ws = new_workspace(device)
@@ -193,8 +230,10 @@ def _default_workspace(device):
 
 def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, Win=1, Hout=1, Wout=1, KH=1, KW=1,
               stride=1, pad_t=0, pad_l=0, ups=0, bias=None, rowvec=None, rows_per_sample=0, ldv=0, residual=None, ldr=0,
-              act=ACT_NONE, ldo=None, alpha=1.0, batch=1, sA=0, sW=0, sO=0, sR=0, ldw=0, act_vec=None, korder=0, workspace=None, name="rf_conv_gemm"):
-    """Prepare an rf_conv_gemm launch (see include/reface_hip.h)."""
+              act=ACT_NONE, ldo=None, alpha=1.0, batch=1, sA=0, sW=0, sO=0, sR=0, ldw=0, act_vec=None, korder=0, workspace=None, x3=False,
+              name="rf_conv_gemm"):
+    """Prepare an rf_conv_gemm launch (see include/reface_hip.h).  x3: split-bf16 operands (src0 = [.., C0 hi | C0 lo] bf16, W from
+    pack_x3, fp32 out); K / C0 are the REAL sizes."""
     lib = _lib.load()
     _require_gpu(src0, W.q if isinstance(W, Fp8Weight) else W, out, src1, bias, rowvec, residual)
     d = ConvGemmDesc()
@@ -206,6 +245,9 @@ def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, 
         d.w_dtype, d.wscale, ldw = RF_FP8_E4M3, _p(wq.scale), W.stride(0)
     else:
         assert W.dtype == src0.dtype
+    if x3:
+        assert src0.dtype == torch.bfloat16 and out.dtype == torch.float32 and wq is None and W.shape[-1] == 3 * K, (src0.dtype, out.dtype, tuple(W.shape), K)
+        d.dtype = RF_BF16X3
     assert (src1 is None or src1.dtype == src0.dtype)
     assert residual is None or residual.dtype == out.dtype
     assert bias is None or bias.dtype == torch.float32
@@ -224,7 +266,18 @@ def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, 
     d.korder = korder
     ws = workspace if workspace is not None else _default_workspace(src0.device)
     d.workspace, d.workspace_bytes = _p(ws), (ws.numel() * ws.element_size() if ws is not None else 0)
-    return Launch(lib.rf_conv_gemm, (C.byref(d),), (d, src0, src1, W, out, bias, rowvec, residual, act_vec, ws, wq), name)
+    l = Launch(lib.rf_conv_gemm, (C.byref(d),), (d, src0, src1, W, out, bias, rowvec, residual, act_vec, ws, wq), name)
+    if wq is not None:
+        # fp8 weights run only on the direct-to-LDS main loop, whose preconditions (one source, 31-bit operand extents, <= 1024^2 outputs,
+        # < 4095 samples, whole K tiles per tap) depend on the launch, not only on the weight: ask the library, and give a layer that
+        # cannot take them its exactly dequantised bf16 weights instead of failing at the first replay
+        bm, bn, sk = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        if lib.rf_conv_gemm_plan(C.byref(d), C.byref(bm), C.byref(bn), C.byref(sk)) != 0:
+            wd = wq.dequant().to(torch.bfloat16).contiguous()
+            d.w_dtype, d.wscale, d.W, d.ldw = 0, None, _p(wd), 0
+            l = Launch(lib.rf_conv_gemm, (C.byref(d),), (d, src0, src1, wd, out, bias, rowvec, residual, act_vec, ws), name)
+            _lib.check(lib.rf_conv_gemm_plan(C.byref(d), C.byref(bm), C.byref(bn), C.byref(sk)), name + ".plan")
+    return l
 
 
 def linear(x, W, out, bias=None, *, act=ACT_NONE, residual=None, rowvec=None, rows_per_sample=0, alpha=1.0, act_vec=None, name="linear"):
@@ -239,19 +292,23 @@ def linear(x, W, out, bias=None, *, act=ACT_NONE, residual=None, rowvec=None, ro
 
 
 def conv2d(x, W, out, bias=None, *, ksize=3, stride=1, pad=(1, 1), ups=0, x2=None, residual=None, rowvec=None,
-           act=ACT_NONE, act_vec=None, korder=0, name="conv2d"):
+           act=ACT_NONE, act_vec=None, korder=0, x3=False, name="conv2d"):
     """Channels-last convolution.  x: [B, Hin, Win, C0] (+ optional x2 [B, Hin, Win, C1] concatenated
-    on channels); W: packed [Cout, k*k*(C0+C1)]; out: [B, Hout, Wout, Cout]."""
+    on channels); W: packed [Cout, k*k*(C0+C1)]; out: [B, Hout, Wout, Cout].  x3: x is the split-bf16 form [B, Hin, Win, 2*C0] of an
+    fp32 tensor and W comes from pack_x3 ([Cout, 3*k*k*C0])."""
     B, Hin, Win, C0 = x.shape
     C1 = 0 if x2 is None else x2.shape[3]
     Bo, Hout, Wout, N = out.shape
     assert Bo == B and x.stride(3) == 1 and out.stride(3) == 1
     K = W.shape[1]
+    if x3:
+        assert x2 is None and C0 % 2 == 0 and K % 3 == 0
+        C0, K = C0 // 2, K // 3
     return conv_gemm(x, W, out, M=B * Hout * Wout, N=N, K=K, C0=C0, ld0=x.stride(2), src1=x2, C1=C1,
                      ld1=(x2.stride(2) if x2 is not None else 0), Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, KH=ksize, KW=ksize,
                      stride=stride, pad_t=pad[0], pad_l=pad[1], ups=ups, bias=bias, residual=residual,
                      ldr=(residual.stride(2) if residual is not None else 0), rowvec=rowvec, rows_per_sample=Hout * Wout,
-                     ldv=(rowvec.stride(0) if rowvec is not None else 0), act=act, act_vec=act_vec, ldo=out.stride(2), korder=korder, name=name)
+                     ldv=(rowvec.stride(0) if rowvec is not None else 0), act=act, act_vec=act_vec, ldo=out.stride(2), korder=korder, x3=x3, name=name)
 
 
 GN_MAX_CHUNKS = 32
@@ -267,7 +324,14 @@ def gn_chunks(B, HW):
     return n
 
 
-def groupnorm(x, gamma, beta, out, partial, *, eps, silu, name="groupnorm"):
+def _gn_out_code(x, out, split):
+    if split:           # out = split-bf16 pairs [B, H, W, 2C] of the normalised fp32 values (RF_BF16X3 operand of the next conv)
+        assert x.dtype == torch.float32 and out.dtype == torch.bfloat16 and out.shape[-1] == 2 * x.shape[-1]
+        return RF_BF16X3
+    return code(out.dtype)
+
+
+def groupnorm(x, gamma, beta, out, partial, *, eps, silu, split=False, name="groupnorm"):
     """GroupNorm(32)(+SiLU) over channels-last x [B, H, W, C] -> out.  ``partial``: fp64 scratch
     of at least B * GN_MAX_CHUNKS * 64 elements.  Returns the two launches (stats, apply)."""
     lib = _lib.load()
@@ -278,7 +342,7 @@ def groupnorm(x, gamma, beta, out, partial, *, eps, silu, name="groupnorm"):
     assert partial.dtype == torch.float64 and partial.numel() >= B * n * 64
     a = Launch(lib.rf_groupnorm_stats, (code(x.dtype), _p(x), B, HW, Cc, x.stride(2), n, _p(partial)), (x, partial), name + ".stats")
     b = Launch(lib.rf_groupnorm_apply, (code(x.dtype), _p(x), B, HW, Cc, x.stride(2), n, _p(partial), _p(gamma), _p(beta),
-                                        float(eps), int(bool(silu)), code(out.dtype), _p(out), out.stride(2)),
+                                        float(eps), int(bool(silu)), _gn_out_code(x, out, split), _p(out), out.stride(2)),
                (x, partial, gamma, beta, out), name + ".apply")
     return [a, b]
 
@@ -341,13 +405,13 @@ def fuse_groupnorm_stats(x, producers):
     return partial, nslots, []
 
 
-def groupnorm_apply(x, gamma, beta, out, partial, nchunks, *, eps, silu, name="groupnorm"):
+def groupnorm_apply(x, gamma, beta, out, partial, nchunks, *, eps, silu, split=False, name="groupnorm"):
     """The normalisation pass alone, on statistics that already sit in ``partial`` (fuse_groupnorm_stats)."""
     lib = _lib.load()
     _require_gpu(x, gamma, beta, out, partial)
     B, H, W_, Cc = x.shape
     return Launch(lib.rf_groupnorm_apply, (code(x.dtype), _p(x), B, H * W_, Cc, x.stride(2), nchunks, _p(partial), _p(gamma), _p(beta),
-                                           float(eps), int(bool(silu)), code(out.dtype), _p(out), out.stride(2)),
+                                           float(eps), int(bool(silu)), _gn_out_code(x, out, split), _p(out), out.stride(2)),
                   (x, partial, gamma, beta, out), name + ".apply")
 
 

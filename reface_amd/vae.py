@@ -60,7 +60,14 @@ class DiagonalGaussianDistribution(object):
 
 class _VAEEngine:
     def __init__(self, sd, cfg: VAEConfig, B, H, W, dtype, device, which):
+        # dtype "bf16x3": fp32 storage of the residual stream, statistics, attention and every epilogue; the operands of the 3x3 / 1x1
+        # convolutions as split-bf16 pairs (hi + lo = 16 significant bits) multiplied in three bf16 MFMA passes with fp32 accumulation
+        # (rf_conv_gemm RF_BF16X3): ~2^-16 relative error per product instead of fp32's 2^-24, at a multiple of the fp32-MFMA rate
+        self.x3 = dtype == "bf16x3"
+        if self.x3:
+            dtype = F32
         self.cfg, self.B, self.dt, self.dev = cfg, B, dtype, device
+        self.n_x3 = 0
         self.pool = _Pool(device)
         self.tracker = ProducerTracker()
         self.pool.on_put = self.tracker.forget
@@ -80,8 +87,18 @@ class _VAEEngine:
     def f32(self, key):
         return self.sd[key].contiguous()
 
-    def _gn(self, x, key, silu=True):
-        out = self.pool.get(tuple(x.shape), self.dt)
+    def _x3_ok(self, cin, ksize=3):
+        return self.x3 and ops.x3_eligible(ksize * ksize * cin, cin)
+
+    def _split(self, x):
+        """fp32 residual-stream tensor -> its split-bf16 form (a conv input that no GroupNorm pass rewrites)."""
+        B, H, W, c = x.shape
+        s = self.pool.get((B, H, W, 2 * c), torch.bfloat16)
+        self.launches.append(ops.split_bf16(x, s, name="split_bf16"))
+        return s
+
+    def _gn(self, x, key, silu=True, split=False):
+        out = self.pool.get(tuple(x.shape[:3]) + (2 * x.shape[3],), torch.bfloat16) if split else self.pool.get(tuple(x.shape), self.dt)
         fused = None
         if self.gn_fuse:            # statistics from the epilogue of the GEMM that wrote x, when its tile plan allows
             prods = self.tracker.producers(x)
@@ -90,32 +107,54 @@ class _VAEEngine:
         if fused is not None:
             self.launches += fused[2]
             self.launches.append(ops.groupnorm_apply(x, self.f32(key + ".weight"), self.f32(key + ".bias"), out, fused[0], fused[1],
-                                                     eps=1e-6, silu=silu, name=key))
+                                                     eps=1e-6, silu=silu, split=split, name=key))
             self.gn_fused += 1
         else:
             self.launches += ops.groupnorm(x, self.f32(key + ".weight"), self.f32(key + ".bias"), out, self.gn_partial, eps=1e-6,
-                                           silu=silu, name=key)
+                                           silu=silu, split=split, name=key)
         return out
 
     def _conv3(self, key, x, cout, *, cin_pad=None, stride=1, pad=(1, 1), ups=0, residual=None, out=None):
         B, H, W, _ = x.shape
         Ho, Wo = (2 * H, 2 * W) if ups else ((H // 2, W // 2) if stride == 2 else (H, W))
         y = out if out is not None else self.pool.get((B, Ho, Wo, cout), self.dt)
-        self.launches.append(self.tracker.record(y, ops.conv2d(x, ops.pack_conv_weight(self.sd[key + ".weight"], self.dt, cin_pad=cin_pad), y,
-                                                               self.f32(key + ".bias"), stride=stride, pad=pad, ups=ups, residual=residual, name=key)))
+        x3 = self.x3 and x.dtype == torch.bfloat16            # x is the split-bf16 form (from _gn(split=True) / _split)
+        wp = ops.pack_conv_weight(self.sd[key + ".weight"], F32 if x3 else self.dt, cin_pad=cin_pad)
+        if x3:
+            wp = ops.pack_x3(wp)
+            self.n_x3 += 1
+        self._conv(x, wp, y, self.f32(key + ".bias"), stride=stride, pad=pad, ups=ups, residual=residual, x3=x3, name=key)
         return y
+
+    def _conv(self, x, wp, y, bias, residual=None, **kw):
+        """One convolution as 1, 2, 4 ... launches over batch slices: the direct-to-LDS main loop addresses its operand with 31-bit byte
+        offsets, and the 512x512 level of a B = 8 decode holds 2.1 GB per tensor (fp32 or split-bf16 alike)."""
+        B, n = x.shape[0], 1
+        while (x.numel() // n) * x.element_size() >= 0x7fff0000 and B % (2 * n) == 0:
+            n *= 2
+        step = B // n
+        for i in range(n):
+            sl = slice(i * step, (i + 1) * step)
+            self.launches.append(self.tracker.record(y[sl], ops.conv2d(x[sl], wp, y[sl], bias, residual=None if residual is None else residual[sl], **kw)))
 
     def _res(self, p, x, cin, cout):
         B, H, W, _ = x.shape
-        t1 = self._gn(x, f"{p}.norm1")
+        t1 = self._gn(x, f"{p}.norm1", split=self._x3_ok(cin))
         h1 = self._conv3(f"{p}.conv1", t1, cout)
         self.pool.put(t1)
-        t2 = self._gn(h1, f"{p}.norm2")
+        t2 = self._gn(h1, f"{p}.norm2", split=self._x3_ok(cout))
         self.pool.put(h1)
         if cin != cout:
             sc = self.pool.get((B, H, W, cout), self.dt)
-            self.launches.append(ops.conv2d(x, self.w(f"{p}.nin_shortcut.weight").reshape(cout, cin), sc,
-                                            self.f32(f"{p}.nin_shortcut.bias"), ksize=1, pad=(0, 0), name=f"{p}.nin_shortcut"))
+            if self._x3_ok(cin, 1):
+                xs = self._split(x)
+                self._conv(xs, ops.pack_x3(self.sd[f"{p}.nin_shortcut.weight"].reshape(cout, cin)), sc,
+                           self.f32(f"{p}.nin_shortcut.bias"), ksize=1, pad=(0, 0), x3=True, name=f"{p}.nin_shortcut")
+                self.pool.put(xs)
+                self.n_x3 += 1
+            else:
+                self._conv(x, self.w(f"{p}.nin_shortcut.weight").reshape(cout, cin), sc,
+                           self.f32(f"{p}.nin_shortcut.bias"), ksize=1, pad=(0, 0), name=f"{p}.nin_shortcut")
         else:
             sc = x
         y = self._conv3(f"{p}.conv2", t2, cout, residual=sc)
@@ -191,10 +230,13 @@ class _VAEEngine:
                 self.pool.put(hcur)
                 hcur, block_in = nh, block_out
             if lvl != 0:
-                nh = self._conv3(f"decoder.up.{lvl}.upsample.conv", hcur, block_in, ups=1)
+                hs = self._split(hcur) if self._x3_ok(block_in) else hcur
+                nh = self._conv3(f"decoder.up.{lvl}.upsample.conv", hs, block_in, ups=1)
+                if hs is not hcur:
+                    self.pool.put(hs)
                 self.pool.put(hcur)
                 hcur = nh
-        g = self._gn(hcur, "decoder.norm_out")
+        g = self._gn(hcur, "decoder.norm_out", split=self._x3_ok(block_in))
         self.pool.put(hcur)
         H, W = g.shape[1], g.shape[2]
         out4 = torch.empty((B, H, W, 4), dtype=F32, device=dev)
@@ -234,11 +276,14 @@ class _VAEEngine:
                 self.pool.put(hcur)
                 hcur, block_in = nh, block_out
             if lvl != nres - 1:
-                nh = self._conv3(f"encoder.down.{lvl}.downsample.conv", hcur, block_in, stride=2, pad=(0, 0))
+                hs = self._split(hcur) if self._x3_ok(block_in) else hcur
+                nh = self._conv3(f"encoder.down.{lvl}.downsample.conv", hs, block_in, stride=2, pad=(0, 0))
+                if hs is not hcur:
+                    self.pool.put(hs)
                 self.pool.put(hcur)
                 hcur = nh
         hcur = self._mid("encoder.mid", hcur, block_in)
-        g = self._gn(hcur, "encoder.norm_out")
+        g = self._gn(hcur, "encoder.norm_out", split=self._x3_ok(block_in))
         self.pool.put(hcur)
         zc = 2 * cfg.z_channels
         h8 = self._conv3("encoder.conv_out", g, zc)
@@ -264,6 +309,9 @@ class AutoencoderKL(nn.Module):
         self.cfg = VAEConfig(embed_dim=embed_dim, **dd)
         self.embed_dim, self.image_key = embed_dim, image_key
         self.compute_dtype = compute_dtype or torch.float32
+        # how the fp32 decode multiplies: "bf16x3" (default) = split-bf16 operand pairs, three bf16 MFMA passes, fp32 accumulate and fp32
+        # storage (pinned to the CPU oracle within the 1e-3 per-pixel gate by tests/test_fullsize_gpu.py); "f32" = exact fp32 MFMA
+        self.decode_mode = os.environ.get("REFACE_VAE_DECODE", "bf16x3")
         tree = ParamTree(vae_param_specs(self.cfg))
         for name, child in tree.named_children():
             self.add_module(name, child)
@@ -281,6 +329,8 @@ class AutoencoderKL(nn.Module):
             raise RuntimeError("reface_amd.AutoencoderKL runs on the GPU only (HIP kernels; there is no CPU fallback)")
         # the encoder may run in its own dtype (throughput mode: bf16 encode of the masked target, fp32 decode of the result)
         dt = (getattr(self, "encode_dtype", None) or self.compute_dtype) if which == "enc" else self.compute_dtype
+        if which == "dec" and dt == torch.float32 and self.decode_mode == "bf16x3":
+            dt = "bf16x3"
         key = (which, B, H, W, dt, weights_version(self))
         eng = self._engines.get(key)
         if eng is None:

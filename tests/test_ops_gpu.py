@@ -489,3 +489,117 @@ def test_ffn_geglu_fused(M):
     ref = F.linear(hid_ref, w2.to(dt).float(), b2) + rr
     check(out, ref, dt)
     assert (out.float() - out_u.float()).abs().max().item() <= 2.0 ** -6 * max(1.0, ref.abs().max().item())       # <= 2 bf16 ulps apart
+
+
+# ------------------------------------------------------------------------------------------------ split-bf16 (RF_BF16X3) operands
+def _split_ref(x):
+    """(hi, lo) bf16 pair of an fp32 tensor, as rf_split_bf16 / rf_groupnorm_apply(out_dtype = RF_BF16X3) define it."""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return hi, lo
+
+
+def test_split_bf16_kernel_bit_exact():
+    x = rnd((3, 5, 7, 64), 900) * 3.0
+    out = torch.zeros((3, 5, 7, 128), dtype=torch.bfloat16, device=DEV)
+    ops.split_bf16(x.to(DEV), out)()
+    torch.cuda.synchronize()
+    hi, lo = _split_ref(x)
+    assert torch.equal(out[..., :64].cpu(), hi) and torch.equal(out[..., 64:].cpu(), lo)
+    # hi + lo carries 16 significant bits
+    rec = out[..., :64].float().cpu() + out[..., 64:].float().cpu()
+    assert ((rec - x).abs() <= 2.0 ** -16 * x.abs() + 1e-30).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 192, 128), (4096, 128, 1152), (1024, 512, 4608)])
+def test_linear_x3_vs_fp64(M, N, K):
+    """out = x W^T on split-bf16 operands: hi*hi + hi*lo + lo*hi in fp32 -- 2^-16-class relative error per product, two orders of
+    magnitude under the plain bf16 kernel, and a transposition-detecting reference (fp64 of the original fp32 operands)."""
+    x = rnd((M, K), 901)
+    w = rnd((N, K), 902) / math.sqrt(K)
+    b = rnd((N,), 903)
+    res = rnd((M, N), 904)
+    xs = torch.empty((M, 2 * K), dtype=torch.bfloat16, device=DEV)
+    ops.split_bf16(x.to(DEV), xs)()
+    out = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    l = ops.conv_gemm(xs, ops.pack_x3(w).to(DEV), out, M=M, N=N, K=K, C0=K, ld0=2 * K, Hin=1, Win=M, Hout=1, Wout=M, bias=b.to(DEV),
+                      residual=res.to(DEV), ldr=N, ldo=N, x3=True)
+    l()
+    torch.cuda.synchronize()
+    ref = (x.double() @ w.double().T + b.double() + res.double())
+    err = (out.cpu().double() - ref).abs().max().item()
+    # sum over K of |x w| ~ 0.8 sqrt(K) * ... : bound the error by 2^-15 * sum|x||w| (three dropped / rounded terms) + fp32 accumulation
+    bound = (x.abs().double() @ w.abs().double().T).max().item() * 2.0 ** -15 + 1e-5
+    assert err < bound, (err, bound)
+    assert err < 2e-4, err
+    # the plain bf16 kernel on the same operands is >= 20x further away: the lo passes really are multiplied in
+    outb = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    ops.linear(x.to(torch.bfloat16).to(DEV), w.to(torch.bfloat16).to(DEV), outb, b.to(DEV), residual=res.to(DEV))()
+    torch.cuda.synchronize()
+    errb = (outb.cpu().double() - ref).abs().max().item()
+    assert errb > 20 * err, (errb, err)
+
+
+@pytest.mark.parametrize("case", ["s1", "s2asym", "ups", "k1", "big"])
+def test_conv_x3_vs_fp64(case):
+    B, H, W_, Ci, Co = 2, 12, 10, 64, 96
+    stride, pad4, ups, ks = 1, (1, 1, 1, 1), 0, 3
+    if case == "s2asym":
+        stride, pad4 = 2, (0, 1, 0, 1)
+    elif case == "ups":
+        ups = 1
+    elif case == "k1":
+        ks, pad4 = 1, (0, 0, 0, 0)
+    elif case == "big":                       # 8-wave tiles + split-K-free long K
+        B, H, W_, Ci, Co = 2, 64, 64, 128, 256
+    x = rnd((B, H, W_, Ci), 905)
+    w = rnd((Co, Ci, ks, ks), 906) / math.sqrt(Ci * ks * ks)
+    b = rnd((Co,), 907)
+    ref = _conv_ref(x.double(), w.double(), b.double(), stride, pad4, ups)
+    xs = torch.empty((B, H, W_, 2 * Ci), dtype=torch.bfloat16, device=DEV)
+    ops.split_bf16(x.to(DEV), xs)()
+    out = torch.empty(ref.shape, dtype=torch.float32, device=DEV)
+    ops.conv2d(xs, ops.pack_x3(ops.pack_conv_weight(w, torch.float32)).to(DEV), out, b.to(DEV), ksize=ks, stride=stride, pad=(pad4[2], pad4[0]),
+               ups=ups, x3=True)()
+    torch.cuda.synchronize()
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert torch.isfinite(out).all() and err < 1e-4, err
+
+
+def test_groupnorm_apply_split_output():
+    """GroupNorm + SiLU of an fp32 tensor written as split-bf16 pairs == rf_split_bf16 of the fp32 result of the same kernel."""
+    B, H, W_, Cc = 2, 16, 16, 128
+    x = rnd((B, H, W_, Cc), 908).to(DEV)
+    g, bt = rnd((Cc,), 909).to(DEV), rnd((Cc,), 910).to(DEV)
+    part = torch.empty(B * ops.GN_MAX_CHUNKS * 64, dtype=torch.float64, device=DEV)
+    y32 = torch.empty_like(x)
+    ops.run(ops.groupnorm(x, g, bt, y32, part, eps=1e-6, silu=True))
+    ys = torch.zeros((B, H, W_, 2 * Cc), dtype=torch.bfloat16, device=DEV)
+    ops.run(ops.groupnorm(x, g, bt, ys, part, eps=1e-6, silu=True, split=True))
+    torch.cuda.synchronize()
+    hi, lo = _split_ref(y32.cpu())
+    assert torch.equal(ys[..., :Cc].cpu(), hi) and torch.equal(ys[..., Cc:].cpu(), lo)
+
+
+def test_geglu_negative_gates():
+    """bf16 GEGLU uses the tanh-form GELU (|gelu_tanh - gelu_erf| <= 4.8e-4 absolute).  For negative gates gelu(g) is small, so the bound on
+    the PRODUCT is absolute: |out - value * gelu_erf(gate)| <= 4.8e-4 * |value| + bf16 rounding of the product.  Gates swept over [-6, 0]."""
+    M, Cc, Fh = 256, 64, 64
+    dt = torch.bfloat16
+    x = torch.zeros((M, Cc))
+    x[:, 0] = torch.linspace(-6.0, 0.0, M)          # channel 0 drives the gate, channel 1 the value
+    x[:, 1] = rnd((M,), 920) * 2.0
+    w = torch.zeros((2 * Fh, Cc))
+    w[:Fh, 1] = 1.0                                  # value rows = x[:, 1]
+    w[Fh:, 0] = 1.0                                  # gate rows  = x[:, 0]
+    b = torch.zeros((2 * Fh,))
+    xd, xr = q(x, dt)
+    wp, bp = ops.pack_geglu(w, b, dt)
+    out = torch.empty((M, Fh), dtype=dt, device=DEV)
+    ops.linear(xd, wp.to(DEV), out, bp.to(DEV), act=ops.ACT_GEGLU)()
+    torch.cuda.synchronize()
+    val, gate = xr[:, 1:2].double(), xr[:, 0:1].double()
+    ref = (val * 0.5 * gate * (1.0 + torch.erf(gate / math.sqrt(2.0)))).expand(M, Fh)
+    err = (out.double().cpu() - ref).abs()
+    lim = 4.8e-4 * val.abs() + 2.0 ** -8 * ref.abs() + 1e-6
+    assert (err <= lim).all(), (err - lim).max().item()

@@ -1,13 +1,14 @@
 #!/bin/bash
 # Build an alternate libreface_hip.so with one replaced .hip source, for same-box A/B runs:
 #   tools/build_variant.sh gemm /tmp/gemm_old.hip base   ->  reface_amd/lib/alt/base.so   (use with REFACE_HIP_LIB=...)
+# Compile flags come from reface_amd/build.py (one source of truth), plus -DRF_EXPERIMENT: only variant builds read the RF_* tuning /
+# timing-decomposition environment switches (csrc/common.h tune_env); $VARIANT_DEFS adds more defines.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 unit=$1; src=$2; tag=$3
 mkdir -p $ROOT/reface_amd/lib/alt
-extra=""
-[ "$unit" = attention ] && extra="-mllvm -amdgpu-mfma-vgpr-form -fno-slp-vectorize"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $extra $VARIANT_DEFS -I$ROOT/reface_amd/csrc -I$ROOT/include -c $src -o $ROOT/reface_amd/lib/alt/$tag.$unit.o
+flags=$(cd $ROOT && python -m reface_amd.build --print-flags $unit)
+/opt/rocm/bin/hipcc $flags -DRF_EXPERIMENT $VARIANT_DEFS -I$ROOT/reface_amd/csrc -I$ROOT/include -c $src -o $ROOT/reface_amd/lib/alt/$tag.$unit.o
 objs=""
 for u in gemm norm attention elementwise encoder ffn; do
   if [ $u = $unit ]; then objs="$objs $ROOT/reface_amd/lib/alt/$tag.$unit.o"; else objs="$objs $ROOT/reface_amd/lib/$u.o"; fi
