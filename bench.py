@@ -338,6 +338,13 @@ def main():
         from reface_amd.multigpu import max_over_ranks
         elapsed = max_over_ranks(elapsed, "cpu" if args.share_gpu else device)
     assert torch.isfinite(out).all(), "non-finite output image"
+    wsums = None
+    if world > 1:
+        # every rank must be running rank 0's weights (flat RCCL broadcast at start-up): one fp64 checksum per rank, gathered once
+        import torch.distributed as dist
+        cs = float(sum(p.detach().double().sum().item() for p in list(unet.parameters())[:64] + list(vae.parameters())[:64]))
+        wsums = [None] * world
+        dist.all_gather_object(wsums, cs)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
@@ -354,6 +361,9 @@ def main():
                    "parallelism": f"dp{world} (pairs sharded, no collective in the step loop)"},
     }
 
+    if wsums is not None:
+        result["weights_checksum_per_rank"] = wsums
+        result["weights_identical_on_all_ranks"] = all(w == wsums[0] for w in wsums)
     if rank == 0 and not args.no_roofline:
         from reface_amd import profiler
         plan = list(sampler._plans.values())[0]

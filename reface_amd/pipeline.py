@@ -14,6 +14,11 @@ class SwapRunner:
     def __init__(self, model, sampler, opt):
         self.model, self.sampler, self.opt = model, sampler, opt
         self.device = torch.device("cuda")
+        # --dump_tensors <dir> (an addition of this build's CLIs): every batch's inputs -- including the random draws the reference makes
+        # implicitly (posterior noise on the CPU, distributions.py:36; x_T on the device, ddim.py:211) -- and intermediate results as
+        # batch_<n>.npz, so that a test can run the CPU oracle chain on exactly the tensors a caller fed the engines
+        self.dump_dir = getattr(opt, "dump_tensors", None)
+        self.n_dumped = 0
 
     @torch.no_grad()
     def start_from_target(self, x0_img):
@@ -37,7 +42,9 @@ class SwapRunner:
         if len(c.shape) == 2:
             c = c.unsqueeze(1)
         inpaint_image, inpaint_mask = test_model_kwargs["inpaint_image"], test_model_kwargs["inpaint_mask"]
-        z_inpaint = m.get_first_stage_encoding(m.encode_first_stage(inpaint_image)).detach()
+        post = m.encode_first_stage(inpaint_image)
+        post_noise = torch.randn(post.mean.shape) if self.dump_dir else None          # (the draw get_first_stage_encoding makes itself otherwise)
+        z_inpaint = m.get_first_stage_encoding(post, noise=post_noise).detach()
         h = z_inpaint.shape[-1]
         m64 = torch.empty((B, 1, h, h), dtype=torch.float32, device=dev)
         ops.bilinear_resize(inpaint_mask.float().contiguous(), m64)()        # torchvision Resize on a tensor (inference_test_bench.py:465)
@@ -45,10 +52,23 @@ class SwapRunner:
         kw["inpaint_image"], kw["inpaint_mask"] = z_inpaint, m64
         shape = [opt.C, opt.H // opt.f, opt.W // opt.f]
         x_T = None if start_code is None else start_code[:B]
+        if x_T is None and self.dump_dir:
+            x_T = torch.randn([B] + shape, device=dev)                                 # the draw the sampler makes itself otherwise
         samples, inter = self.sampler.sample(S=opt.ddim_steps, conditioning=c, batch_size=B, shape=shape, verbose=False,
                                              unconditional_guidance_scale=opt.scale, unconditional_conditioning=uc, eta=opt.ddim_eta,
                                              x_T=x_T, log_every_t=log_every_t, test_model_kwargs=kw)
-        return self.decode01(samples), inter
+        x_img = self.decode01(samples)
+        if self.dump_dir:
+            import os
+            import numpy as np
+            os.makedirs(self.dump_dir, exist_ok=True)
+            f = lambda t: t.detach().float().cpu().numpy()
+            np.savez(os.path.join(self.dump_dir, f"batch_{self.n_dumped:04d}.npz"), test_batch=f(test_batch), ref_imgs=f(ref_imgs),
+                     inpaint_image=f(inpaint_image), inpaint_mask=f(inpaint_mask), post_noise=f(post_noise), x_T=f(x_T), c=f(c),
+                     z_inpaint=f(z_inpaint), mask64=f(m64), samples=f(samples), x_img=f(x_img),
+                     uc=f(uc) if uc is not None else np.zeros(0, np.float32))
+            self.n_dumped += 1
+        return x_img, inter
 
     @torch.no_grad()
     def decode01(self, latents):

@@ -66,6 +66,7 @@ def build_parser():
     p.add_argument("--save_vis", action="store_true")
     p.add_argument("--seg12", default=True, action="store_true")
     # additions (not in the reference)
+    p.add_argument("--dump_tensors", type=str, default=None, help="directory for per-batch .npz dumps of the tensors fed to / produced by the engines (tests)")
     p.add_argument("--clip_vision_config", type=str, default=None, help="JSON dict overriding the CLIP ViT dims (tests)")
     p.add_argument("--num_workers", type=int, default=4)
     return p

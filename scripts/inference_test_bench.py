@@ -64,6 +64,7 @@ def build_parser():
     p.add_argument("--precision", type=str, choices=["full", "autocast", "bf16", "fp8"], default="full")
     # additions (not in the reference)
     p.add_argument("--n_items", type=int, default=8, help="number of synthetic pairs (--dataset synthetic)")
+    p.add_argument("--dump_tensors", type=str, default=None, help="directory for per-batch .npz dumps of the tensors fed to / produced by the engines (tests)")
     p.add_argument("--clip_vision_config", type=str, default=None, help="JSON dict overriding the CLIP ViT dims (tests)")
     p.add_argument("--num_workers", type=int, default=4, help="DataLoader workers of the folder readers (reference: 4)")
     p.add_argument("--gpu_prep", action="store_true", help="folder readers hand over uint8 arrays; normalise / mask / resize run on the GPU")

@@ -134,6 +134,55 @@ def test_whole_chain_vs_reference_golden(golden_dir):
     assert d.max() <= 1 and (d[:, :2 + 3 * (H + 2)] == 0).all()                # everything left of the result panel is byte-exact
 
 
+SMALL_UNET = dict(in_channels=9, model_channels=64, out_channels=4, num_res_blocks=2, attention_resolutions=(4, 2, 1), channel_mult=(1, 2, 4, 4),
+                  num_heads=8, context_dim=768)
+SMALL_VAE = dict(ch=32, ch_mult=(1, 2, 4, 4), num_res_blocks=2, in_channels=3, out_ch=3, z_channels=4, embed_dim=4, double_z=True,
+                 attn_resolutions=(), resolution=256)
+
+
+def _oracle_chain_check(dump_npz, png_path, S, scale, rows=(0,)):
+    """The CPU oracle chain (oracle/: conditioning_with_feat -> VAE encode + posterior sample -> mask64 -> CFG DDIM -> fp32 decode ->
+    uint8) on exactly the tensors a caller's batch fed the engines (SwapRunner --dump_tensors), with the CLI's `--ckpt none` seeds;
+    checks the engines' intermediates and the PNG the caller wrote (<= 1 LSB)."""
+    from PIL import Image
+    from oracle import ddim as oddim, encoders as oenc, unet as ounet, vae as ovae
+    d = np.load(dump_npz)
+    ucfg, vcfg = P.UNetConfig(**SMALL_UNET), P.VAEConfig(**SMALL_VAE)
+    ccfg = P.CLIPVisionConfig(**dict(SMALL_CLIP, patch=14, image=224, proj=768, mapper_layers=5))
+    usd = P.seeded_state_dict(P.unet_param_specs(ucfg), 1234)
+    vsd = P.seeded_state_dict(P.vae_param_specs(vcfg), 55)
+    csd = P.seeded_state_dict(P.clip_param_specs(ccfg), 88)
+    asd = P.seeded_state_dict(P.arcface_param_specs(), 77)
+    heads = P.seeded_state_dict(P.cond_head_specs(), 9)
+    r = list(rows)
+    T = lambda k: torch.from_numpy(d[k][r])
+    target, ref, inp_img, inp_mask, x_T, noise = T("test_batch"), T("ref_imgs"), T("inpaint_image"), T("inpaint_mask"), T("x_T"), T("post_noise")
+    B = len(r)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    with torch.no_grad():
+        c = oenc.conditioning_with_feat(heads, csd, ccfg, asd, P.arcface_units(), ref, torch.zeros(B, 136), target)      # no dlib: zeros branch
+        assert maxerr(c, d["c"][r]) < 5e-5, maxerr(c, d["c"][r])
+        mean, logvar = ovae.encode_moments(vsd, vcfg, inp_img)
+        z_inp = ovae.first_stage_encoding(mean, logvar, noise)
+        assert maxerr(z_inp, d["z_inpaint"][r]) < 1e-4, maxerr(z_inp, d["z_inpaint"][r])
+        m64 = oenc.mask64(inp_mask)
+        assert maxerr(m64, d["mask64"][r]) == 0
+        uc = heads["learnable_vector"].repeat(B, 1, 1)
+        plan = P.unet_plan(ucfg)
+        samples, _ = oddim.sample(lambda x, t, cc: ounet.unet_forward(usd, plan, x, t, cc, ucfg.model_channels), S, x_T, c, uc, z_inp, m64, scale)
+        assert maxerr(samples, d["samples"][r]) < 5e-4, maxerr(samples, d["samples"][r])
+        x_dec = ovae.decode_first_stage(vsd, vcfg, samples)
+    img01 = torch.clamp((x_dec + 1.0) / 2.0, 0.0, 1.0)
+    assert maxerr(img01, d["x_img"][r]) < 1e-3, maxerr(img01, d["x_img"][r])          # the north-star pixel bound
+    u8 = oenc.to_uint8_image(x_dec)[0]
+    png = np.asarray(Image.open(png_path))
+    if png.shape != u8.shape:           # the video caller stores its crops at 1024^2 (PIL bilinear of the 512^2 result): compare at 512^2
+        return u8
+    diff = np.abs(png.astype(int) - u8.astype(int))
+    assert diff.max() <= 1 and (diff != 0).mean() < 5e-3, (diff.max(), (diff != 0).mean())
+    return u8
+
+
 def test_cli_synthetic_run(tmp_path):
     """scripts/inference_test_bench.py end to end on seeded weights: writes the reference's output tree."""
     import json
@@ -184,16 +233,23 @@ def test_cli_swap_selected(tmp_path):
     _prepared_swap_tree(base, n_tar=3, n_src=2)
     cmd = [sys.executable, os.path.join(ROOT, "scripts", "inference_swap_selected.py"), "--outdir", str(out), "--Base_dir", base, "--config",
            os.path.join(ROOT, "tests", "configs", "reface_small.yaml"), "--ckpt", "none", "--n_samples", "2", "--ddim_steps", "4", "--scale", "3.5",
-           "--H", "512", "--W", "512", "--precision", "bf16", "--num_workers", "0", "--clip_vision_config", json.dumps(SMALL_CLIP)]
+           "--H", "512", "--W", "512", "--precision", "full", "--num_workers", "0", "--clip_vision_config", json.dumps(SMALL_CLIP),
+           "--dump_tensors", str(tmp_path / "dump")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     for s in ("0", "1"):
         assert sorted(os.listdir(out / "results" / s)) == [f"{i:012d}.png" for i in range(3)]
         assert len(os.listdir(out / "grid" / s)) == 3 and len(os.listdir(out / s)) == 12
     assert any(f.startswith("_intermediate_") for f in os.listdir(out / "model_outputs"))
-    from PIL import Image
-    im = np.asarray(Image.open(out / "results" / "1" / "000000000002.png"))
-    assert im.shape == (512, 512, 3) and im.std() > 1.0
+    # caller-specific arithmetic against the oracle: batches are (source 0: targets 0-1, target 2), (source 1: targets 0-1, target 2);
+    # the LAST batch is source 1 on target 2 -- ONE source repeated over the batch (inference_swap_selected.py:649-653), its own folder
+    dumps = sorted(os.listdir(tmp_path / "dump"))
+    assert dumps == [f"batch_{i:04d}.npz" for i in range(4)], dumps
+    d0, d2 = np.load(tmp_path / "dump" / dumps[0]), np.load(tmp_path / "dump" / dumps[2])
+    assert np.array_equal(d0["ref_imgs"][0], d0["ref_imgs"][1]) and not np.array_equal(d0["ref_imgs"][0], d2["ref_imgs"][0])     # one source per pass
+    assert np.array_equal(d0["test_batch"], d2["test_batch"])                                                                       # every source sees every target
+    _oracle_chain_check(tmp_path / "dump" / dumps[3], out / "results" / "1" / "000000000002.png", S=4, scale=3.5)
+    _oracle_chain_check(tmp_path / "dump" / dumps[0], out / "results" / "0" / "000000000000.png", S=4, scale=3.5)
     # without the prepared tree the CLI says what is out of scope instead of failing somewhere inside
     r2 = subprocess.run(cmd[:4] + ["--Base_dir", str(tmp_path / "nothing")] + cmd[6:], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r2.returncode != 0 and "stage 1" in (r2.stderr + r2.stdout)
@@ -215,14 +271,24 @@ def test_cli_swap_video(tmp_path):
     shutil.copy(base / "source_mask" / "0.png", out / "temp_results" / "me.jpg")          # (the reference saves the label map under the source's own file name)
     cmd = [sys.executable, os.path.join(ROOT, "scripts", "inference_swap_video.py"), "--outdir", str(out), "--Base_dir", str(base), "--target_video",
            "videos/clip.mp4", "--src_image", "faces/me.jpg", "--config", os.path.join(ROOT, "tests", "configs", "reface_small.yaml"), "--ckpt", "none",
-           "--n_samples", "2", "--ddim_steps", "4", "--scale", "3.5", "--precision", "bf16", "--num_workers", "0", "--clip_vision_config",
-           json.dumps(SMALL_CLIP)]
+           "--n_samples", "2", "--ddim_steps", "4", "--scale", "3.5", "--precision", "full", "--num_workers", "0", "--clip_vision_config",
+           json.dumps(SMALL_CLIP), "--dump_tensors", str(tmp_path / "dump")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert sorted(os.listdir(out / "model_outputs")) == [f"{i:012d}.png" for i in range(4)]          # 5 frames, batches of 2, drop_last
     from PIL import Image
     im = np.asarray(Image.open(out / "model_outputs" / "000000000003.png"))
-    assert im.shape == (1024, 1024, 3) and im.std() > 1.0
+    assert im.shape == (1024, 1024, 3)
+    # this caller's quirks against the oracle chain: ONE start latent for every frame of every batch (inference_swap_video.py), whole
+    # batches only; the 1024^2 crop is the PIL-bilinear enlargement of the 512^2 result the oracle reproduces
+    dumps = sorted(os.listdir(tmp_path / "dump"))
+    assert len(dumps) == 2
+    d0, d1 = np.load(tmp_path / "dump" / dumps[0]), np.load(tmp_path / "dump" / dumps[1])
+    assert np.array_equal(d0["x_T"][0], d0["x_T"][1]) and np.array_equal(d0["x_T"], d1["x_T"])
+    u8 = _oracle_chain_check(tmp_path / "dump" / dumps[1], out / "model_outputs" / "000000000003.png", S=4, scale=3.5, rows=(1,))
+    big = np.asarray(Image.fromarray(u8).resize((1024, 1024), Image.BILINEAR))
+    diff = np.abs(big.astype(int) - im.astype(int))
+    assert diff.max() <= 2 and (diff != 0).mean() < 2e-2, (diff.max(), (diff != 0).mean())
     r2 = subprocess.run(cmd[:6] + ["--target_video", "videos/other.mp4"] + cmd[8:], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r2.returncode != 0 and "stage 1" in (r2.stderr + r2.stdout)
 
@@ -257,3 +323,23 @@ def test_device_prep_matches_host(tmp_path):
             # the source face goes through a 512 -> 224 bilinear resize of its mask (non-integer ratio): last-bit differences of the
             # interpolation weights against torch's CPU kernel, <= 1 fp32 ulp of the O(1) products
             assert (out["ref_imgs"][i].cpu() - hk["ref_imgs"]).abs().max().item() < 2e-6
+
+
+def test_bench_two_ranks_share_gpu():
+    """The N > 1 path of bench.py end to end on one GPU: `--gpus 2 --share-gpu` spawns torch.distributed.run as a child (gloo, both ranks
+    on cuda:0), rank 0 generates the weights and broadcasts them flat, the ranks shard the pairs, time = max over ranks.  Checks the
+    line the driver parses: n_gpus, a finite whole-job value, and that rank 1 ended up with rank 0's weights."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-roofline", "--no-parity", "--no-conditioning", "--ddim-steps", "10", "--batch", "2"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["value"] == d["value"] and d["ms_per_step"] > 0
+    assert d["weights_identical_on_all_ranks"] is True and len(d["weights_checksum_per_rank"]) == 2, d.get("weights_checksum_per_rank")
