@@ -95,6 +95,14 @@ typedef struct rf_conv_gemm_desc {
     /* Replaces the same nn.Conv2d / nn.Linear weights (openaimodel.py:204,230,241; attention.py:40,60,159-170), half the bytes. */
     int32_t w_dtype;
     const float* wscale;  /* [N] fp32, powers of two */
+    /* fp8 x fp8 path (the fp8 matrix pipe, v_mfma_scale_f32_32x32x64_f8f6f4): dtype = w_dtype = RF_FP8_E4M3.  src0 holds e4m3fn activation bytes */
+    /* (ld0 / C0 / K in bytes = elements) and ascale one E8M0 byte (scale 2^(e - 127)) per (pixel, 32-channel block) with pixel pitch as_ld (a */
+    /* multiple of 4, pad bytes = a valid code), both written by rf_quantize_fp8_act or by rf_groupnorm_apply / rf_layernorm with out_dtype = */
+    /* RF_FP8_E4M3; W as in the w_dtype path with every filter tap's channel run zero-padded to a multiple of 128 (K counts the padded run; a */
+    /* k x k window needs C0 % 128 == 0 -- a 1 x 1 / linear layer may over-read up to 127 bytes of the next pixel against zero weights). */
+    /* out_dtype RF_BF16.  Replaces the same nn.Conv2d / nn.Linear calls with both operands in fp8 (BASELINE configs[4]). */
+    const void* ascale;
+    int32_t as_ld;
 } rf_conv_gemm_desc;
 
 int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream);
@@ -149,6 +157,18 @@ int rf_layernorm(int dtype, const void* x, int M, int C, int ldx, const float* g
 int rf_attention(int dtype, const void* q, const void* k, const void* v, void* out,
                  int B, int heads, int d, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo,
                  int64_t sq, int64_t sk, int64_t sv, int64_t so, float scale, void* stream);
+
+/* fp8 activation producers of the fp8 x fp8 GEMM path (rf_conv_gemm_desc.ascale): bf16 in -> e4m3fn bytes q [rows][ldq] + one E8M0 scale byte per
+ * (row, 32-channel block), scale [rows][lds]; the scale is the smallest power of two that brings the block's |max| under 448, values are
+ * rounded to nearest even.  Bytes of q beyond C and scale bytes beyond C / 32 are NOT written (the caller keeps them 0 / 127).
+ *   rf_quantize_fp8_act     : plain quantisation of x [M, C]
+ *   rf_groupnorm_apply_fp8  : rf_groupnorm_apply (nn.GroupNorm + SiLU, util.py:214-216) with this output form
+ *   rf_layernorm_fp8        : rf_layernorm (nn.LayerNorm, attention.py:231-233) with this output form */
+int rf_quantize_fp8_act(const void* x, int64_t M, int C, int ldx, void* q, int ldq, void* scale, int lds, void* stream);
+int rf_groupnorm_apply_fp8(const void* x, int B, int HW, int C, int ldx, int nchunks, const double* partial, const float* gamma,
+                           const float* beta, float eps, int silu, void* q, int ldq, void* scale, int lds, void* stream);
+int rf_layernorm_fp8(const void* x, int M, int C, int ldx, const float* gamma, const float* beta, float eps, void* q, int ldq, void* scale,
+                     int lds, void* stream);
 
 /* Row softmax over the last dim of [rows, cols] fp32, in place allowed (VAE AttnBlock, model.py:188). */
 int rf_softmax_rows(float* x, int rows, int cols, int ld, void* stream);

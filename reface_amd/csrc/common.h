@@ -15,6 +15,7 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 
 typedef uint16_t bf16_t;   // storage type of bf16 values
+typedef uint8_t fp8_t;     // storage type of OCP e4m3fn values (fp8 activations / weights of the MX-scaled MFMA path)
 
 namespace rf {
 
@@ -78,11 +79,48 @@ __device__ __forceinline__ void split4_bf16(const float* f, u32x2_t& hi, u32x2_t
     lo[1] = pack_bf2(r2, r3);
 }
 
+// ---- fp8 (OCP e4m3fn) activation quantisation with one E8M0 scale per 32-channel block (the A operand of the MX-scaled MFMA path)
+// max over the 4 lanes of a quad (a 32-channel block = 4 consecutive lanes holding 8 channels each)
+__device__ __forceinline__ float quad_max(float v) {
+    v = fmaxf(v, as_f32((uint32_t)__builtin_amdgcn_mov_dpp((int)as_u32(v), 0xB1, 0xF, 0xF, true)));      // quad_perm [1,0,3,2]
+    v = fmaxf(v, as_f32((uint32_t)__builtin_amdgcn_mov_dpp((int)as_u32(v), 0x4E, 0xF, 0xF, true)));      // quad_perm [2,3,0,1]
+    return v;
+}
+// E8M0 code c of the smallest power of two 2^(c - 127) with amax / 2^(c - 127) <= 448 = 1.75 * 2^8 (e4m3fn's largest finite value)
+__device__ __forceinline__ int e8m0_for_amax(float amax) {
+    const uint32_t b = as_u32(amax);
+    int c = (int)((b >> 23) & 0xffu) - 8 + ((b & 0x7fffffu) > 0x600000u ? 1 : 0);
+    return c < 0 ? 0 : (c > 253 ? 253 : c);
+}
+// 8 floats -> 8 e4m3fn bytes of x * 2^(127 - code) (exact scaling, round-to-nearest-even, saturating)
+__device__ __forceinline__ u32x2_t quant8_fp8(const float* f, int code) {
+    const float inv = as_f32((uint32_t)(254 - code) << 23);
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, hi, true);
+    return u32x2_t{(uint32_t)lo, (uint32_t)hi};
+}
+// one lane's 8 consecutive channels of a 32-channel block (4 consecutive lanes): block amax -> scale code -> 8 bytes; lane 0 of the quad
+// also stores the code
+__device__ __forceinline__ void quant_block8(const float* f, fp8_t* qdst, fp8_t* sdst, bool quad_leader) {
+    float m = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(f[e]));
+    const int code = e8m0_for_amax(quad_max(m));
+    *(u32x2_t*)qdst = quant8_fp8(f, code);
+    if (quad_leader) *sdst = (fp8_t)code;
+}
+
 template <typename T> struct elem;
 template <> struct elem<float> {
     static constexpr int VEC = 4;   // elements per 16-byte vector
     __device__ static __forceinline__ float load(const float* p) { return *p; }
     __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct elem<fp8_t> {
+    static constexpr int VEC = 16;
 };
 template <> struct elem<bf16_t> {
     static constexpr int VEC = 8;

@@ -54,6 +54,9 @@ struct GemmParams {
     int epi2_ok;     // host only: operand alignment / feature set allow the direct (register -> global) epilogue
     int dbg;         // RF_GEMM_DBG (timing experiments only): bit 0 = skip the epilogue, bit 1 = skip the main loop
     const float* wscale;   // W8 kernels: per-output-channel power-of-two scale of the fp8 (e4m3fn) weights
+    const void* ascale;    // A8 kernels (fp8 activations): E8M0 scale bytes, one per (pixel, 32-channel block), pixel pitch as_ld bytes (a multiple of 4)
+    int as_ld;
+    unsigned as_bytes;
     int x3;          // split-bf16 operands (RF_BF16X3): K counts VIRTUAL tiles, three per real 64-element K tile -- (A hi, W hi), (A hi, W lo),
                      // (A lo, W hi); W rows hold them in that order, the A lo plane lies lo_off bytes behind the hi plane of the same pixel
     int lo_off;
@@ -77,6 +80,18 @@ template <> struct MmaFrag<bf16_t> {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
     }
 };
+template <> struct MmaFrag<fp8_t> {      // (the fp8 x fp8 path has its own main loop with block scales; this keeps the shared lambdas well-formed)
+    __device__ static __forceinline__ void mma(f32x16_t&, const u32x4_t&, const u32x4_t&) {}
+};
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+// acc += (A row block, 64 K) x (B row block, 64 K)^T on the MX-scaled fp8 MFMA: each lane supplies 32 bytes per operand -- 16-byte slots h and
+// 2 + h of the 64-byte K slice (h = lane >> 5) -- and ONE E8M0 scale per operand in byte 0 of sa / sb, which the hardware applies to the
+// 32 consecutive K elements [32 h, 32 h + 32) of that lane's row (tools/mx_probe2.py pins this mapping on the chip)
+__device__ __forceinline__ void mma_mx8(f32x16_t& acc, const u32x4_t& a0, const u32x4_t& a1, int sa, const u32x4_t& b0, const u32x4_t& b1, int sb) {
+    const v8i_t a = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+    const v8i_t b = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, sa, 0, sb);
+}
 template <> struct MmaFrag<float> {
     __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
 #pragma unroll
@@ -120,6 +135,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
     static_assert(EPI == 0 || GLDS, "the direct / packed epilogues are built on the direct-to-LDS main loop");
     static_assert(EPI != 2 || sizeof(TO) == 2, "the packed staged epilogue writes bf16");
     static_assert(!W8 || (GLDS && sizeof(T) == 2), "fp8 weights: bf16 activations on the direct-to-LDS main loop");
+    // A8: fp8 (e4m3fn) activations with one E8M0 scale per 32 channels x fp8 weights with one power-of-two scale per output channel on
+    // v_mfma_scale_f32_32x32x64_f8f6f4: a K tile (128-byte rows) holds 128 K elements, two k-steps of 64
+    constexpr bool A8 = std::is_same<T, fp8_t>::value;
+    static_assert(!A8 || (GLDS && !W8 && NST == 2), "fp8 activations: direct-to-LDS main loop, two stages");
     constexpr int NT = WM * WN * 64;
     constexpr int BM = 32 * TM * WM;
     constexpr int BN = 32 * TN * WN;
@@ -133,6 +152,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ldsA = smem;                       // [2][BM][128]
     char* const ldsB = smem + NST * BM * 128;      // [NST][BN][128]
+    char* const ldsS = smem + NST * (BM + BN) * 128;      // A8: [2][8 waves][64 rows] scale dwords (4 E8M0 bytes = the 4 blocks of a K tile)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -304,12 +324,29 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, p.w_bytes, 0x00020000);
         constexpr int OOB = 0x7fffffff;
         constexpr int NP = AV + BV;
-        static_assert(NP <= 16, "piece table too small");
+        static_assert(NP <= 20, "piece table too small");
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         const int lane_k = slot * VEC * (int)sizeof(T);       // byte offset of this lane's 16-byte K slot inside a K tile
-        int offs[16];        // [0, AV): A pieces, [AV, NP): B pieces (fixed size: see the note on hipcc at `rowd`)
+        int offs[20];        // [0, AV): A pieces, [AV, NP): B pieces (fixed size: see the note on hipcc at `rowd`)
         unsigned rowd[8];    // CONV: packed (sample << 20 | oy << 10 | ox) of this thread's A rows, ~0u = row beyond M
         static_assert(AV <= 8, "row table too small");
+        // A8: lane l of wave w also fetches the scale dword of tile row 64 w + l (one 4-byte piece per wave and K tile)
+        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(A8 ? p.ascale : (const void*)src0), 0, A8 ? p.as_bytes : 0u, 0x00020000);
+        unsigned srowd = ~0u;
+        int soffs = OOB;
+        if constexpr (A8) {
+            static_assert(BM <= NT, "one scale row per thread");
+            const int srow = wave_u * 64 + lane, m = m0 + srow;
+            const bool sv = srow < BM && m < p.M;
+            if (CONV) {
+                const int hw = p.Hout * p.Wout;
+                const int b = m / hw, rem = m - b * hw;
+                const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+                srowd = sv ? ((unsigned)b << 20 | (unsigned)oy << 10 | (unsigned)ox) : ~0u;
+            } else {
+                soffs = sv ? m * p.as_ld : OOB;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < BV; ++j) {
             const int n = n0 + r0 + j * RPP;
@@ -348,6 +385,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 const bool ok = d != ~0u && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
                 if (p.ups) { iy >>= 1; ix >>= 1; }
                 offs[i] = ok ? (((int)(d >> 20) * p.Hin + iy) * p.Win + ix) * p.ld0 * (int)sizeof(T) + lane_k : OOB;
+            }
+            if constexpr (A8) {
+                const unsigned d = srowd;
+                int iy = (int)((d >> 10) & 1023u) * p.stride - p.pad_t + ty;
+                int ix = (int)(d & 1023u) * p.stride - p.pad_l + tx;
+                const bool ok = d != ~0u && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+                if (p.ups) { iy >>= 1; ix >>= 1; }
+                soffs = ok ? (((int)(d >> 20) * p.Hin + iy) * p.Win + ix) * p.as_ld : OOB;
             }
         };
         // uniform K state of the NEXT tile to issue: absolute tile index, and for convs (tap, channel chunk inside the tap)
@@ -401,7 +446,115 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(b + (q - AV) * (RPP * 128)), 16, offs[q], soB, 0, 0);
                 }
             }
+            if constexpr (A8) {          // every call issues the tile's scale piece (q0 is 0 in every call): NP + 1 pieces per wave and tile
+                char* const sdst = ldsS + buf * 2048 + wave_u * 256;
+                const int soS = (CONV ? ic : ia) * 4;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) void*)sdst, 4, soffs, soS, 0, 0);
+            }
         };
+        if constexpr (A8) {
+            // ---- fp8 x fp8 main loop: two k-steps of 64 per K tile, A fragments double-buffered, W fragments rotated in place (column j of
+            // the next k-step is fetched right behind column j's MFMAs), one barrier per tile -- the structure of the bf16 loop below at twice
+            // the K per tile and per MFMA (64 matrix-pipe cycles each)
+            using std::integral_constant;
+            constexpr int JS8 = TN > 2 ? 2 : 1;
+            u32x4_t fa8[2][TM][2], fb8[TN][2];
+            int sa8[2][TM], wsc[TN];
+            const int lrow_ = lane & 31, lhalf_ = lane >> 5;
+            const int frag_sw8 = (lrow_ >> 1) & 7;
+            const int brow8 = EPI == 1 ? (16 * ((lrow_ >> 2) & 1) + 4 * (lrow_ >> 3) + (lrow_ & 3)) : lrow_;
+            const int frag_swb8 = (brow8 >> 1) & 7;
+            int fk8[2], fkb8[2], ssh[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                fk8[kk] = ((4 * kk + lhalf_) ^ frag_sw8) << 4;           // 16-byte slot 4 kk + h; the lane's second slot (4 kk + 2 + h) is this ^ 32
+                fkb8[kk] = ((4 * kk + lhalf_) ^ frag_swb8) << 4;
+                ssh[kk] = (2 * kk + lhalf_) * 8;                        // the lane's 32-channel block inside the K tile: byte 2 kk + h of the scale dword
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn * TN + j) * 32 + brow8;
+                wsc[j] = n < p.N ? (int)((as_u32(p.wscale[n]) >> 23) & 0xffu) : 127;          // power-of-two fp32 scale -> its E8M0 code
+            }
+            const char* curA = ldsA + (wm * TM) * 4096 + lrow_ * 128;
+            const char* curB = ldsB + (wn * TN) * 4096 + brow8 * 128;
+            const char* curS = ldsS + ((wm * TM) * 32 + lrow_) * 4;
+            const char* othA = curA + BM * 128;
+            const char* othB = curB + BN * 128;
+            const char* othS = curS + 2048;
+            auto ld_a = [&](int buf, const char* bA, const char* bS, int kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    fa8[buf][i][0] = *(const u32x4_t*)(bA + i * 4096 + fk8[kk]);
+                    fa8[buf][i][1] = *(const u32x4_t*)(bA + i * 4096 + (fk8[kk] ^ 32));
+                    sa8[buf][i] = (int)((*(const uint32_t*)(bS + i * 128) >> ssh[kk]) & 0xffu);
+                }
+            };
+            auto ld_b = [&](int j, const char* bB, int kk) {
+                fb8[j][0] = *(const u32x4_t*)(bB + j * 4096 + fkb8[kk]);
+                fb8[j][1] = *(const u32x4_t*)(bB + j * 4096 + (fkb8[kk] ^ 32));
+            };
+            auto mma_col = [&](int buf, int j) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if constexpr (EPI == 1) mma_mx8(acc[i][j], fb8[j][0], fb8[j][1], wsc[j], fa8[buf][i][0], fa8[buf][i][1], sa8[buf][i]);
+                    else mma_mx8(acc[i][j], fa8[buf][i][0], fa8[buf][i][1], sa8[buf][i], fb8[j][0], fb8[j][1], wsc[j]);
+                }
+            };
+            auto phase8 = [&](auto KK, int stage, bool more) {
+                constexpr int kk = decltype(KK)::value;
+                constexpr int cur = kk, nx = kk ^ 1, nkk = kk ^ 1;
+                const char* const nA = kk == 0 ? curA : othA;
+                const char* const nB = kk == 0 ? curB : othB;
+                const char* const nS = kk == 0 ? curS : othS;
+#pragma unroll
+                for (int j = 0; j < JS8; ++j) mma_col(cur, j);
+                if (kk == 1) {
+                    // own pieces of the next tile have landed and every fragment of this tile is in registers; past the barrier that holds
+                    // for all waves: this stage may be overwritten (tile kt+2) and the other stage may be read
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                ld_a(nx, nA, nS, nkk);
+#pragma unroll
+                for (int j = 0; j < JS8; ++j) ld_b(j, nB, nkk);
+                if (kk == 1 && more) issue_pieces(stage, 0, NP);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = JS8; j < TN; ++j) {
+                    mma_col(cur, j);
+                    ld_b(j, nB, nkk);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (nk > 0) {
+                issue_pieces(0, 0, AV);               // (its W pieces are already in flight; + the scale piece)
+                if (nk > 1) {
+                    next_tile();
+                    issue_pieces(1, 0, NP);
+                    if (nk > 2) next_tile();
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP + 1) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                ld_a(0, curA, curS, 0);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) ld_b(j, curB, 0);
+            }
+            for (int kt = 0; kt < nk; ++kt) {
+                const int stage = kt & 1;
+                const bool more = kt + 2 < nk;
+                phase8(integral_constant<int, 0>{}, stage, more);
+                phase8(integral_constant<int, 1>{}, stage, more);
+                if (kt + 3 < nk) next_tile();
+                const char* t = curA; curA = othA; othA = t;
+                t = curB; curB = othB; othB = t;
+                t = curS; curS = othS; othS = t;
+            }
+            __syncthreads();
+        } else {
         // Fragment pipeline: the ds_reads of k-step kk+1 are issued while the MFMAs of k-step kk run, so the matrix pipe does not
         // wait on LDS latency (all waves of a block are phase-locked by the per-tile barrier, nobody else would cover it).
         // Small wave tiles keep two full fragment sets; the 2x5 wave tile has no registers for that and rotates its B fragments
@@ -563,6 +716,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         }
         }
         __syncthreads();
+        }       // (!A8)
     } else {
         load_tiles();
         store_tiles(0);
@@ -1310,10 +1464,11 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int NST = 2;            // LDS stages of the direct-to-LDS main loop (3 stages of the big tiles at 1 block/CU measured slower)
     // The 4-wave 128x160 tile also exists with a ring of 4 stages (147 KB: one block per CU), for grids of at most one block per CU
-    constexpr bool DEEP_OK = WM * WN == 4 && TM * TN == 5 && !W8;
+    constexpr bool DEEP_OK = WM * WN == 4 && TM * TN == 5 && !W8 && !std::is_same<T, fp8_t>::value;
     constexpr int NSTD = DEEP_OK ? 4 : 2;
     constexpr int NCH = (BM * BN * 4 > 96 * 1024) ? WM : 1;
-    constexpr int smem_ml = NST * (BM + BN) * 128, smem_ep = (BM / NCH) * BN * 4;
+    constexpr bool A8 = std::is_same<T, fp8_t>::value;
+    constexpr int smem_ml = NST * (BM + BN) * 128 + (A8 ? 4096 : 0), smem_ep = (BM / NCH) * BN * 4;
     constexpr int smem = smem_ml > smem_ep ? smem_ml : smem_ep;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
@@ -1330,12 +1485,12 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
         p.mfast = mf_env >= 0 ? mf_env : (cost_m < 0.8 * cost_n ? 1 : 0);
     }
     // split-K for launches that cannot fill the chip: each z-slice owns a K range, partial sums go through the caller's workspace
-    p.splitk = pick_splitk(d, p, (long long)p.tiles_m * p.tiles_n, sizeof(T) == 2 ? 64 : 32);
+    p.splitk = pick_splitk(d, p, (long long)p.tiles_m * p.tiles_n, 128 / (int)sizeof(T));
     if (p.splitk > 1) p.ws = (float*)d->workspace;
     // statistics tiling: the GEMM tile, or the reduce pass's tile when split-K moves the epilogue there
     const int skr = sk_rows_for(p.M, p.N);
     const int st_rows = p.splitk > 1 ? skr : BM, st_cols = p.splitk > 1 ? SK_COLS : BN;
-    if (W8) RF_CHECK(p.glds, "rf_conv_gemm: fp8 weights need the direct-to-LDS main loop (one source, K and channel count multiples of 64)");
+    if (W8 || A8) RF_CHECK(p.glds, "rf_conv_gemm: fp8 operands need the direct-to-LDS main loop (one source, K and channel count multiples of the K tile)");
     if (p.plan) { p.plan[0] = st_rows; p.plan[1] = st_cols; p.plan[2] = p.splitk; return 0; }
     if (p.gn_rows > 0) {
         RF_CHECK(p.gn_rows % st_rows == 0 && p.M % p.gn_rows == 0 && d->batch == 1 && d->act != RF_ACT_GEGLU,
@@ -1355,8 +1510,8 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     //          GEGLU, fp32 output with statistics, unaligned shapes).
     // RF_EPI=0 forces EPI 0, RF_EPI=1 / 2 allow only that fast form (A/B runs).
     static const int epi_env = tune_env("RF_EPI", -1);
-    constexpr bool PACKED_OK = sizeof(TO) == 2;
-    constexpr bool DIRECT_OK = (WM * WN == 8) || (TM * TN == 5);
+    constexpr bool PACKED_OK = sizeof(TO) == 2 && !A8;
+    constexpr bool DIRECT_OK = (WM * WN == 8) || (TM * TN == 5) || (TM * TN >= 16);
     const bool ep_common = p.glds && p.epi2_ok && p.splitk == 1 && (!p.rowvec || p.rows_per_sample % BM == 0) &&
                            (d->act == RF_ACT_NONE || (d->act == RF_ACT_GEGLU && TN % 2 == 0));
     static const int gn_direct = tune_env("RF_EPI_GN", 1);      // 0: fused statistics keep EPI 0
@@ -1385,6 +1540,10 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     static const int deep_env = tune_env("RF_GEMM_DEEP", 0);        // largest grid (blocks) that takes the ring; off by default: 4096x1280x5120 68.3 -> 66.7 us alone, GEMM family 12.63 -> 12.69 ms in situ
     constexpr int smem_deep = NSTD * (BM + BN) * 128 > smem ? NSTD * (BM + BN) * 128 : smem;
     const bool deep = DEEP_OK && p.glds && !packed && !p.x3 && (long long)grid.x * grid.y * grid.z <= deep_env;
+    if constexpr (A8) {            // fp8 activations: direct-to-LDS kernels only, staged or direct epilogue
+        if (conv) { if (esel == 1) RF_LAUNCH_VARIANT(true, true, 1) else RF_LAUNCH_VARIANT(true, true, 0) }
+        else { if (esel == 1) RF_LAUNCH_VARIANT(false, true, 1) else RF_LAUNCH_VARIANT(false, true, 0) }
+    } else
     if (conv && p.glds) {
         if (esel == 2) RF_LAUNCH_VARIANT(true, true, 2)
         else if (esel == 1) RF_LAUNCH_VARIANT(true, true, 1)
@@ -1408,8 +1567,32 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     return 0;
 }
 
+#ifdef RF_EXPERIMENT
+template <typename T, typename TO, int TN_, bool W8>
+static int launch_wide(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipStream_t st) {
+    if constexpr (!W8 && sizeof(T) == 2 && sizeof(TO) == 2) return launch_cfg<T, TO, 2, 2, 4, TN_, false>(d, p, conv, st);
+    else { RF_CHECK(false, "rf_conv_gemm: the one-wave-per-SIMD tiles are bf16 -> bf16 experiments"); }
+}
+#endif
+
 template <typename T, typename TO, bool W8 = false>
 static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipStream_t st) {
+    if constexpr (std::is_same<T, fp8_t>::value) {
+        // fp8 x fp8: 32-byte fragments (8 registers per 32-row block and k-step) leave no room for the 64-row wave tiles at two waves per
+        // SIMD (they spill 260-940 bytes per lane): 128 x 320 / 128 x 256 blocks of 8 waves (wave tile 32 x 160 / 32 x 128), else the 4-wave tiles
+        const int N_ = p.N;
+        const bool g = d->act == RF_ACT_GEGLU;
+        const bool n320 = !g && N_ % 320 == 0, n256 = N_ % 256 == 0 && !n320;
+        const long long mt128 = (p.M + 127) / 128;
+        const long long nt = n320 ? N_ / 320 : (n256 ? N_ / 256 : 0);
+        if (nt > 0 && mt128 * nt * pick_splitk(d, p, mt128 * nt, 128) >= 160)
+            return n320 ? launch_cfg<T, TO, 4, 2, 1, 5, false>(d, p, conv, st) : launch_cfg<T, TO, 4, 2, 1, 4, false>(d, p, conv, st);
+        if (g) return launch_cfg<T, TO, 2, 2, 2, 2, false>(d, p, conv, st);
+        if (N_ <= 64) return launch_cfg<T, TO, 4, 1, 1, 2, false>(d, p, conv, st);
+        const int pad128 = ((N_ + 127) / 128) * 128, pad160 = ((N_ + 159) / 160) * 160;
+        if (pad160 < pad128) return launch_cfg<T, TO, 4, 1, 1, 5, false>(d, p, conv, st);
+        return launch_cfg<T, TO, 2, 2, 2, 2, false>(d, p, conv, st);
+    } else {
     const int N = p.N;
     {   // experiments: RF_GEMM_CFG=<0..6> forces one tile configuration (GEGLU still needs an even TN)
         static const int forced_all = tune_env("RF_GEMM_CFG", -1);
@@ -1427,13 +1610,18 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
             case 4: return launch_cfg<T, TO, 2, 2, 2, 2, W8>(d, p, conv, st);
             case 5: return launch_cfg<T, TO, 4, 1, 1, 2, W8>(d, p, conv, st);
             case 6: if (!g) return launch_cfg<T, TO, 4, 1, 1, 5, W8>(d, p, conv, st); break;
+#ifdef RF_EXPERIMENT
+            // one wave per SIMD, 512 registers per lane: 4 waves as 2 x 2 with 128x160 / 128x128 wave tiles (a third fewer fragment reads per FLOP)
+            case 7: if (!g && p.glds && d->batch == 1) return launch_wide<T, TO, 5, W8>(d, p, conv, st); break;
+            case 8: if (p.glds && d->batch == 1) return launch_wide<T, TO, 4, W8>(d, p, conv, st); break;
+#endif
             default: break;
         }
     }
     // 8-wave blocks with 320- / 256-wide tiles: half the LDS and L2 traffic per FLOP of the 4-wave configs.  Take the tallest
     // tile (256 rows, wave tile 64 x 160 / 64 x 128) that still gives ~one block per CU, else the 128-row variant.
     if (p.glds && d->batch == 1) {
-        const int bk = sizeof(T) == 2 ? 64 : 32;
+        const int bk = 128 / (int)sizeof(T);
         const long long mt256 = (p.M + 255) / 256, mt128 = (p.M + 127) / 128;
         const bool n320 = d->act != RF_ACT_GEGLU && N % 320 == 0, n256 = N % 256 == 0 && !n320;
         const long long nt = n320 ? N / 320 : (n256 ? N / 256 : 0);
@@ -1460,6 +1648,7 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
     const int pad128 = ((N + 127) / 128) * 128, pad160 = ((N + 159) / 160) * 160;
     if (pad160 < pad128) return launch_cfg<T, TO, 4, 1, 1, 5, W8>(d, p, conv, st);
     return launch_cfg<T, TO, 2, 2, 2, 2, W8>(d, p, conv, st);
+    }
 }
 
 }  // namespace rf
@@ -1468,22 +1657,28 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
     using namespace rf;
     RF_CHECK(d != nullptr, "rf_conv_gemm: null descriptor");
     const bool x3 = d->dtype == RF_BF16X3;
-    RF_CHECK(d->dtype == RF_F32 || d->dtype == RF_BF16 || x3, "rf_conv_gemm: bad dtype %d", d->dtype);
+    RF_CHECK(d->dtype == RF_F32 || d->dtype == RF_BF16 || x3 || d->dtype == RF_FP8_E4M3, "rf_conv_gemm: bad dtype %d", d->dtype);
+    RF_CHECK(d->dtype != RF_FP8_E4M3 || (d->w_dtype == RF_FP8_E4M3 && d->wscale && d->ascale && d->as_ld > 0 && d->as_ld % 4 == 0 && d->out_dtype == RF_BF16 &&
+                                         d->C1 == 0 && d->batch == 1 && d->korder == 0 && d->K % 128 == 0 && (d->C0 % 128 == 0 || (d->KH == 1 && d->KW == 1))),
+             "rf_conv_gemm: fp8 activations need fp8 weights + wscale, ascale with a pitch that is a multiple of 4, bf16 output, one source, batch 1, "
+             "K a multiple of 128 (zero-padded weights) and, for k x k windows, C0 a multiple of 128");
     RF_CHECK(!x3 || (d->out_dtype == RF_F32 && d->w_dtype == 0 && d->korder == 0 && d->C1 == 0 && d->batch == 1 && d->ld0 >= 2 * d->C0),
              "rf_conv_gemm: split-bf16 operands need fp32 output, one source with pixel pitch >= 2*C0, batch 1, tap-major K");
     RF_CHECK(d->out_dtype == RF_F32 || d->out_dtype == RF_BF16, "rf_conv_gemm: bad out_dtype %d", d->out_dtype);
-    const int vec = d->dtype == RF_F32 ? 4 : 8;
+    const bool a8 = d->dtype == RF_FP8_E4M3;           // fp8 activations + E8M0 block scales x fp8 weights (MX-scaled MFMA)
+    const int vec = d->dtype == RF_F32 ? 4 : (a8 ? 16 : 8);
     const int ctot = d->C0 + d->C1;
     RF_CHECK(d->M > 0 && d->N > 0 && d->K > 0 && d->batch >= 1, "rf_conv_gemm: bad sizes M=%d N=%d K=%d batch=%d", d->M, d->N, d->K, d->batch);
     RF_CHECK(d->src0 && d->W && d->out, "rf_conv_gemm: null operand");
     RF_CHECK(d->K % vec == 0 && ctot % vec == 0 && d->C0 % vec == 0 && d->ld0 % vec == 0,
              "rf_conv_gemm: K=%d C0=%d C1=%d ld0=%d must be multiples of %d", d->K, d->C0, d->C1, d->ld0, vec);
     RF_CHECK(d->C1 == 0 || (d->src1 && d->ld1 % vec == 0), "rf_conv_gemm: bad second source");
-    const bool w8 = d->w_dtype == RF_FP8_E4M3;
-    RF_CHECK(d->w_dtype == 0 || w8, "rf_conv_gemm: bad w_dtype %d", d->w_dtype);
+    const bool w8 = d->w_dtype == RF_FP8_E4M3 && d->dtype != RF_FP8_E4M3;          // W8A16: fp8 weights dequantised to bf16 in the fragment path
+    RF_CHECK(d->w_dtype == 0 || d->w_dtype == RF_FP8_E4M3, "rf_conv_gemm: bad w_dtype %d", d->w_dtype);
     RF_CHECK(!w8 || (d->dtype == RF_BF16 && d->wscale && d->ldw % 128 == 0 && d->ldw >= d->K && d->batch == 1 && d->korder == 0),
              "rf_conv_gemm: fp8 weights need bf16 activations, wscale, batch 1 and ldw (bytes) a multiple of 128 >= K (ldw=%d K=%d)", d->ldw, d->K);
     RF_CHECK(w8 || d->ldw == 0 || (d->ldw >= (x3 ? 3 : 1) * d->K && d->ldw % vec == 0), "rf_conv_gemm: bad ldw=%d", d->ldw);
+    RF_CHECK(!a8 || (d->ldw % 128 == 0 && d->ldw >= d->K), "rf_conv_gemm: fp8 x fp8 needs ldw (bytes) a multiple of 128 >= K");
     RF_CHECK(d->KH >= 1 && d->KW >= 1 && d->stride >= 1, "rf_conv_gemm: bad window");
     RF_CHECK(d->KH * d->KW * ctot <= d->K && d->K < d->KH * d->KW * ctot + 8 * vec,
              "rf_conv_gemm: K=%d inconsistent with KH*KW*(C0+C1)=%d", d->K, d->KH * d->KW * ctot);
@@ -1534,10 +1729,10 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
     }
     {
         // direct-to-LDS main loop needs one source, 31-bit byte offsets ...
-        const long long es = d->dtype == RF_F32 ? 4 : 2;
+        const long long es = d->dtype == RF_F32 ? 4 : (a8 ? 1 : 2);
         const long long rows_a = conv ? (long long)(d->M / (d->Hout * d->Wout)) * d->Hin * d->Win : d->M;
         const long long ab = ((rows_a - 1) * d->ld0 + (conv ? d->C0 : d->K) + (x3 ? d->C0 : 0)) * es;
-        const long long wb = w8 ? (long long)d->N * p.ldw : ((long long)(d->N - 1) * p.ldw + (x3 ? 3 : 1) * d->K) * es;
+        const long long wb = (w8 || a8) ? (long long)d->N * p.ldw : ((long long)(d->N - 1) * p.ldw + (x3 ? 3 : 1) * d->K) * es;
         // ... and K tiles that never straddle a filter tap (uniform K offset per tile; rows packed as sample:12 | oy:10 | ox:10)
         const int bk = (int)(128 / es);
         const bool uniform = d->K % bk == 0 && (!conv || (ctot % bk == 0 && d->K == d->KH * d->KW * ctot &&
@@ -1546,6 +1741,8 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
         p.korder = d->korder;
         p.a_bytes = (unsigned)(p.glds ? ab : 0);
         p.w_bytes = (unsigned)(p.glds ? wb : 0);
+        p.ascale = d->ascale; p.as_ld = d->as_ld;
+        p.as_bytes = (unsigned)(a8 ? rows_a * d->as_ld : 0);
         p.x3 = x3 ? 1 : 0;
         p.lo_off = x3 ? d->C0 * 2 : 0;
         if (x3) {
@@ -1560,6 +1757,7 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
         return launch_typed<bf16_t, bf16_t, true>(d, p, conv, st);
     }
     if (x3) return launch_typed<bf16_t, float>(d, p, conv, st);
+    if (a8) return launch_typed<fp8_t, bf16_t>(d, p, conv, st);
     if (d->dtype == RF_F32) {
         if (d->out_dtype == RF_F32) return launch_typed<float, float>(d, p, conv, st);
         return launch_typed<float, bf16_t>(d, p, conv, st);

@@ -104,7 +104,8 @@ template <typename T, typename TO, int NS>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restrict__ x, int HW, int C, int ldx, int nchunks,
                                                               const double* __restrict__ partial, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, int do_silu,
-                                                              TO* __restrict__ out, int ldo, int achunks, int split) {
+                                                              TO* __restrict__ out, int ldo, int achunks, int split,
+                                                              fp8_t* __restrict__ sc_out = nullptr, int lds_sc = 0) {
     constexpr int VEC = elem<T>::VEC;
     const int nvec = C / VEC;
     const int TV = nvec < GN_THREADS ? nvec : GN_THREADS;
@@ -201,7 +202,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
                     float y = f[e] * sc[q][e] + sh[q][e];
                     f[e] = do_silu ? silu_exact(y) : y;
                 }
-                if constexpr (sizeof(TO) == sizeof(T)) {
+                if constexpr (sizeof(TO) == 1) {             // bf16 in -> fp8 out + one E8M0 scale per 32-channel block (4 consecutive threads)
+                    quant_block8(f, orow + v * VEC, sc_out + ((long long)b * HW + p) * lds_sc + (v >> 2), (v & 3) == 0);
+                } else if constexpr (sizeof(TO) == sizeof(T)) {
                     *(u32x4_t*)(orow + v * VEC) = pack16<TO>(f);
                 } else if constexpr (sizeof(TO) == 4) {      // bf16 in -> fp32 out: two vectors
                     *(u32x4_t*)(orow + v * VEC) = pack16<float>(f);
@@ -226,7 +229,8 @@ constexpr int LN_RPW = 1;          // rows per wave.  4 (loads of four rows in f
 // NV = 16-byte vectors per lane (C <= NV * 64 * VEC); two-pass statistics in registers, fp32.
 template <typename T, typename TO, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int M, int C, int ldx, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float eps, TO* __restrict__ out, int ldo) {
+                                                        const float* __restrict__ beta, float eps, TO* __restrict__ out, int ldo,
+                                                        fp8_t* __restrict__ sc_out = nullptr, int lds_sc = 0) {
     constexpr int VEC = elem<T>::VEC;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
     const int lane = threadIdx.x & 63;
@@ -292,7 +296,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
                 float y[VEC];
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) y[e] = (f[r][q][e] - mean[r]) * rstd[r] * g[q][e] + bt[q][e];
-                if constexpr (sizeof(TO) == sizeof(T)) {
+                if constexpr (sizeof(TO) == 1) {
+                    quant_block8(y, orow + v * VEC, sc_out + (long long)(row0 + r) * lds_sc + (v >> 2), (v & 3) == 0);
+                } else if constexpr (sizeof(TO) == sizeof(T)) {
                     *(u32x4_t*)(orow + v * VEC) = pack16<TO>(y);
                 } else if constexpr (sizeof(TO) == 4) {
                     *(u32x4_t*)(orow + v * VEC) = pack16<float>(y);
@@ -423,6 +429,65 @@ extern "C" int rf_groupnorm_apply(int dtype, const void* x, int B, int HW, int C
 #undef GN_APPLY
 #undef GN_APPLY_
     RF_LAUNCH_CHECK("rf_groupnorm_apply");
+    return 0;
+}
+
+extern "C" int rf_groupnorm_apply_fp8(const void* x, int B, int HW, int C, int ldx, int nchunks, const double* partial, const float* gamma,
+                                      const float* beta, float eps, int silu, void* q, int ldq, void* scale, int lds, void* stream) {
+    if (gn_check("rf_groupnorm_apply_fp8", RF_BF16, C, ldx, nchunks)) return 1;
+    RF_CHECK(x && partial && gamma && beta && q && scale && B > 0 && HW > 0, "rf_groupnorm_apply_fp8: bad arguments");
+    RF_CHECK((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 && ((uintptr_t)q & 7) == 0, "rf_groupnorm_apply_fp8: gamma / beta / q alignment");
+    RF_CHECK(ldq >= C && ldq % 8 == 0 && lds >= C / 32, "rf_groupnorm_apply_fp8: ldq=%d lds=%d for C=%d", ldq, lds, C);
+    int achunks = (1024 + B - 1) / B;
+    const int maxc = (HW + 15) / 16;
+    if (achunks > maxc) achunks = maxc;
+    if (achunks < 1) achunks = 1;
+    dim3 grid(achunks, B);
+    const int ns = (C / 8 + GN_THREADS - 1) / GN_THREADS;
+#define GNQ_(NS_) hipLaunchKernelGGL((gn_apply_kernel<bf16_t, fp8_t, NS_>), grid, dim3(GN_THREADS), 0, (hipStream_t)stream, (const bf16_t*)x, HW, C, ldx, nchunks, partial, gamma, beta, eps, silu, (fp8_t*)q, ldq, achunks, 0, (fp8_t*)scale, lds)
+    if (ns <= 1) GNQ_(1); else if (ns <= 2) GNQ_(2); else GNQ_(GN_SLOTS);
+#undef GNQ_
+    RF_LAUNCH_CHECK("rf_groupnorm_apply_fp8");
+    return 0;
+}
+
+extern "C" int rf_layernorm_fp8(const void* x, int M, int C, int ldx, const float* gamma, const float* beta, float eps, void* q, int ldq, void* scale,
+                                int lds, void* stream) {
+    RF_CHECK(x && gamma && beta && q && scale && M > 0, "rf_layernorm_fp8: bad arguments");
+    RF_CHECK((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 && ((uintptr_t)q & 7) == 0, "rf_layernorm_fp8: gamma / beta / q alignment");
+    RF_CHECK(C % 32 == 0 && ldx % 8 == 0 && ldq % 8 == 0 && ldq >= C && lds >= C / 32 && C / 8 <= 64 * LN_MAXV, "rf_layernorm_fp8: C=%d ldx=%d ldq=%d lds=%d unsupported", C, ldx, ldq, lds);
+    dim3 grid((M + 4 * LN_RPW - 1) / (4 * LN_RPW));
+    const int nv = (C / 8 + 63) / 64;
+#define LNQ_(NV) hipLaunchKernelGGL((layernorm_kernel<bf16_t, fp8_t, NV>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, M, C, ldx, gamma, beta, eps, (fp8_t*)q, ldq, (fp8_t*)scale, lds)
+    if (nv <= 1) LNQ_(1); else if (nv <= 2) LNQ_(2); else if (nv <= 3) LNQ_(3); else LNQ_(LN_MAXV);
+#undef LNQ_
+    RF_LAUNCH_CHECK("rf_layernorm_fp8");
+    return 0;
+}
+
+// x [M, C] bf16 (row pitch ldx) -> e4m3fn bytes q [M][ldq] + one E8M0 scale byte per 32-channel block, scale [M][lds]
+__global__ __launch_bounds__(256) void quantize_fp8_act_kernel(const bf16_t* __restrict__ x, long long M, int C, int ldx, fp8_t* __restrict__ q, int ldq,
+                                                               fp8_t* __restrict__ sc, int lds) {
+    const int vpr = C >> 3;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool on = i < M * vpr;            // (vpr is a multiple of 4: the lanes of a quad are on or off together)
+    const long long r = on ? i / vpr : 0;
+    const int v = on ? (int)(i - r * vpr) : 0;
+    float f[8];
+    u32x4_t raw = {0u, 0u, 0u, 0u};
+    if (on) raw = *(const u32x4_t*)(x + r * ldx + v * 8);
+    unpack16<bf16_t>(raw, f);
+    if (on) quant_block8(f, q + r * ldq + v * 8, sc + r * lds + (v >> 2), (v & 3) == 0);
+}
+
+extern "C" int rf_quantize_fp8_act(const void* x, int64_t M, int C, int ldx, void* q, int ldq, void* scale, int lds, void* stream) {
+    RF_CHECK(x && q && scale && M > 0 && C > 0 && C % 32 == 0 && ldx % 8 == 0 && ldq % 8 == 0 && ldq >= C && lds >= C / 32,
+             "rf_quantize_fp8_act: bad arguments M=%lld C=%d ldx=%d ldq=%d lds=%d", (long long)M, C, ldx, ldq, lds);
+    RF_CHECK((((uintptr_t)x & 15) | ((uintptr_t)q & 7)) == 0, "rf_quantize_fp8_act: operand alignment");
+    const long long n = (long long)M * (C / 8);
+    hipLaunchKernelGGL(quantize_fp8_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long long)M, C, ldx,
+                       (fp8_t*)q, ldq, (fp8_t*)scale, lds);
+    RF_LAUNCH_CHECK("rf_quantize_fp8_act");
     return 0;
 }
 

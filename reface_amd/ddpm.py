@@ -219,7 +219,7 @@ class LatentDiffusion(nn.Module, _DeviceMixin):
         ``encoders=True`` also switches the CLIP ViT-L/14 / ArcFace towers and the VAE *encoder* (conditioning stage 4x faster; the
         conditioning vector and the inpaint latent then deviate ~1 % from fp32 -- throughput mode only; the VAE decode stays fp32)."""
         self.model.diffusion_model.set_compute_dtype(dtype)
-        if dtype == "fp8":                 # fp8 GEMM weights are a UNet mode; the towers / VAE encoder take the bf16 activations' dtype
+        if dtype in ("fp8", "fp8w"):       # fp8 GEMM operands are a UNet mode; the towers / VAE encoder take the bf16 activations' dtype
             dtype = torch.bfloat16
         if encoders:
             for m in (getattr(self, "cond_stage_model", None), getattr(getattr(self, "face_ID_model", None), "facenet", None)):

@@ -148,6 +148,62 @@ class Fp8Weight:
         return self.q[:, :self.K].view(torch.float8_e4m3fn).float() * self.scale[:, None]
 
 
+class Fp8Act:
+    """An activation tensor in the fp8 storage of the fp8 x fp8 GEMM path: ``q`` [..., Cp] uint8 e4m3fn bytes (Cp = C rounded up to a multiple of
+    128; the pad bytes stay 0) and ``scale`` [..., Cp / 32] uint8 E8M0 codes, one per 32-channel block (pad blocks stay 127 = 1.0);
+    x[..., c] = fp8(q[..., c]) * 2^(scale[..., c // 32] - 127)."""
+    __slots__ = ("q", "scale", "C")
+
+    def __init__(self, shape, device):
+        *lead, c = shape
+        cp = (c + 127) // 128 * 128
+        self.q = torch.zeros((*lead, cp), dtype=torch.uint8, device=device)
+        self.scale = torch.full((*lead, cp // 32), 127, dtype=torch.uint8, device=device)
+        self.C = c
+
+    @property
+    def shape(self):
+        return tuple(self.q.shape[:-1]) + (self.C,)
+
+    @property
+    def Cp(self):
+        return self.q.shape[-1]
+
+    def view(self, *lead):
+        o = object.__new__(Fp8Act)
+        o.q, o.scale, o.C = self.q.view(*lead, self.q.shape[-1]), self.scale.view(*lead, self.scale.shape[-1]), self.C
+        return o
+
+    def dequant(self):
+        """fp32 [..., C] values the kernel multiplies with (exact)."""
+        s = torch.pow(2.0, self.scale.float() - 127.0).repeat_interleave(32, dim=-1)
+        return (self.q.view(torch.float8_e4m3fn).float() * s)[..., :self.C]
+
+
+def quantize_act(x, out, name="quantize_fp8_act"):
+    """x bf16 [..., C] -> out (Fp8Act of the same logical shape) through rf_quantize_fp8_act."""
+    lib = _lib.load()
+    _require_gpu(x, out.q, out.scale)
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    assert x.dtype == torch.bfloat16 and x.stride(-1) == 1 and out.C == Cc
+    return Launch(lib.rf_quantize_fp8_act, (_p(x), M, Cc, x.stride(-2), _p(out.q), out.q.stride(-2), _p(out.scale), out.scale.stride(-2)),
+                  (x, out.q, out.scale), name)
+
+
+def quantize_fp8_padded(w2d, taps, cin):
+    """GEMM weight [N, taps * cin] (tap-major K) -> Fp8Weight [N, taps * Cp] with every tap's channel run zero-padded to Cp = a multiple of
+    128: the K order of an Fp8Act source (rf_conv_gemm fp8 x fp8 path)."""
+    n, k = w2d.shape
+    assert k == taps * cin, (k, taps, cin)
+    cp = (cin + 127) // 128 * 128
+    if cp != cin:
+        w = torch.zeros((n, taps, cp), dtype=torch.float32, device=w2d.device)
+        w[..., :cin] = w2d.float().reshape(n, taps, cin)
+        w2d = w.reshape(n, taps * cp)
+    return quantize_fp8(w2d)
+
+
 def fp8_eligible(K, cin=None):
     """rf_conv_gemm takes fp8 weights on its direct-to-LDS main loop: K (and, for convolutions, the channel count) multiples
     of the 64-element bf16 K tile."""
@@ -235,13 +291,19 @@ def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, 
     """Prepare an rf_conv_gemm launch (see include/reface_hip.h).  x3: split-bf16 operands (src0 = [.., C0 hi | C0 lo] bf16, W from
     pack_x3, fp32 out); K / C0 are the REAL sizes."""
     lib = _lib.load()
+    a8 = None
+    if isinstance(src0, Fp8Act):          # fp8 activations + block scales: K / C0 / ld0 are the PADDED byte counts (the caller passes them)
+        a8, src0 = src0, src0.q
+        assert isinstance(W, Fp8Weight) and out.dtype == torch.bfloat16 and src1 is None and not x3
     _require_gpu(src0, W.q if isinstance(W, Fp8Weight) else W, out, src1, bias, rowvec, residual)
     d = ConvGemmDesc()
-    d.dtype, d.out_dtype = code(src0.dtype), code(out.dtype)
+    d.dtype, d.out_dtype = (RF_FP8_E4M3 if a8 is not None else code(src0.dtype)), code(out.dtype)
+    if a8 is not None:
+        d.ascale, d.as_ld = _p(a8.scale), a8.scale.stride(-2)
     wq = None
     if isinstance(W, Fp8Weight):             # fp8 weights: bf16 activations, bytes + per-row scales
         wq, W = W, W.q
-        assert src0.dtype == torch.bfloat16 and wq.K == K and ldw == 0
+        assert (src0.dtype == torch.bfloat16 or a8 is not None) and wq.K == K and ldw == 0, (src0.dtype, wq.K, K)
         d.w_dtype, d.wscale, ldw = RF_FP8_E4M3, _p(wq.scale), W.stride(0)
     else:
         assert W.dtype == src0.dtype
@@ -266,8 +328,8 @@ def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, 
     d.korder = korder
     ws = workspace if workspace is not None else _default_workspace(src0.device)
     d.workspace, d.workspace_bytes = _p(ws), (ws.numel() * ws.element_size() if ws is not None else 0)
-    l = Launch(lib.rf_conv_gemm, (C.byref(d),), (d, src0, src1, W, out, bias, rowvec, residual, act_vec, ws, wq), name)
-    if wq is not None:
+    l = Launch(lib.rf_conv_gemm, (C.byref(d),), (d, src0, src1, W, out, bias, rowvec, residual, act_vec, ws, wq, a8), name)
+    if wq is not None and a8 is None:
         # fp8 weights run only on the direct-to-LDS main loop, whose preconditions (one source, 31-bit operand extents, <= 1024^2 outputs,
         # < 4095 samples, whole K tiles per tap) depend on the launch, not only on the weight: ask the library, and give a layer that
         # cannot take them its exactly dequantised bf16 weights instead of failing at the first replay
@@ -282,10 +344,14 @@ def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, 
 
 def linear(x, W, out, bias=None, *, act=ACT_NONE, residual=None, rowvec=None, rows_per_sample=0, alpha=1.0, act_vec=None, name="linear"):
     """out[M, N] = act(x[M, K] @ W[N, K]^T + bias) (+ residual).  x / out may be row-strided 2-D views."""
-    M, K = x.shape
+    if isinstance(x, Fp8Act):             # K = the padded channel count (W from quantize_fp8_padded(w, 1, C))
+        M, K, ld0 = x.q.shape[0], x.Cp, x.q.stride(0)
+    else:
+        (M, K), ld0 = x.shape, x.stride(0)
+        assert x.stride(1) == 1
     N = W.shape[0]
-    assert W.shape[1] == K and x.stride(1) == 1 and out.stride(1) == 1, (tuple(W.shape), K)
-    return conv_gemm(x, W, out, M=M, N=N, K=K, C0=K, ld0=x.stride(0), Hin=1, Win=M, Hout=1, Wout=M, bias=bias, act=act,
+    assert W.shape[1] == K and out.stride(1) == 1, (tuple(W.shape), K)
+    return conv_gemm(x, W, out, M=M, N=N, K=K, C0=K, ld0=ld0, Hin=1, Win=M, Hout=1, Wout=M, bias=bias, act=act,
                      residual=residual, ldr=(residual.stride(0) if residual is not None else 0), rowvec=rowvec,
                      rows_per_sample=rows_per_sample, ldv=(rowvec.stride(0) if rowvec is not None else 0),
                      ldo=out.stride(0), alpha=alpha, act_vec=act_vec, name=name)
@@ -296,15 +362,21 @@ def conv2d(x, W, out, bias=None, *, ksize=3, stride=1, pad=(1, 1), ups=0, x2=Non
     """Channels-last convolution.  x: [B, Hin, Win, C0] (+ optional x2 [B, Hin, Win, C1] concatenated
     on channels); W: packed [Cout, k*k*(C0+C1)]; out: [B, Hout, Wout, Cout].  x3: x is the split-bf16 form [B, Hin, Win, 2*C0] of an
     fp32 tensor and W comes from pack_x3 ([Cout, 3*k*k*C0])."""
-    B, Hin, Win, C0 = x.shape
+    if isinstance(x, Fp8Act):             # C0 = the padded channel count (W from quantize_fp8_padded(w, k*k, C))
+        B, Hin, Win, C0 = x.q.shape
+        ld0 = x.q.stride(2)
+    else:
+        B, Hin, Win, C0 = x.shape
+        ld0 = x.stride(2)
+        assert x.stride(3) == 1
     C1 = 0 if x2 is None else x2.shape[3]
     Bo, Hout, Wout, N = out.shape
-    assert Bo == B and x.stride(3) == 1 and out.stride(3) == 1
+    assert Bo == B and out.stride(3) == 1
     K = W.shape[1]
     if x3:
         assert x2 is None and C0 % 2 == 0 and K % 3 == 0
         C0, K = C0 // 2, K // 3
-    return conv_gemm(x, W, out, M=B * Hout * Wout, N=N, K=K, C0=C0, ld0=x.stride(2), src1=x2, C1=C1,
+    return conv_gemm(x, W, out, M=B * Hout * Wout, N=N, K=K, C0=C0, ld0=ld0, src1=x2, C1=C1,
                      ld1=(x2.stride(2) if x2 is not None else 0), Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, KH=ksize, KW=ksize,
                      stride=stride, pad_t=pad[0], pad_l=pad[1], ups=ups, bias=bias, residual=residual,
                      ldr=(residual.stride(2) if residual is not None else 0), rowvec=rowvec, rows_per_sample=Hout * Wout,
@@ -335,12 +407,14 @@ def groupnorm(x, gamma, beta, out, partial, *, eps, silu, split=False, name="gro
     """GroupNorm(32)(+SiLU) over channels-last x [B, H, W, C] -> out.  ``partial``: fp64 scratch
     of at least B * GN_MAX_CHUNKS * 64 elements.  Returns the two launches (stats, apply)."""
     lib = _lib.load()
-    _require_gpu(x, gamma, beta, out, partial)
     B, H, W_, Cc = x.shape
     HW = H * W_
     n = gn_chunks(B, HW)
     assert partial.dtype == torch.float64 and partial.numel() >= B * n * 64
     a = Launch(lib.rf_groupnorm_stats, (code(x.dtype), _p(x), B, HW, Cc, x.stride(2), n, _p(partial)), (x, partial), name + ".stats")
+    if isinstance(out, Fp8Act):
+        return [a, groupnorm_apply(x, gamma, beta, out, partial, n, eps=eps, silu=silu, name=name)]
+    _require_gpu(x, gamma, beta, out, partial)
     b = Launch(lib.rf_groupnorm_apply, (code(x.dtype), _p(x), B, HW, Cc, x.stride(2), n, _p(partial), _p(gamma), _p(beta),
                                         float(eps), int(bool(silu)), _gn_out_code(x, out, split), _p(out), out.stride(2)),
                (x, partial, gamma, beta, out), name + ".apply")
@@ -406,10 +480,17 @@ def fuse_groupnorm_stats(x, producers):
 
 
 def groupnorm_apply(x, gamma, beta, out, partial, nchunks, *, eps, silu, split=False, name="groupnorm"):
-    """The normalisation pass alone, on statistics that already sit in ``partial`` (fuse_groupnorm_stats)."""
+    """The normalisation pass alone, on statistics that already sit in ``partial`` (fuse_groupnorm_stats).  ``out`` may be an Fp8Act
+    (bf16 input): the normalised values leave as e4m3fn bytes + block scales."""
     lib = _lib.load()
-    _require_gpu(x, gamma, beta, out, partial)
     B, H, W_, Cc = x.shape
+    if isinstance(out, Fp8Act):
+        _require_gpu(x, gamma, beta, out.q, out.scale, partial)
+        assert x.dtype == torch.bfloat16 and out.C == Cc
+        return Launch(lib.rf_groupnorm_apply_fp8, (_p(x), B, H * W_, Cc, x.stride(2), nchunks, _p(partial), _p(gamma), _p(beta), float(eps),
+                                                   int(bool(silu)), _p(out.q), out.q.stride(2), _p(out.scale), out.scale.stride(2)),
+                      (x, partial, gamma, beta, out.q, out.scale), name + ".apply")
+    _require_gpu(x, gamma, beta, out, partial)
     return Launch(lib.rf_groupnorm_apply, (code(x.dtype), _p(x), B, H * W_, Cc, x.stride(2), nchunks, _p(partial), _p(gamma), _p(beta),
                                            float(eps), int(bool(silu)), _gn_out_code(x, out, split), _p(out), out.stride(2)),
                   (x, partial, gamma, beta, out), name + ".apply")
@@ -417,8 +498,13 @@ def groupnorm_apply(x, gamma, beta, out, partial, nchunks, *, eps, silu, split=F
 
 def layernorm(x, gamma, beta, out, *, eps=1e-5, name="layernorm"):
     lib = _lib.load()
-    _require_gpu(x, gamma, beta, out)
     M, Cc = x.shape
+    if isinstance(out, Fp8Act):
+        _require_gpu(x, gamma, beta, out.q, out.scale)
+        assert x.dtype == torch.bfloat16 and out.C == Cc
+        return Launch(lib.rf_layernorm_fp8, (_p(x), M, Cc, x.stride(0), _p(gamma), _p(beta), float(eps), _p(out.q), out.q.stride(0), _p(out.scale),
+                                             out.scale.stride(0)), (x, gamma, beta, out.q, out.scale), name)
+    _require_gpu(x, gamma, beta, out)
     return Launch(lib.rf_layernorm, (code(x.dtype), _p(x), M, Cc, x.stride(0), _p(gamma), _p(beta), float(eps), code(out.dtype),
                                      _p(out), out.stride(0)), (x, gamma, beta, out), name)
 

@@ -11,6 +11,8 @@ def launch_family(l):
     n = l.fn.__name__
     if n == "rf_conv_gemm":
         d = l.keep[0]
+        if d.dtype == 2:
+            return "rf_conv_gemm[fp8]"           # fp8 activations (E8M0 block scales) x fp8 weights on the MX-scaled fp8 MFMA
         if d.w_dtype == 2:
             return "rf_conv_gemm[fp8w]"          # fp8 (e4m3fn) weights x bf16 activations on the bf16 MFMA
         if d.dtype == 3:
@@ -25,6 +27,8 @@ def gemm_flops(l):
         return 0.0
     d = l.keep[0]
     k_real = d.KH * d.KW * (d.C0 + d.C1)
+    if d.dtype == 2:            # fp8 activations: C0 / K count the channel run PADDED to 128; the algorithmic count uses the real channels
+        k_real = d.KH * d.KW * next((k.C for k in l.keep if type(k).__name__ == "Fp8Act"), d.C0)
     return 2.0 * d.M * d.N * min(k_real, d.K) * d.batch
 
 

@@ -70,7 +70,13 @@ class UNetEngine:
     def __init__(self, sd, cfg: UNetConfig, B, H, W, dtype, device, uniform_t=False, emb_rows=None, cfg_pair=False):
         # dtype "fp8" (BASELINE configs[4]): bf16 activations, GEMM weights stored as fp8 e4m3fn + per-output-channel power-of-two
         # scales wherever rf_conv_gemm takes them (K and channel count multiples of 64), fp32 accumulate
-        self.w8 = dtype == "fp8"
+        # "fp8": additionally fp8 ACTIVATIONS (e4m3fn + one E8M0 scale per 32 channels, written by the GroupNorm / LayerNorm passes) into the
+        # ResBlock convolutions, proj_in, qkv and GEGLU projections, multiplied on the MX-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4);
+        # "fp8w": fp8 weights only (bf16 activations on the bf16 MFMA)
+        self.w8 = dtype in ("fp8", "fp8w")
+        self.a8 = dtype == "fp8"
+        self.n_a8 = 0
+        self._apool = {}
         if self.w8:
             dtype = torch.bfloat16
         self.cfg, self.B, self.H, self.W, self.dt, self.dev = cfg, B, H, W, dtype, device
@@ -120,6 +126,20 @@ class UNetEngine:
             self.n_fp8 += 1
             return ops.quantize_fp8(w2d)
         return w2d.to(self.dt).contiguous()
+
+    def aget(self, shape):
+        """An Fp8Act buffer (free-list by shape; pad bytes / pad scales are initialised once and never written)."""
+        lst = self._apool.get(tuple(shape))
+        return lst.pop() if lst else ops.Fp8Act(tuple(shape), self.dev)
+
+    def aput(self, a):
+        self._apool.setdefault(tuple(a.shape), []).append(a)
+
+    def gw8(self, w2d, taps, cin):
+        """fp8 weight of an fp8-activation GEMM: every tap's channel run zero-padded to the 128-byte K tile."""
+        self.n_fp8 += 1
+        self.n_a8 += 1
+        return ops.quantize_fp8_padded(w2d.to(self.dev), taps, cin)
 
     # ------------------------------------------------------------------ timestep path (fp32)
     def _res_prefixes(self):
@@ -210,6 +230,8 @@ class UNetEngine:
     def _conv3(self, x, wkey, out, bkey, name, **kw):
         """3x3 conv launch; K order chosen per layer (ops.conv_korder)."""
         cin = x.shape[3]
+        if isinstance(x, ops.Fp8Act):
+            return ops.conv2d(x, self.gw8(ops.pack_conv_weight(self.sd[wkey], F32), 9, cin), out, self.f32(bkey), name=name, **kw)
         ko = ops.conv_korder(cin, self.dt) if self.korder_on else 0
         wp = ops.pack_conv_weight(self.sd[wkey], F32, korder=ko)
         return ops.conv2d(x, wp.to(self.dt) if ko else self.gw(wp, cin), out, self.f32(bkey), korder=ko, name=name, **kw)
@@ -219,8 +241,8 @@ class UNetEngine:
         self.main.append(launch)
         return self.tracker.record(out, launch)
 
-    def _gn(self, x, key, eps, silu):
-        out = self.pool.get(tuple(x.shape), self.dt)
+    def _gn(self, x, key, eps, silu, fp8=False):
+        out = self.aget(x.shape) if fp8 else self.pool.get(tuple(x.shape), self.dt)
         fused = None
         if self.gn_fuse:
             prods = self.tracker.producers(x)
@@ -238,14 +260,14 @@ class UNetEngine:
 
     def _res(self, p, x, cin, cout, dst):
         B, H, W, _ = x.shape
-        t1 = self._gn(x, f"{p}.in_layers.0", 1e-5, True)
+        t1 = self._gn(x, f"{p}.in_layers.0", 1e-5, True, fp8=self.a8)
         h1 = self.pool.get((B, H, W, cout), self.dt)
         rv = self.emb_vec(p)
         if self.uniform_t:
             rv = rv.as_strided((B, cout), (0, 1), rv.storage_offset())      # every sample reads row 0 (B = this input's batch)
         self._add(self._conv3(t1, f"{p}.in_layers.2.weight", h1, f"{p}.in_layers.2.bias", f"{p}.in_layers.2", rowvec=rv), h1)
-        self.pool.put(t1)
-        t2 = self._gn(h1, f"{p}.out_layers.0", 1e-5, True)
+        (self.aput if self.a8 else self.pool.put)(t1)
+        t2 = self._gn(h1, f"{p}.out_layers.0", 1e-5, True, fp8=self.a8)
         self.pool.put(h1)
         if cin != cout:
             skip = self.pool.get((B, H, W, cout), self.dt)
@@ -255,7 +277,7 @@ class UNetEngine:
             skip = x
         y = dst if dst is not None else self.pool.get((B, H, W, cout), self.dt)
         self._add(self._conv3(t2, f"{p}.out_layers.3.weight", y, f"{p}.out_layers.3.bias", f"{p}.out_layers.3", residual=skip), y)
-        self.pool.put(t2)
+        (self.aput if self.a8 else self.pool.put)(t2)
         if cin != cout:
             self.pool.put(skip)
         return y
@@ -267,19 +289,24 @@ class UNetEngine:
         M, d = B * H * W, c // heads
         t = f"{p}.transformer_blocks.0"
         nb = 2 if pair else 1                   # batch fan-out at the cross-attention
-        g = self._gn(x, f"{p}.norm", 1e-6, False)
+        a8 = self.a8
+        g = self._gn(x, f"{p}.norm", 1e-6, False, fp8=a8)
         tok = self.pool.get((M, c), self.dt)
-        self.main.append(ops.linear(g.view(M, c), self.gw(self.sd[f"{p}.proj_in.weight"].reshape(c, c)), tok, self.f32(f"{p}.proj_in.bias"),
+        w_pi = self.sd[f"{p}.proj_in.weight"].reshape(c, c)
+        self.main.append(ops.linear(g.view(M, c), self.gw8(w_pi, 1, c) if a8 else self.gw(w_pi), tok, self.f32(f"{p}.proj_in.bias"),
                                     name=f"{p}.proj_in"))
-        self.pool.put(g)
-        ln = self.pool.get((M, c), self.dt)
+        (self.aput if a8 else self.pool.put)(g)
+        ln = self.aget((M, c)) if a8 else self.pool.get((M, c), self.dt)
         self.main.append(ops.layernorm(tok, self.f32(f"{t}.norm1.weight"), self.f32(f"{t}.norm1.bias"), ln, name=f"{t}.norm1"))
         qkv = self.pool.get((M, 3 * c), self.dt)
         # to_q carries d^-0.5 * log2(e): the scores reach the attention kernels in the exp2 domain (scale = ln 2 below) -- the product
         # is rounded to the storage type once, as a weight, instead of the kernel re-rounding q * scale
         wqkv = torch.cat([self.sd[f"{t}.attn1.to_q.weight"].float() * (d ** -0.5 * ops.LOG2E), self.sd[f"{t}.attn1.to_k.weight"].float(),
                           self.sd[f"{t}.attn1.to_v.weight"].float()], 0)
-        self.main.append(ops.linear(ln, self.gw(wqkv), qkv, None, name=f"{t}.attn1.qkv"))
+        self.main.append(ops.linear(ln, self.gw8(wqkv, 1, c) if a8 else self.gw(wqkv), qkv, None, name=f"{t}.attn1.qkv"))
+        if a8:
+            self.aput(ln)
+            ln = self.pool.get((M, c), self.dt)
         att = ln    # reuse the LayerNorm buffer for the attention output
         q3 = qkv.view(B, H * W, 3 * c)
         self.main.append(ops.attention(q3[..., :c], q3[..., c:2 * c], q3[..., 2 * c:], att.view(B, H * W, c), heads=heads,
@@ -293,9 +320,9 @@ class UNetEngine:
                                         rows_per_sample=H * W, name=f"{t}.attn1.to_out"))
         self.pool.put(qkv)
         self.pool.put(tok)
-        if pair:
+        if pair or a8:
             self.pool.put(ln)
-            ln = self.pool.get((nb * M, c), self.dt)
+            ln = self.aget((nb * M, c)) if a8 else self.pool.get((nb * M, c), self.dt)
         self.main.append(ops.layernorm(x1, self.f32(f"{t}.norm3.weight"), self.f32(f"{t}.norm3.bias"), ln, name=f"{t}.norm3"))
         wg, bg = ops.pack_geglu(self.sd[f"{t}.ff.net.0.proj.weight"], self.sd[f"{t}.ff.net.0.proj.bias"], F32)
         if self.ffn_fuse and c == 320 and self.dt == torch.bfloat16 and not self.w8:
@@ -305,9 +332,12 @@ class UNetEngine:
                                            self.f32(f"{t}.ff.net.2.bias"), x2, residual=x1, name=f"{t}.ff"))
             self.pool.put(ln)
         else:
-            wg = self.gw(wg)
+            wg = self.gw8(wg, 1, c) if a8 else self.gw(wg)
             gg = self.pool.get((nb * M, 4 * c), self.dt)
             self.main.append(ops.linear(ln, wg, gg, bg, act=ops.ACT_GEGLU, name=f"{t}.ff.net.0"))
+            if a8:
+                self.aput(ln)
+                ln = self.pool.get((nb * M, c), self.dt)
             x2 = ln
             self.main.append(ops.linear(gg, self.gw(self.sd[f"{t}.ff.net.2.weight"]), x2, self.f32(f"{t}.ff.net.2.bias"), residual=x1, name=f"{t}.ff.net.2"))
             self.pool.put(gg)
@@ -456,9 +486,10 @@ class UNetModel(nn.Module):
         self._engines = {}
 
     def set_compute_dtype(self, dtype):
-        """torch.float32 (exact-fp32 parity mode) | torch.bfloat16 (throughput mode) | "fp8" (fp8 e4m3fn GEMM weights + bf16
-        activations, BASELINE configs[4])."""
-        if dtype not in (torch.float32, torch.bfloat16, "fp8"):
+        """torch.float32 (exact-fp32 parity mode) | torch.bfloat16 (throughput mode) | "fp8" (BASELINE configs[4]: fp8 e4m3fn GEMM weights
+        everywhere + fp8 activations with E8M0 block scales into the ResBlock convs / proj_in / qkv / GEGLU on the fp8 MFMA) | "fp8w" (fp8
+        weights, bf16 activations, bf16 MFMA)."""
+        if dtype not in (torch.float32, torch.bfloat16, "fp8", "fp8w"):
             raise ValueError(f"unsupported UNet compute dtype {dtype!r}")
         self.compute_dtype = dtype
         self._engines.clear()

@@ -603,3 +603,120 @@ def test_geglu_negative_gates():
     err = (out.double().cpu() - ref).abs()
     lim = 4.8e-4 * val.abs() + 2.0 ** -8 * ref.abs() + 1e-6
     assert (err <= lim).all(), (err - lim).max().item()
+
+
+# ------------------------------------------------------------------------------------------------ fp8 x fp8 (MX-scaled MFMA) path
+def _quant_act_ref(x):
+    """torch restatement of rf_quantize_fp8_act: per (row, 32-channel block) the smallest power-of-two scale with amax / scale <= 448,
+    RNE conversion to e4m3fn.  Returns (q as float8 tensor, E8M0 codes)."""
+    *lead, c = x.shape
+    xb = x.float().reshape(*lead, c // 32, 32)
+    amax = xb.abs().amax(-1)
+    m, e = torch.frexp(amax)                                   # amax = m * 2^e, m in [0.5, 1)
+    # amax = (2m) * 2^(e-1), 2m in [1, 2): code = (e - 1 + 127) - 8 + (2m > 1.75)
+    code = (e - 1 + 127 - 8 + (2 * m > 1.75).int()).clamp(0, 253)
+    code = torch.where(amax > 0, code, torch.zeros_like(code))
+    scale = torch.pow(2.0, code.float() - 127.0)
+    q = (xb / scale[..., None]).reshape(*lead, c).to(torch.float8_e4m3fn)
+    return q, code.to(torch.uint8)
+
+
+@pytest.mark.parametrize("M,Cc", [(300, 320), (64, 128), (1000, 960)])
+def test_quantize_fp8_act(M, Cc):
+    x = (rnd((M, Cc), 930) * torch.exp(rnd((M, 1), 931))).to(torch.bfloat16)          # rows of very different magnitude
+    x[0, :32] = 0                                                                       # an all-zero block
+    out = ops.Fp8Act((M, Cc), DEV)
+    ops.quantize_act(x.to(DEV), out)()
+    torch.cuda.synchronize()
+    q, code = _quant_act_ref(x)
+    assert torch.equal(out.scale[:, :Cc // 32].cpu(), code)
+    assert torch.equal(out.q[:, :Cc].cpu(), q.view(torch.uint8))
+    assert (out.q[:, Cc:] == 0).all() and (out.scale[:, Cc // 32:] == 127).all()       # pads untouched
+    # round trip: 3 mantissa bits + block scaling
+    deq = out.dequant().cpu()
+    blockmax = x.float().reshape(M, Cc // 32, 32).abs().amax(-1).repeat_interleave(32, dim=1)
+    assert ((deq - x.float()).abs() <= 2.0 ** -4 * x.float().abs() + 2.0 ** -9 * blockmax + 1e-30).all()
+
+
+@pytest.mark.parametrize("M,N,K,kind", [(256, 320, 320, "plain"), (4096, 960, 320, "plain"), (2048, 640, 1280, "res"), (1024, 1280, 5120, "plain"),
+                                        (512, 2560, 320, "geglu"), (77, 200, 128, "plain")])
+def test_linear_fp8_act(M, N, K, kind):
+    """fp8 activations (E8M0 block scales) x fp8 weights (per-row scales) on v_mfma_scale_f32_32x32x64_f8f6f4: products of fp8 values are
+    exact in fp32 and the accumulation is fp32, so the result must match an fp32 reference on the DEQUANTISED operands to bf16 output
+    rounding -- including K = 320 (padded to 384 against zero weights)."""
+    dt = torch.bfloat16
+    x = (rnd((M, K), 932) * 0.7).to(dt)
+    xa = ops.Fp8Act((M, K), DEV)
+    ops.quantize_act(x.to(DEV), xa)()
+    w = rnd((N, K), 933) / math.sqrt(K)
+    b = rnd((N,), 934)
+    if kind == "geglu":
+        wp, bp = ops.pack_geglu(w, b, torch.float32)
+        fw = ops.quantize_fp8_padded(wp.to(DEV), 1, K)
+        out = torch.empty((M, N // 2), dtype=dt, device=DEV)
+        ops.linear(xa, fw, out, bp.to(DEV), act=ops.ACT_GEGLU)()
+        torch.cuda.synchronize()
+        wd = fw.dequant()[:, :K].cpu()
+        f = N // 2
+        wv, wg = wd.reshape(f // 32, 2, 32, K)[:, 0].reshape(f, K), wd.reshape(f // 32, 2, 32, K)[:, 1].reshape(f, K)
+        xd = xa.dequant().cpu()
+        ref = F.linear(xd, wv, b[:f]) * F.gelu(F.linear(xd, wg, b[f:]))
+    else:
+        fw = ops.quantize_fp8_padded(w.to(DEV), 1, K)
+        res, rr = q(rnd((M, N), 935), dt) if kind == "res" else (None, 0.0)
+        out = torch.empty((M, N), dtype=dt, device=DEV)
+        l = ops.linear(xa, fw, out, b.to(DEV), residual=res)
+        l()
+        torch.cuda.synchronize()
+        assert l.keep[0].dtype == 2 and l.keep[0].w_dtype == 2
+        ref = F.linear(xa.dequant().cpu(), fw.dequant()[:, :K].cpu(), b) + rr
+    check(out, ref, dt)
+
+
+@pytest.mark.parametrize("case", ["c320", "c640s", "c128"])
+def test_conv_fp8_act(case):
+    dt = torch.bfloat16
+    B, H, W_, Ci, Co = {"c320": (2, 16, 16, 320, 320), "c640s": (2, 8, 8, 640, 640), "c128": (1, 12, 10, 128, 96)}[case]
+    x = (rnd((B, H, W_, Ci), 936) * 0.8).to(dt)
+    xa = ops.Fp8Act((B, H, W_, Ci), DEV)
+    ops.quantize_act(x.to(DEV), xa)()
+    w = rnd((Co, Ci, 3, 3), 937) / math.sqrt(9 * Ci)
+    b = rnd((Co,), 938)
+    rv = rnd((B, Co), 939)
+    fw = ops.quantize_fp8_padded(ops.pack_conv_weight(w, torch.float32).to(DEV), 9, Ci)
+    out = torch.empty((B, H, W_, Co), dtype=dt, device=DEV)
+    ops.conv2d(xa, fw, out, b.to(DEV), rowvec=rv.to(DEV))()
+    torch.cuda.synchronize()
+    Cp = xa.Cp
+    wd = fw.dequant().cpu().reshape(Co, 9, Cp)[:, :, :Ci].reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2)
+    ref = _conv_ref(xa.dequant().cpu(), wd, b, 1, (1, 1, 1, 1), 0) + rv[:, None, None, :]
+    check(out, ref, dt)
+
+
+def test_norms_fp8_output():
+    """GroupNorm+SiLU and LayerNorm writing fp8 + block scales directly == rf_quantize_fp8_act semantics applied to the fp32 normalised values
+    (the bf16-output kernels round to bf16 first: compare dequantised values with a 3-mantissa-bit + block-scale tolerance)."""
+    B, H, W_, Cc = 2, 16, 16, 320
+    x = rnd((B, H, W_, Cc), 940).to(torch.bfloat16).to(DEV)
+    g, bt = rnd((Cc,), 941).to(DEV), rnd((Cc,), 942).to(DEV)
+    part = torch.empty(B * ops.GN_MAX_CHUNKS * 64, dtype=torch.float64, device=DEV)
+    y32 = torch.empty((B, H, W_, Cc), dtype=torch.float32, device=DEV)
+    ops.run(ops.groupnorm(x, g, bt, y32, part, eps=1e-5, silu=True))
+    ya = ops.Fp8Act((B, H, W_, Cc), DEV)
+    ops.run(ops.groupnorm(x, g, bt, ya, part, eps=1e-5, silu=True))
+    torch.cuda.synchronize()
+    qr, code = _quant_act_ref(y32.cpu())
+    assert (ya.scale[..., :Cc // 32].cpu().int() - code.int()).abs().max() <= 1          # (fp32 evaluation order may move an amax across a power of two)
+    d = (ya.dequant().cpu() - y32.cpu()).abs()
+    bm = y32.cpu().reshape(B, H, W_, Cc // 32, 32).abs().amax(-1).repeat_interleave(32, dim=-1)
+    assert (d <= 2.0 ** -4 * y32.cpu().abs() + 2.0 ** -8 * bm + 1e-6).all(), d.max().item()
+    M = 512
+    xl = rnd((M, Cc), 943).to(torch.bfloat16).to(DEV)
+    l32 = torch.empty((M, Cc), dtype=torch.float32, device=DEV)
+    ops.layernorm(xl, g, bt, l32)()
+    la = ops.Fp8Act((M, Cc), DEV)
+    ops.layernorm(xl, g, bt, la)()
+    torch.cuda.synchronize()
+    d = (la.dequant().cpu() - l32.cpu()).abs()
+    bm = l32.cpu().reshape(M, Cc // 32, 32).abs().amax(-1).repeat_interleave(32, dim=-1)
+    assert (d <= 2.0 ** -4 * l32.cpu().abs() + 2.0 ** -8 * bm + 1e-6).all(), d.max().item()

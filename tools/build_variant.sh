@@ -14,4 +14,5 @@ for u in gemm norm attention elementwise encoder ffn; do
   if [ $u = $unit ]; then objs="$objs $ROOT/reface_amd/lib/alt/$tag.$unit.o"; else objs="$objs $ROOT/reface_amd/lib/$u.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/reface_amd/lib/alt/$tag.so $objs
+if nm -u -C $ROOT/reface_amd/lib/alt/$tag.so | grep -q "rf::"; then echo "variant has undefined rf:: symbols (host stubs missing):"; nm -u -C $ROOT/reface_amd/lib/alt/$tag.so | grep "rf::" | head -4; exit 1; fi
 echo $ROOT/reface_amd/lib/alt/$tag.so
