@@ -28,8 +28,9 @@ sys.path.insert(0, ROOT)
 
 F_UNET = {64: 796.94e9, 96: 2137.52e9}   # algorithmic FLOP per sample per UNet evaluation by latent side (SURVEY.md 8d / BASELINE.md 2)
 F_VAE_DEC_512 = 2514.5e9      # fp32 VAE decode per 512x512 image
-PEAK = {"bf16": 2500.0, "f32": 157.3, "fp8": 2500.0}     # dense MFMA TFLOP/s of the instruction each mode issues (MI355X_MICROARCH.md):
-                                                         # the fp8-weight mode dequantises to bf16 in the LDS read path -> bf16 MFMA rate
+PEAK = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0, "fp8w": 2500.0}     # dense MFMA TFLOP/s of the instruction the dominant family issues
+                                                         # (MI355X_MICROARCH.md): "fp8" = fp8 x fp8 on the MX-scaled fp8 MFMA (5 PF dense);
+                                                         # "fp8w" dequantises fp8 weights to bf16 in the LDS read path -> bf16 MFMA rate
 # BASELINE.json configs[i] -> per-GPU workload (configs[2] = configs[1] on every one of the N GPUs)
 CONFIGS = {
     "c1": dict(idx=1, latent=64, batch=8, dtype="bf16"),
@@ -266,7 +267,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="image pairs per GPU per step (overrides the config)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--latent", type=int, default=None, help="latent side (64 = 512x512 images; overrides the config)")
-    ap.add_argument("--dtype", default=None, choices=["bf16", "f32", "fp8"], help="UNet compute mode (overrides the config)")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f32", "fp8", "fp8w"], help="UNet compute mode (overrides the config)")
     ap.add_argument("--scale", type=float, default=3.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -301,7 +302,7 @@ def main():
 
     from reface_amd import ops
     from reface_amd.ddim import DDIMSampler
-    dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "fp8": "fp8"}[dname]
+    dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "fp8": "fp8", "fp8w": "fp8w"}[dname]
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     unet, vae, ldm, cpu_sd = build_models(dtype, device, rank, world, want_cpu)
     sampler = DDIMSampler(ldm)
@@ -349,7 +350,10 @@ def main():
     value = world * B * args.steps / elapsed
 
     px = 8 * h
-    wdesc = {"bf16": "bf16 UNet", "f32": "exact-fp32 UNet", "fp8": "fp8 (e4m3fn) UNet weights, bf16 activations, fp32 accumulate"}[dname]
+    wdesc = {"bf16": "bf16 UNet", "f32": "exact-fp32 UNet",
+             "fp8": "fp8 (e4m3fn) UNet weights + fp8 activations (E8M0 block scales) into the ResBlock convs / proj_in / qkv / GEGLU on the fp8 MFMA, "
+                    "bf16 residual stream, fp32 accumulate",
+             "fp8w": "fp8 (e4m3fn) UNet weights, bf16 activations, fp32 accumulate"}[dname]
     workload = f"{cname}:{px}x{px}:S{S}:B{B}:{dname}"
     result = {
         "metric": f"{px}x{px} {S}-step DDIM images/sec", "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -393,7 +397,7 @@ def main():
             vae._engines = {k: v for k, v in vae._engines.items() if v is not e32}
             del e32, f32_img, fast_img
             torch.cuda.empty_cache()
-        key = {"bf16": "rf_conv_gemm[bf16]", "f32": "rf_conv_gemm[f32]", "fp8": "rf_conv_gemm[fp8w]"}[dname]
+        key = {"bf16": "rf_conv_gemm[bf16]", "f32": "rf_conv_gemm[f32]", "fp8": "rf_conv_gemm[fp8]", "fp8w": "rf_conv_gemm[fp8w]"}[dname]
         if key not in fam:
             key = "rf_conv_gemm[bf16]"
         dom = fam[key]

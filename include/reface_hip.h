@@ -103,6 +103,10 @@ typedef struct rf_conv_gemm_desc {
     /* out_dtype RF_BF16.  Replaces the same nn.Conv2d / nn.Linear calls with both operands in fp8 (BASELINE configs[4]). */
     const void* ascale;
     int32_t as_ld;
+    /* out_dtype = RF_FP8_E4M3 (fp8 x fp8 path with act = GEGLU only): out receives the N/2 gated values as e4m3fn bytes (ldo in bytes) and oscale */
+    /* one E8M0 byte per (row, 32 output columns), row pitch os_ld -- the A operand of the following ff.net.2 GEMM (attention.py:60). */
+    void* oscale;
+    int32_t os_ld;
 } rf_conv_gemm_desc;
 
 int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream);

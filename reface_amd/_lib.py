@@ -37,6 +37,7 @@ class ConvGemmDesc(C.Structure):
         ("gn_part1", C.c_void_p), ("gn_cpg1", C.c_int32), ("gn_coff1", C.c_int32), ("gn_slot1", C.c_int32), ("gn_nchunks1", C.c_int32),
         ("w_dtype", C.c_int32), ("wscale", C.c_void_p),
         ("ascale", C.c_void_p), ("as_ld", C.c_int32),
+        ("oscale", C.c_void_p), ("os_ld", C.c_int32),
     ]
 
 

@@ -54,6 +54,8 @@ struct GemmParams {
     int epi2_ok;     // host only: operand alignment / feature set allow the direct (register -> global) epilogue
     int dbg;         // RF_GEMM_DBG (timing experiments only): bit 0 = skip the epilogue, bit 1 = skip the main loop
     const float* wscale;   // W8 kernels: per-output-channel power-of-two scale of the fp8 (e4m3fn) weights
+    void* oscale;          // A8 kernels with GEGLU: `out` receives e4m3fn bytes (pitch ldo BYTES) and oscale one E8M0 code per (row, 32 output columns)
+    int os_ld;
     const void* ascale;    // A8 kernels (fp8 activations): E8M0 scale bytes, one per (pixel, 32-channel block), pixel pitch as_ld bytes (a multiple of 4)
     int as_ld;
     unsigned as_bytes;
@@ -90,7 +92,11 @@ typedef int v8i_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void mma_mx8(f32x16_t& acc, const u32x4_t& a0, const u32x4_t& a1, int sa, const u32x4_t& b0, const u32x4_t& b1, int sb) {
     const v8i_t a = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
     const v8i_t b = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
-    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, sa, 0, sb);
+    // inline asm, volatile: as a builtin (a pure call) hipcc sinks all MFMAs of a K tile to the end of the loop body, past every fragment
+    // load and the barrier -- three fragment sets live (256 VGPRs + scratch) and no LDS latency hidden under the matrix pipe.  Volatile
+    // statements keep their order against each other and against the loop's wait / barrier statements.  (s_nop 1: wait states between a
+    // VALU write of a scale / operand register and the MFMA that reads it, which the compiler does not pad inside asm.)
+    asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb));
 }
 template <> struct MmaFrag<float> {
     __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
@@ -295,6 +301,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         if (!GLDS)
             for (int i = 0; i < kb0; ++i) advance_k();
     }
+    // K-tile counts are wave-uniform, but hipcc's divergence analysis does not see it through the split-K arithmetic: everything derived from
+    // them (the issue state, the SGPR offsets of the LDS-DMA pieces, the `more` conditions) would live in VGPRs, every DMA piece would sit in a
+    // waterfall loop (v_readfirstlane / v_cmp / s_and_saveexec / branch: ~10 instructions and a serialisation point per piece, nine pieces per
+    // tile right behind the barrier) and every `if (more)` would be an exec-masked region
+    nk = __builtin_amdgcn_readfirstlane(nk);
+    kb0_tiles = __builtin_amdgcn_readfirstlane(kb0_tiles);
     const int lrow = lane & 31, lhalf = lane >> 5;
 
     auto compute_tile = [&](int buf) {
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             // (values computed OUTSIDE the builtin's argument list: a call expression inside it makes hipcc's host pass drop the
             // kernel's stub without a diagnostic)
             char* const b0 = ldsB + w_stage<W8>(kb0_tiles, 0) * BN * 128 + wave_u * 1024;
-            const int so0 = w_soff<W8>(kb0_tiles);
+            const int so0 = __builtin_amdgcn_readfirstlane(w_soff<W8>(kb0_tiles));
 #pragma unroll
             for (int j = 0; j < BV; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(b0 + j * (RPP * 128)), 16, offs[AV + j], so0, 0, 0);
@@ -435,7 +447,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         auto issue_pieces = [&](int buf, int q0, int q1) {
             char* a = ldsA + buf * BM * 128 + wave_u * 1024;
             char* b = ldsB + w_stage<W8>(it, buf) * BN * 128 + wave_u * 1024;
-            const int soA = (CONV ? ic : ia) * 128 + ((X3OK && ph == 2) ? p.lo_off : 0), soB = w_soff<W8>(it);
+            const int soA = __builtin_amdgcn_readfirstlane((CONV ? ic : ia) * 128 + ((X3OK && ph == 2) ? p.lo_off : 0));
+            const int soB = __builtin_amdgcn_readfirstlane(w_soff<W8>(it));
             if (W8 && (it & 1) && q1 > AV) q1 = AV;          // odd tile: its W half arrived with the even tile before it
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
@@ -448,7 +461,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             }
             if constexpr (A8) {          // every call issues the tile's scale piece (q0 is 0 in every call): NP + 1 pieces per wave and tile
                 char* const sdst = ldsS + buf * 2048 + wave_u * 256;
-                const int soS = (CONV ? ic : ia) * 4;
+                const int soS = __builtin_amdgcn_readfirstlane((CONV ? ic : ia) * 4);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) void*)sdst, 4, soffs, soS, 0, 0);
             }
         };
@@ -948,6 +961,22 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                                     unpack16<TO>(rp[h], f);
 #pragma unroll
                                     for (int e = 0; e < 16 / OV; ++e) v[h * (16 / OV) + e] += f[e];
+                                }
+                            }
+                            if constexpr (A8) {
+                                if (p.oscale) {
+                                    // fp8 output for the next fp8 x fp8 GEMM (ff.net.2): this lane holds columns [16 h, 16 h + 16) of a 32-column
+                                    // block of its row, lane ^ 32 the other half: block amax across the two, one E8M0 code, 16 bytes per lane
+                                    float m = 0.f;
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(v[r]));
+                                    const auto sw = __builtin_amdgcn_permlane32_swap(as_u32(m), as_u32(m), false, false);
+                                    const int code = e8m0_for_amax(fmaxf(as_f32(sw[0]), as_f32(sw[1])));
+                                    const u32x2_t q0 = quant8_fp8(v, code), q1 = quant8_fp8(v + 8, code);
+                                    fp8_t* const qrow = (fp8_t*)p.out + (long long)row * p.ldo;
+                                    *(u32x4_t*)(qrow + ocol) = u32x4_t{q0[0], q0[1], q1[0], q1[1]};
+                                    if (lhalf == 0) ((fp8_t*)p.oscale)[(long long)row * p.os_ld + (ocol >> 5)] = (fp8_t)code;
+                                    continue;
                                 }
                             }
                             store16(outp + (long long)row * p.ldo + ocol, v);
@@ -1519,6 +1548,7 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     // (packed: measured neutral-to-negative in situ -- proj_out 4096x1280x1280 with fused statistics 37 -> 63 us, the rest within
     //  noise, r02f -- so it is opt-in: RF_EPI=2)
     const bool packed = !direct && PACKED_OK && epi_env == 2 && ep_common;
+    RF_CHECK(!p.oscale || direct, "rf_conv_gemm: fp8 output needs the direct epilogue (8-wave tile, aligned rows, no split-K)");
     constexpr int smem_pk = BM * BN * 2;
     const int smem_l = (packed && smem_pk > smem) ? smem_pk : smem;
 #define RF_LAUNCH_VARIANT(CONV_, GLDS_, EPI_)                                                                                   \
@@ -1585,6 +1615,7 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
         const bool n320 = !g && N_ % 320 == 0, n256 = N_ % 256 == 0 && !n320;
         const long long mt128 = (p.M + 127) / 128;
         const long long nt = n320 ? N_ / 320 : (n256 ? N_ / 256 : 0);
+        if (n256 && ((p.M + 255) / 256) * nt >= 192) return launch_cfg<T, TO, 4, 2, 2, 4, false>(d, p, conv, st);
         if (nt > 0 && mt128 * nt * pick_splitk(d, p, mt128 * nt, 128) >= 160)
             return n320 ? launch_cfg<T, TO, 4, 2, 1, 5, false>(d, p, conv, st) : launch_cfg<T, TO, 4, 2, 1, 4, false>(d, p, conv, st);
         if (g) return launch_cfg<T, TO, 2, 2, 2, 2, false>(d, p, conv, st);
@@ -1656,15 +1687,18 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
 static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
     using namespace rf;
     RF_CHECK(d != nullptr, "rf_conv_gemm: null descriptor");
+    const bool oq = d->out_dtype == RF_FP8_E4M3;       // fp8 output + block scales (GEGLU of the fp8 x fp8 path)
     const bool x3 = d->dtype == RF_BF16X3;
     RF_CHECK(d->dtype == RF_F32 || d->dtype == RF_BF16 || x3 || d->dtype == RF_FP8_E4M3, "rf_conv_gemm: bad dtype %d", d->dtype);
-    RF_CHECK(d->dtype != RF_FP8_E4M3 || (d->w_dtype == RF_FP8_E4M3 && d->wscale && d->ascale && d->as_ld > 0 && d->as_ld % 4 == 0 && d->out_dtype == RF_BF16 &&
+    RF_CHECK(d->dtype != RF_FP8_E4M3 || (d->w_dtype == RF_FP8_E4M3 && d->wscale && d->ascale && d->as_ld > 0 && d->as_ld % 4 == 0 && (d->out_dtype == RF_BF16 || oq) &&
                                          d->C1 == 0 && d->batch == 1 && d->korder == 0 && d->K % 128 == 0 && (d->C0 % 128 == 0 || (d->KH == 1 && d->KW == 1))),
              "rf_conv_gemm: fp8 activations need fp8 weights + wscale, ascale with a pitch that is a multiple of 4, bf16 output, one source, batch 1, "
              "K a multiple of 128 (zero-padded weights) and, for k x k windows, C0 a multiple of 128");
     RF_CHECK(!x3 || (d->out_dtype == RF_F32 && d->w_dtype == 0 && d->korder == 0 && d->C1 == 0 && d->batch == 1 && d->ld0 >= 2 * d->C0),
              "rf_conv_gemm: split-bf16 operands need fp32 output, one source with pixel pitch >= 2*C0, batch 1, tap-major K");
-    RF_CHECK(d->out_dtype == RF_F32 || d->out_dtype == RF_BF16, "rf_conv_gemm: bad out_dtype %d", d->out_dtype);
+    RF_CHECK(d->out_dtype == RF_F32 || d->out_dtype == RF_BF16 || oq, "rf_conv_gemm: bad out_dtype %d", d->out_dtype);
+    RF_CHECK(!oq || (d->dtype == RF_FP8_E4M3 && d->act == RF_ACT_GEGLU && d->oscale && d->os_ld >= d->N / 64 && !d->residual && d->N % 64 == 0),
+             "rf_conv_gemm: fp8 output is the GEGLU epilogue of the fp8 x fp8 path (oscale, no residual, N a multiple of 64)");
     const bool a8 = d->dtype == RF_FP8_E4M3;           // fp8 activations + E8M0 block scales x fp8 weights (MX-scaled MFMA)
     const int vec = d->dtype == RF_F32 ? 4 : (a8 ? 16 : 8);
     const int ctot = d->C0 + d->C1;
@@ -1712,6 +1746,8 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
     RF_CHECK(!(d->gn_part0 || d->gn_part1) || d->gn_rows > 0, "rf_conv_gemm: gn_part set but gn_rows = %d", d->gn_rows);
     {
         const uintptr_t oa = d->out_dtype == RF_F32 ? 16 : 8;
+        p.oscale = oq ? d->oscale : nullptr;
+        p.os_ld = d->os_ld;
         const int nout = d->act == RF_ACT_GEGLU ? d->N / 2 : d->N;
         bool ok = (d->N % 4 == 0) && (nout % 4 == 0) && (d->ldo % 4 == 0) && ((uintptr_t)d->out % oa == 0) && (d->sO % 4 == 0);
         if (d->residual) ok = ok && (d->ldr % 4 == 0) && ((uintptr_t)d->residual % oa == 0) && (d->sR % 4 == 0);
@@ -1719,7 +1755,7 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
         if (d->rowvec) ok = ok && (d->ldv % 4 == 0) && ((uintptr_t)d->rowvec % 16 == 0);
         p.vec_ok = ok ? 1 : 0;
         // direct epilogue: 16 contiguous output columns per lane, written / read as 16-byte vectors
-        const int es_o = d->out_dtype == RF_F32 ? 4 : 2;
+        const int es_o = d->out_dtype == RF_F32 ? 4 : (oq ? 1 : 2);
         bool e2 = (d->N % 16 == 0) && (nout % 16 == 0) && ((long long)d->ldo * es_o % 16 == 0) && ((uintptr_t)d->out % 16 == 0) &&
                   ((long long)d->sO * es_o % 16 == 0) && d->act != RF_ACT_PRELU;
         if (d->residual) e2 = e2 && ((long long)d->ldr * es_o % 16 == 0) && ((uintptr_t)d->residual % 16 == 0) && ((long long)d->sR * es_o % 16 == 0);

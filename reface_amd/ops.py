@@ -169,7 +169,10 @@ class Fp8Act:
     def Cp(self):
         return self.q.shape[-1]
 
-    def view(self, *lead):
+    def view(self, *shape):
+        """Reshape of the leading dims: ``shape`` is the logical shape (..., C), as for a tensor."""
+        assert shape[-1] == self.C, (shape, self.C)
+        lead = shape[:-1]
         o = object.__new__(Fp8Act)
         o.q, o.scale, o.C = self.q.view(*lead, self.q.shape[-1]), self.scale.view(*lead, self.scale.shape[-1]), self.C
         return o
@@ -294,10 +297,16 @@ def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, 
     a8 = None
     if isinstance(src0, Fp8Act):          # fp8 activations + block scales: K / C0 / ld0 are the PADDED byte counts (the caller passes them)
         a8, src0 = src0, src0.q
-        assert isinstance(W, Fp8Weight) and out.dtype == torch.bfloat16 and src1 is None and not x3
+        assert isinstance(W, Fp8Weight) and (isinstance(out, Fp8Act) or out.dtype == torch.bfloat16) and src1 is None and not x3
+    oq = None
+    if isinstance(out, Fp8Act):           # GEGLU of the fp8 x fp8 path writing fp8 + block scales for ff.net.2
+        oq, out = out, out.q
+        assert a8 is not None and act == ACT_GEGLU and residual is None and oq.C == N // 2
     _require_gpu(src0, W.q if isinstance(W, Fp8Weight) else W, out, src1, bias, rowvec, residual)
     d = ConvGemmDesc()
-    d.dtype, d.out_dtype = (RF_FP8_E4M3 if a8 is not None else code(src0.dtype)), code(out.dtype)
+    d.dtype, d.out_dtype = (RF_FP8_E4M3 if a8 is not None else code(src0.dtype)), (RF_FP8_E4M3 if oq is not None else code(out.dtype))
+    if oq is not None:
+        d.oscale, d.os_ld = _p(oq.scale), oq.scale.stride(-2)
     if a8 is not None:
         d.ascale, d.as_ld = _p(a8.scale), a8.scale.stride(-2)
     wq = None
@@ -328,7 +337,7 @@ def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, 
     d.korder = korder
     ws = workspace if workspace is not None else _default_workspace(src0.device)
     d.workspace, d.workspace_bytes = _p(ws), (ws.numel() * ws.element_size() if ws is not None else 0)
-    l = Launch(lib.rf_conv_gemm, (C.byref(d),), (d, src0, src1, W, out, bias, rowvec, residual, act_vec, ws, wq, a8), name)
+    l = Launch(lib.rf_conv_gemm, (C.byref(d),), (d, src0, src1, W, out, bias, rowvec, residual, act_vec, ws, wq, a8, oq), name)
     if wq is not None and a8 is None:
         # fp8 weights run only on the direct-to-LDS main loop, whose preconditions (one source, 31-bit operand extents, <= 1024^2 outputs,
         # < 4095 samples, whole K tiles per tap) depend on the launch, not only on the weight: ask the library, and give a layer that
@@ -350,11 +359,12 @@ def linear(x, W, out, bias=None, *, act=ACT_NONE, residual=None, rowvec=None, ro
         (M, K), ld0 = x.shape, x.stride(0)
         assert x.stride(1) == 1
     N = W.shape[0]
-    assert W.shape[1] == K and out.stride(1) == 1, (tuple(W.shape), K)
+    ldo = out.q.stride(0) if isinstance(out, Fp8Act) else out.stride(0)
+    assert W.shape[1] == K and (isinstance(out, Fp8Act) or out.stride(1) == 1), (tuple(W.shape), K)
     return conv_gemm(x, W, out, M=M, N=N, K=K, C0=K, ld0=ld0, Hin=1, Win=M, Hout=1, Wout=M, bias=bias, act=act,
                      residual=residual, ldr=(residual.stride(0) if residual is not None else 0), rowvec=rowvec,
                      rows_per_sample=rows_per_sample, ldv=(rowvec.stride(0) if rowvec is not None else 0),
-                     ldo=out.stride(0), alpha=alpha, act_vec=act_vec, name=name)
+                     ldo=ldo, alpha=alpha, act_vec=act_vec, name=name)
 
 
 def conv2d(x, W, out, bias=None, *, ksize=3, stride=1, pad=(1, 1), ups=0, x2=None, residual=None, rowvec=None,

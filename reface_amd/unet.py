@@ -333,14 +333,17 @@ class UNetEngine:
             self.pool.put(ln)
         else:
             wg = self.gw8(wg, 1, c) if a8 else self.gw(wg)
-            gg = self.pool.get((nb * M, 4 * c), self.dt)
+            # fp8 mode: the gated hidden tensor leaves the GEGLU epilogue as fp8 + block scales (half the bytes of the widest tensor of the
+            # block) and ff.net.2 runs on the fp8 MFMA too
+            gg = self.aget((nb * M, 4 * c)) if a8 else self.pool.get((nb * M, 4 * c), self.dt)
             self.main.append(ops.linear(ln, wg, gg, bg, act=ops.ACT_GEGLU, name=f"{t}.ff.net.0"))
             if a8:
                 self.aput(ln)
                 ln = self.pool.get((nb * M, c), self.dt)
             x2 = ln
-            self.main.append(ops.linear(gg, self.gw(self.sd[f"{t}.ff.net.2.weight"]), x2, self.f32(f"{t}.ff.net.2.bias"), residual=x1, name=f"{t}.ff.net.2"))
-            self.pool.put(gg)
+            w2 = self.sd[f"{t}.ff.net.2.weight"]
+            self.main.append(ops.linear(gg, self.gw8(w2, 1, 4 * c) if a8 else self.gw(w2), x2, self.f32(f"{t}.ff.net.2.bias"), residual=x1, name=f"{t}.ff.net.2"))
+            (self.aput if a8 else self.pool.put)(gg)
         self.pool.put(x1)
         y = dst if dst is not None else self.pool.get((nb * B, H, W, c), self.dt)
         w_po, b_po = self.gw(self.sd[f"{p}.proj_out.weight"].reshape(c, c)), self.f32(f"{p}.proj_out.bias")

@@ -720,3 +720,44 @@ def test_norms_fp8_output():
     d = (la.dequant().cpu() - l32.cpu()).abs()
     bm = l32.cpu().reshape(M, Cc // 32, 32).abs().amax(-1).repeat_interleave(32, dim=-1)
     assert (d <= 2.0 ** -4 * l32.cpu().abs() + 2.0 ** -8 * bm + 1e-6).all(), d.max().item()
+
+
+@pytest.mark.parametrize("M,K,F4", [(2048, 320, 1280), (4096, 640, 2560)])
+def test_geglu_fp8_output_feeds_ff2(M, K, F4):
+    """fp8 x fp8 GEGLU whose direct epilogue writes the gated values as e4m3fn + E8M0 block scales (block amax across the lane pair that
+    shares a 32-column block), consumed by the fp8 x fp8 ff.net.2 GEMM.  The quantised hidden tensor must be the rf_quantize_fp8_act
+    quantisation of the exact GEGLU values (codes may differ by one where fp32 evaluation order moves an amax across a power of two),
+    and ff.net.2 on it must match an fp32 reference on the dequantised operands."""
+    dt = torch.bfloat16
+    x = (rnd((M, K), 950) * 0.7).to(dt)
+    xa = ops.Fp8Act((M, K), DEV)
+    ops.quantize_act(x.to(DEV), xa)()
+    w1 = rnd((2 * F4, K), 951) / math.sqrt(K)
+    b1 = rnd((2 * F4,), 952)
+    wp, bp = ops.pack_geglu(w1, b1, torch.float32)
+    fw1 = ops.quantize_fp8_padded(wp.to(DEV), 1, K)
+    hq = ops.Fp8Act((M, F4), DEV)
+    l = ops.linear(xa, fw1, hq, bp.to(DEV), act=ops.ACT_GEGLU)
+    l()
+    torch.cuda.synchronize()
+    assert l.keep[0].out_dtype == 2
+    wd = fw1.dequant()[:, :K].cpu()
+    wv, wg = wd.reshape(F4 // 32, 2, 32, K)[:, 0].reshape(F4, K), wd.reshape(F4 // 32, 2, 32, K)[:, 1].reshape(F4, K)
+    xd = xa.dequant().cpu()
+    gate = F.linear(xd, wg, b1[F4:])
+    href = F.linear(xd, wv, b1[:F4]) * F.gelu(gate)            # erf GELU; the bf16-path kernels use the tanh form (<= 4.8e-4 * |value|)
+    qr, code = _quant_act_ref(href)
+    assert (hq.scale[:, :F4 // 32].cpu().int() - code.int()).abs().max() <= 1
+    d = (hq.dequant().cpu() - href).abs()
+    bm = href.reshape(M, F4 // 32, 32).abs().amax(-1).repeat_interleave(32, dim=-1)
+    vmag = F.linear(xd, wv, b1[:F4]).abs()
+    assert (d <= 2.0 ** -4 * href.abs() + 2.0 ** -8 * bm + 6e-4 * vmag + 1e-6).all(), d.max().item()
+    # ff.net.2 on the quantised hidden tensor
+    w2 = rnd((K, F4), 953) / math.sqrt(F4)
+    b2 = rnd((K,), 954)
+    res, rr = q(rnd((M, K), 955), dt)
+    fw2 = ops.quantize_fp8_padded(w2.to(DEV), 1, F4)
+    out = torch.empty((M, K), dtype=dt, device=DEV)
+    ops.linear(hq, fw2, out, b2.to(DEV), residual=res)()
+    torch.cuda.synchronize()
+    check(out, F.linear(hq.dequant().cpu(), fw2.dequant().cpu(), b2) + rr, dt)
