@@ -149,10 +149,12 @@ def _oracle_chain_check(dump_npz, png_path, S, scale, rows=(0,)):
     d = np.load(dump_npz)
     ucfg, vcfg = P.UNetConfig(**SMALL_UNET), P.VAEConfig(**SMALL_VAE)
     ccfg = P.CLIPVisionConfig(**dict(SMALL_CLIP, patch=14, image=224, proj=768, mapper_layers=5))
-    usd = P.seeded_state_dict(P.unet_param_specs(ucfg), 1234)
-    vsd = P.seeded_state_dict(P.vae_param_specs(vcfg), 55)
-    csd = P.seeded_state_dict(P.clip_param_specs(ccfg), 88)
-    asd = P.seeded_state_dict(P.arcface_param_specs(), 77)
+    # (seeded tensors depend on the FULL key: generate with the prefixes load_model_from_config(--ckpt none) uses, then strip them)
+    strip = lambda sd, pre: {k[len(pre):]: v for k, v in sd.items()}
+    usd = strip(P.seeded_state_dict(P.unet_param_specs(ucfg), 1234, "model.diffusion_model."), "model.diffusion_model.")
+    vsd = strip(P.seeded_state_dict(P.vae_param_specs(vcfg), 55, "first_stage_model."), "first_stage_model.")
+    csd = strip(P.seeded_state_dict(P.clip_param_specs(ccfg), 88, "cond_stage_model."), "cond_stage_model.")
+    asd = strip(P.seeded_state_dict(P.arcface_param_specs(), 77, "face_ID_model.facenet."), "face_ID_model.facenet.")
     heads = P.seeded_state_dict(P.cond_head_specs(), 9)
     r = list(rows)
     T = lambda k: torch.from_numpy(d[k][r])

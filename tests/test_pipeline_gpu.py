@@ -244,9 +244,12 @@ def test_vae_small_vs_reference_golden(golden_dir):
     g = G(golden_dir, "vae_small")
     post = m.encode(torch.tanh(rnd((2, 3, 64, 64), 40)).to(DEV))
     assert maxerr(post.mean, g["mean"]) < 5e-5 and maxerr(post.logvar, g["logvar"]) < 5e-5
-    dec = m.decode(rnd((2, 4, 8, 8), 41).to(DEV))
-    assert dec.shape == g["dec"].shape
-    assert maxerr(dec, g["dec"]) < 5e-5, maxerr(dec, g["dec"])
+    for mode, lim in (("f32", 5e-5), ("bf16x3", 2e-4)):          # exact-fp32 MFMA; split-bf16 operands on the layers wide enough for it (default)
+        m.decode_mode = mode
+        m._engines.clear()
+        dec = m.decode(rnd((2, 4, 8, 8), 41).to(DEV))
+        assert dec.shape == g["dec"].shape
+        assert maxerr(dec, g["dec"]) < lim, (mode, maxerr(dec, g["dec"]))
     # posterior sample + scale (distributions.py:35-37, ddpm.py:857) against the oracle formula
     eps = rnd((2, 4, 8, 8), 44)
     z = post.sample(noise=eps, scale=0.18215)
@@ -261,7 +264,7 @@ def test_vae_full_width_blocks_vs_reference_golden(golden_dir):
     g = G(golden_dir, "vae_blocks")
     cfg = P.VAEConfig()
 
-    def run_block(kind, specs_fn, seed, x, *shape_args):
+    def run_block(kind, specs_fn, seed, x, *shape_args, mode="f32"):
         s = collections.OrderedDict()
         specs_fn(s)
         sd = P.seeded_state_dict(s, seed)
@@ -269,6 +272,7 @@ def test_vae_full_width_blocks_vs_reference_golden(golden_dir):
         from reface_amd.unet import _Pool
         B = x.shape[0]
         eng.cfg, eng.B, eng.dt, eng.dev = cfg, B, torch.float32, torch.device(DEV)
+        eng.x3, eng.n_x3 = mode == "bf16x3", 0
         eng.pool = _Pool(eng.dev)
         eng.sd = {k: v.to(DEV) for k, v in sd.items()}
         eng.gn_partial = torch.empty(B * ops.GN_MAX_CHUNKS * 64, dtype=torch.float64, device=DEV)
@@ -283,7 +287,8 @@ def test_vae_full_width_blocks_vs_reference_golden(golden_dir):
         return y.permute(0, 3, 1, 2)
 
     for tag, cin, cout, hw in (("a", 512, 512, 16), ("b", 512, 256, 16), ("c", 128, 128, 32)):
-        y = run_block("res", lambda s: P._vae_res(s, "r", cin, cout), 56, rnd((1, cin, hw, hw), 42), "r", cin, cout)
-        assert maxerr(y, g[f"res_{tag}_y"]) < 1e-4, (tag, maxerr(y, g[f"res_{tag}_y"]))
+        for mode, lim in (("f32", 1e-4), ("bf16x3", 3e-4)):
+            y = run_block("res", lambda s: P._vae_res(s, "r", cin, cout), 56, rnd((1, cin, hw, hw), 42), "r", cin, cout, mode=mode)
+            assert maxerr(y, g[f"res_{tag}_y"]) < lim, (tag, mode, maxerr(y, g[f"res_{tag}_y"]))
     y = run_block("attn", lambda s: P._vae_attn(s, "a", 512), 57, rnd((1, 512, 16, 16), 43), "a", 512)
     assert maxerr(y, g["attn_y"]) < 1e-4, maxerr(y, g["attn_y"])
