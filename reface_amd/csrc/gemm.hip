@@ -18,6 +18,15 @@
 
 #include "common.h"
 
+// How the LDS-DMA pieces of tile kt+2 are issued behind the barrier that frees their stage (same-box A/B on the whole benchmark, r03):
+//   0: one burst (both waves of every SIMD stall on ~9 x 60-180 issue cycles at the same time)        935.9 / 933.6 ms per batch
+//   1: between the MFMA columns of k-step 3 (the issue slots hide under the matrix pipe)              921.4 / 920.0      <- default
+//   2: as 1 with the barrier ahead of all of k-step 3's columns                                      920.4 / 920.5 (vs 921.5 / 921.6 for 1 on that box)
+//   3: in thirds over k-step 3 and k-steps 0 / 1 of the next tile                                    965.3 / 964.1 (vs 939.9 / 937.0 for 1 on that box)
+#ifndef RF_SPREAD_DMA
+#define RF_SPREAD_DMA 1
+#endif
+
 namespace rf {
 
 struct GemmParams {
@@ -459,7 +468,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(b + (q - AV) * (RPP * 128)), 16, offs[q], soB, 0, 0);
                 }
             }
-            if constexpr (A8) {          // every call issues the tile's scale piece (q0 is 0 in every call): NP + 1 pieces per wave and tile
+            if (A8 && q0 == 0) {          // the call that starts a tile also issues its scale piece: NP + 1 pieces per wave and tile
                 char* const sdst = ldsS + buf * 2048 + wave_u * 256;
                 const int soS = __builtin_amdgcn_readfirstlane((CONV ? ic : ia) * 4);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) void*)sdst, 4, soffs, soS, 0, 0);
@@ -531,12 +540,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 ld_a(nx, nA, nS, nkk);
 #pragma unroll
                 for (int j = 0; j < JS8; ++j) ld_b(j, nB, nkk);
-                if (kk == 1 && more) issue_pieces(stage, 0, NP);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = JS8; j < TN; ++j) {
                     mma_col(cur, j);
                     ld_b(j, nB, nkk);
+                    if (kk == 1) {          // the pieces of tile kt+2 go out between the MFMA columns behind the barrier (RF_SPREAD_DMA 1)
+                        constexpr int COLS = TN - JS8, PPC = (NP + COLS - 1) / COLS;
+                        if (more) issue_pieces(stage, (j - JS8) * PPC, (j - JS8 + 1) * PPC < NP ? (j - JS8 + 1) * PPC : NP);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -573,7 +585,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         // Small wave tiles keep two full fragment sets; the 2x5 wave tile has no registers for that and rotates its B fragments
         // in place: column j of the next k-step is fetched right after column j's MFMAs have been issued.
         constexpr bool ROT = TM * TN > 8;
-        constexpr int JS = ROT ? 2 : 0;      // B columns whose MFMAs go ahead of the first next-fragment reads
+        constexpr int JS_ = ROT ? 2 : 0;      // B columns whose MFMAs go ahead of the first next-fragment reads
         u32x4_t fa[2][TM], fb[W8 ? 1 : 2][W8 ? 1 : TN];
         u32x2_t fbr[W8 ? 2 : 1][W8 ? TN : 1];          // W8: raw 8-byte fp8 fragments
         float ws[W8 ? TN : 1];                         // W8: scale of this lane's W row in each 32-row block
@@ -615,13 +627,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         };
         // one k-step: its MFMAs, the fetch of the next step's fragments (k-step 3 fetches from the other stage, after the
         // barrier; on the last tile that fetch reads stale bytes that are never used) and a third of the next tile's pieces
-        auto phase = [&](auto KK, int stage, bool more, bool deep) {
+        auto phase = [&](auto KK, int stage, bool more, bool deep, bool cont = false) {
             constexpr int kk = decltype(KK)::value;
             constexpr int cur = kk & 1, nx = cur ^ 1;
             constexpr int fbc = ROT ? 0 : cur, fbn = ROT ? 0 : nx;
             constexpr int nkk = (kk + 1) & 3;
             const char* const nA = (kk < 3 ? curA : othA) + fk[nkk];
             const char* const nB = (kk < 3 ? curB : othB) + (fkb[nkk] ^ (kk < 3 ? curPar : othPar));
+#if RF_SPREAD_DMA == 2
+            constexpr int JS = (kk == 3 && ROT) ? 0 : JS_;          // k-step 3: barrier first, every MFMA column behind it takes its share of the pieces
+#else
+            constexpr int JS = JS_;
+#endif
 #pragma unroll
             for (int j = 0; j < JS; ++j) {
                 const u32x4_t bj = bfrag(fbc, j);
@@ -636,6 +653,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 // that holds for all waves: this stage may be overwritten (tile kt+2) and the other stage may be read
                 // (NST > 2: tiles kt+2 .. kt+NST-1 stay in flight behind the one that must have landed -- `deep` says all of them exist)
                 if (NST > 2 && deep) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * NP) : "memory");
+                else if (RF_DBG(p, 64)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // timing decomposition: the pieces are never waited for
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
@@ -643,7 +661,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             for (int i = 0; i < TM; ++i) fa[nx][i] = *(const u32x4_t*)(nA + i * 4096);
 #pragma unroll
             for (int j = 0; j < (ROT ? JS : TN); ++j) load_b(fbn, j, nB + j * 4096);
-            if (kk == 3 && more) issue_pieces(stage, 0, NP);      // 'more' here: tile kt+2 exists
+#if !RF_SPREAD_DMA
+            if (kk == 3 && more && !RF_DBG(p, 32)) issue_pieces(stage, 0, NP);      // 'more' here: tile kt+2 exists  (RF_GEMM_DBG bit 5: no DMA in
+                                                                                    // the main loop -- stale operands, timing decomposition only)
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = JS; j < TN; ++j) {
@@ -655,8 +676,33 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 }
                 if (ROT) {
                     load_b(0, j, nB + j * 4096);
+#if !RF_SPREAD_DMA
                     __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
+#if RF_SPREAD_DMA
+                // the pieces of tile kt+2 go out between the MFMA columns of k-step 3 (their issue slots hide under the matrix pipe) instead of
+                // in one burst behind the barrier, where both waves of a SIMD stall on ~9 x 60-180 issue cycles at the same time
+#if RF_SPREAD_DMA == 3
+                // ... in thirds: behind the barrier of k-step 3, then at k-steps 0 and 1 of the next tile (stage ^ 1 there: the stage that tile's
+                // predecessor freed); the issue state advances after k-step 1
+                if (kk != 2) {
+                    constexpr int G = kk == 3 ? 0 : (kk == 0 ? 1 : 2), gs = G * NP / 3, gn = (G + 1) * NP / 3 - gs, COLS = TN - JS;
+                    const int q0 = gs + (j - JS) * gn / COLS, q1 = gs + (j - JS + 1) * gn / COLS;          // (constants after unrolling)
+                    if (q1 > q0 && !RF_DBG(p, 32)) {
+                        if (kk == 3) { if (more) issue_pieces(stage, q0, q1); }
+                        else if (cont) issue_pieces(stage ^ 1, q0, q1);
+                    }
+                }
+                if (ROT || kk != 2) __builtin_amdgcn_sched_barrier(0);
+#else
+                if (kk == 3) {
+                    constexpr int COLS = TN - JS, PPC = (NP + COLS - 1) / COLS;
+                    if (more && !RF_DBG(p, 32)) issue_pieces(stage, (j - JS) * PPC, (j - JS + 1) * PPC < NP ? (j - JS + 1) * PPC : NP);
+                }
+                if (ROT || kk == 3) __builtin_amdgcn_sched_barrier(0);
+#endif
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -712,11 +758,20 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         for (int kt = 0; kt < nk; ++kt) {
             const int stage = kt & 1;
             const bool more = kt + 2 < nk;
+#if RF_SPREAD_DMA == 3
+            const bool cont = kt >= 1 && kt + 1 < nk;          // tile kt+1's second and third thirds are still to be issued
+            phase(integral_constant<int, 0>{}, stage, more, false, cont);
+            phase(integral_constant<int, 1>{}, stage, more, false, cont);
+            if (kt >= 1 && kt + 2 < nk) next_tile();
+            phase(integral_constant<int, 2>{}, stage, more, false);
+            phase(integral_constant<int, 3>{}, stage, more, false);
+#else
             phase(integral_constant<int, 0>{}, stage, more, false);
             phase(integral_constant<int, 1>{}, stage, more, false);
             phase(integral_constant<int, 2>{}, stage, more, false);
             phase(integral_constant<int, 3>{}, stage, more, false);
             if (kt + 3 < nk) next_tile();
+#endif
             const char* t = curA; curA = othA; othA = t;
             if constexpr (W8) {
                 ++t_abs;

@@ -12,8 +12,10 @@ REFACE_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun
 python3 - <<PY
 import csv, glob, collections, json, re
 def fam(n):
+    if "conv_gemm_kernel<unsigned char" in n: return "rf_conv_gemm[fp8]"          # fp8 activations x fp8 weights (MX-scaled MFMA)
     m = re.search(r"conv_gemm_kernel<(unsigned short|float), (unsigned short|float)", n)
     if m:
+        if m.group(1) == "unsigned short" and m.group(2) == "float": return "rf_conv_gemm[bf16x3]"      # bf16 operands, fp32 out: the split-bf16 VAE convs (+ the UNet's 4-channel out conv)
         if re.search(r", true>\(", n): return "rf_conv_gemm[fp8w]"
         return "rf_conv_gemm[%s]" % ("bf16" if m.group(1) == "unsigned short" else "f32")
     m = re.search(r"rf::(\w+?)_kernel", n)
