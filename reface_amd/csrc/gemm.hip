@@ -88,7 +88,13 @@ __device__ __forceinline__ u32x4_t fp8x8_to_bf16x8(const u32x2_t& r, float scale
 template <typename T> struct MmaFrag;
 template <> struct MmaFrag<bf16_t> {
     __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+#if RF_PIN_MFMA
+        // experiment: MFMAs as volatile asm statements -- their order against each other and against the loop's waits / barrier is then the
+        // source order (what fixed the fp8 x fp8 loop, where the builtin form was sunk below every fragment load)
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+#else
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+#endif
     }
 };
 template <> struct MmaFrag<fp8_t> {      // (the fp8 x fp8 path has its own main loop with block scales; this keeps the shared lambdas well-formed)
@@ -627,6 +633,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         };
         // one k-step: its MFMAs, the fetch of the next step's fragments (k-step 3 fetches from the other stage, after the
         // barrier; on the last tile that fetch reads stale bytes that are never used) and a third of the next tile's pieces
+        const bool late = RF_SPREAD_DMA == 4 && NT == 512 && wave_u >= 4;
         auto phase = [&](auto KK, int stage, bool more, bool deep, bool cont = false) {
             constexpr int kk = decltype(KK)::value;
             constexpr int cur = kk & 1, nx = cur ^ 1;
@@ -695,6 +702,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                     }
                 }
                 if (ROT || kk != 2) __builtin_amdgcn_sched_barrier(0);
+#elif RF_SPREAD_DMA == 4
+                // 8-wave blocks: the waves that share a SIMD issue at different times -- waves 0-3 behind the barrier of k-step 3 (tile kt+2 into
+                // the stage just freed), waves 4-7 at k-step 0 of the next tile (`cont`: into stage ^ 1) -- so that one wave of every SIMD feeds
+                // the matrix pipe while the other is stalled on the address path
+                if (kk == 3 || kk == 0) {
+                    constexpr int COLS = TN - JS, PPC = (NP + COLS - 1) / COLS;
+                    const int q0 = (j - JS) * PPC, q1 = (j - JS + 1) * PPC < NP ? (j - JS + 1) * PPC : NP;
+                    if (kk == 3) { if (more && !late) issue_pieces(stage, q0, q1); }
+                    else if (cont && late) issue_pieces(stage ^ 1, q0, q1);
+                }
+                if (ROT || kk == 3 || kk == 0) __builtin_amdgcn_sched_barrier(0);
 #else
                 if (kk == 3) {
                     constexpr int COLS = TN - JS, PPC = (NP + COLS - 1) / COLS;
@@ -758,7 +776,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         for (int kt = 0; kt < nk; ++kt) {
             const int stage = kt & 1;
             const bool more = kt + 2 < nk;
-#if RF_SPREAD_DMA == 3
+#if RF_SPREAD_DMA == 4
+            const bool cont = kt >= 1 && kt + 1 < nk;          // late waves: tile kt+1 is still to be issued (k-step 0)
+            phase(integral_constant<int, 0>{}, stage, more, false, cont);
+            if (late && kt >= 1 && kt + 2 < nk) next_tile();
+            phase(integral_constant<int, 1>{}, stage, more, false);
+            phase(integral_constant<int, 2>{}, stage, more, false);
+            phase(integral_constant<int, 3>{}, stage, more, false);
+            if (!late && kt + 3 < nk) next_tile();
+#elif RF_SPREAD_DMA == 3
             const bool cont = kt >= 1 && kt + 1 < nk;          // tile kt+1's second and third thirds are still to be issued
             phase(integral_constant<int, 0>{}, stage, more, false, cont);
             phase(integral_constant<int, 1>{}, stage, more, false, cont);
@@ -1575,6 +1601,11 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     const int skr = sk_rows_for(p.M, p.N);
     const int st_rows = p.splitk > 1 ? skr : BM, st_cols = p.splitk > 1 ? SK_COLS : BN;
     if (W8 || A8) RF_CHECK(p.glds, "rf_conv_gemm: fp8 operands need the direct-to-LDS main loop (one source, K and channel count multiples of the K tile)");
+    if (p.oscale) {            // fp8 GEGLU output exists only in the direct epilogue: decided here so that rf_conv_gemm_plan reports it
+        constexpr bool DOK = (WM * WN == 8) || (TM * TN == 5) || (TM * TN >= 16) || A8;
+        RF_CHECK(DOK && TN % 2 == 0 && p.glds && p.epi2_ok && p.splitk == 1,
+                 "rf_conv_gemm: fp8 output needs the direct epilogue (even TN, aligned rows, no split-K) -- this launch got a %d x %d tile", BM, BN);
+    }
     if (p.plan) { p.plan[0] = st_rows; p.plan[1] = st_cols; p.plan[2] = p.splitk; return 0; }
     if (p.gn_rows > 0) {
         RF_CHECK(p.gn_rows % st_rows == 0 && p.M % p.gn_rows == 0 && d->batch == 1 && d->act != RF_ACT_GEGLU,
@@ -1595,7 +1626,8 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     // RF_EPI=0 forces EPI 0, RF_EPI=1 / 2 allow only that fast form (A/B runs).
     static const int epi_env = tune_env("RF_EPI", -1);
     constexpr bool PACKED_OK = sizeof(TO) == 2 && !A8;
-    constexpr bool DIRECT_OK = (WM * WN == 8) || (TM * TN == 5) || (TM * TN >= 16);
+    constexpr bool DIRECT_OK = (WM * WN == 8) || (TM * TN == 5) || (TM * TN >= 16) || std::is_same<T, fp8_t>::value;      // (fp8 x fp8: every tile --
+                                                                                          // the GEGLU epilogue with fp8 output exists only in this form)
     const bool ep_common = p.glds && p.epi2_ok && p.splitk == 1 && (!p.rowvec || p.rows_per_sample % BM == 0) &&
                            (d->act == RF_ACT_NONE || (d->act == RF_ACT_GEGLU && TN % 2 == 0));
     static const int gn_direct = tune_env("RF_EPI_GN", 1);      // 0: fused statistics keep EPI 0

@@ -673,10 +673,12 @@ def test_linear_fp8_act(M, N, K, kind):
     check(out, ref, dt)
 
 
-@pytest.mark.parametrize("case", ["c320", "c640s", "c128"])
+@pytest.mark.parametrize("case", ["c320", "c640s", "c128", "down", "up"])
 def test_conv_fp8_act(case):
     dt = torch.bfloat16
-    B, H, W_, Ci, Co = {"c320": (2, 16, 16, 320, 320), "c640s": (2, 8, 8, 640, 640), "c128": (1, 12, 10, 128, 96)}[case]
+    B, H, W_, Ci, Co = {"c320": (2, 16, 16, 320, 320), "c640s": (2, 8, 8, 640, 640), "c128": (1, 12, 10, 128, 96), "down": (2, 16, 16, 320, 320),
+                        "up": (2, 8, 8, 640, 640)}[case]
+    stride, ups = (2 if case == "down" else 1), (1 if case == "up" else 0)
     x = (rnd((B, H, W_, Ci), 936) * 0.8).to(dt)
     xa = ops.Fp8Act((B, H, W_, Ci), DEV)
     ops.quantize_act(x.to(DEV), xa)()
@@ -684,12 +686,13 @@ def test_conv_fp8_act(case):
     b = rnd((Co,), 938)
     rv = rnd((B, Co), 939)
     fw = ops.quantize_fp8_padded(ops.pack_conv_weight(w, torch.float32).to(DEV), 9, Ci)
-    out = torch.empty((B, H, W_, Co), dtype=dt, device=DEV)
-    ops.conv2d(xa, fw, out, b.to(DEV), rowvec=rv.to(DEV))()
+    Ho, Wo = (2 * H, 2 * W_) if ups else (H // stride, W_ // stride)
+    out = torch.empty((B, Ho, Wo, Co), dtype=dt, device=DEV)
+    ops.conv2d(xa, fw, out, b.to(DEV), rowvec=rv.to(DEV), stride=stride, ups=ups)()
     torch.cuda.synchronize()
     Cp = xa.Cp
     wd = fw.dequant().cpu().reshape(Co, 9, Cp)[:, :, :Ci].reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2)
-    ref = _conv_ref(xa.dequant().cpu(), wd, b, 1, (1, 1, 1, 1), 0) + rv[:, None, None, :]
+    ref = _conv_ref(xa.dequant().cpu(), wd, b, stride, (1, 1, 1, 1), ups) + rv[:, None, None, :]
     check(out, ref, dt)
 
 

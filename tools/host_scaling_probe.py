@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Host-side scaling probe for the 8-GPU run (the only scaling risk of the sharded path is host contention).
+
+Runs the HOST half of scripts/inference_test_bench.py -- the CelebA reader behind a DataLoader (4 worker processes, as the reference),
+the landmark-prefetch thread slot and the PNG writer thread (reface_amd/output.OutputWriter: 6 PNG files per image) -- with the GPU
+replaced by a sleep of the measured per-batch device time, in 1 process and then in N processes at once (one per GPU of a node), on a
+synthetic CelebAMask-HQ tree.  Reports per-process ms per batch of 8: the host half must stay under the device time of a batch
+(~900 ms for 8 images on MI355X) in all N processes at once for the >= 7.5x target to be reachable.  CPU only; no GPU is touched.
+
+  python tools/host_scaling_probe.py [--procs 8] [--batches 6] [--device-ms 900]
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def make_tree(root, n):
+    import numpy as np
+    from PIL import Image
+    os.makedirs(os.path.join(root, "CelebA-HQ-img"), exist_ok=True)
+    os.makedirs(os.path.join(root, "CelebA-HQ-mask", "Overall_mask"), exist_ok=True)
+    rng = np.random.default_rng(0)
+    for i in list(range(28000, 28000 + n)) + list(range(29000, 29000 + n)):
+        Image.fromarray(rng.integers(0, 256, (1024, 1024, 3), dtype=np.uint8)).save(os.path.join(root, "CelebA-HQ-img", f"{i}.jpg"), quality=90)
+        Image.fromarray(rng.integers(0, 19, (512, 512), dtype=np.uint8)).save(os.path.join(root, "CelebA-HQ-mask", "Overall_mask", f"{i}.png"))
+
+
+def worker(tree, outdir, batches, device_ms, B=8):
+    import numpy as np
+    import torch
+    from reface_amd import output as O
+    from reface_amd.data import CelebAdataset
+    torch.set_num_threads(1)
+    ds = CelebAdataset(dataset_dir=tree, n_targets=batches * B)
+    loader = torch.utils.data.DataLoader(ds, batch_size=B, num_workers=4, shuffle=False)
+    O.make_dirs(outdir) if hasattr(O, "make_dirs") else [os.makedirs(os.path.join(outdir, d), exist_ok=True) for d in ("results", "grid", "samples")]
+    writer = O.OutputWriter(outdir)
+    t0 = time.perf_counter()
+    host_ms = []
+    n = 0
+    for target, prior, kw, ids in loader:
+        t_host = time.perf_counter()
+        time.sleep(device_ms / 1e3)                      # the device's share of the batch (sampling + decode are queued, the host is free)
+        res = np.random.rand(target.shape[0], 3, 512, 512).astype(np.float32)
+        ref = np.random.rand(target.shape[0], 3, 512, 512).astype(np.float32)
+        writer.submit(list(ids), res, target.float().numpy(), kw["inpaint_image"].float().numpy(), kw["inpaint_mask"].float().numpy(), ref)
+        host_ms.append(1e3 * (time.perf_counter() - t_host) - device_ms)
+        n += 1
+        if n == 1:
+            t0 = time.perf_counter()                     # steady state: the first batch carries the DataLoader workers' start-up
+        if n >= batches:
+            break
+    writer.close()
+    total = 1e3 * (time.perf_counter() - t0)
+    print(json.dumps({"batches": n, "ms_per_batch": total / max(n - 1, 1), "host_ms_on_launch_thread": sum(host_ms[1:]) / max(len(host_ms) - 1, 1)}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--procs", type=int, default=8)
+    ap.add_argument("--batches", type=int, default=6)
+    ap.add_argument("--device-ms", type=float, default=900.0)
+    ap.add_argument("--worker", nargs=2, default=None)
+    a = ap.parse_args()
+    if a.worker:
+        worker(a.worker[0], a.worker[1], a.batches, a.device_ms)
+        return
+    with tempfile.TemporaryDirectory() as tmp:
+        tree = os.path.join(tmp, "CelebAMask-HQ")
+        make_tree(tree, a.batches * 8)
+        out = {}
+        for n in (1, a.procs):
+            ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", tree, os.path.join(tmp, f"out_{n}_{r}"), "--batches", str(a.batches),
+                                    "--device-ms", str(a.device_ms)], stdout=subprocess.PIPE, text=True) for r in range(n)]
+            rs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in ps]
+            out[n] = {"ms_per_batch_max": max(r["ms_per_batch"] for r in rs), "ms_per_batch_mean": sum(r["ms_per_batch"] for r in rs) / n,
+                      "host_ms_on_launch_thread_max": max(r["host_ms_on_launch_thread"] for r in rs)}
+        out["cpus"] = len(os.sched_getaffinity(0))
+        out["device_ms_assumed"] = a.device_ms
+        out["verdict"] = ("host half hides under the device time in all %d processes" % a.procs
+                          if out[a.procs]["ms_per_batch_max"] < 1.05 * max(a.device_ms, out[1]["ms_per_batch_max"]) else
+                          "host half EXCEEDS the device time with %d processes: scaling would be host-bound on this machine" % a.procs)
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
