@@ -184,8 +184,14 @@ class DDIMSampler(object):
         ops.run(eng.make_emb_launches(t_all, table))
         coefs = torch.flip(self.ddim_coefs, dims=[0]).contiguous().to(dev)      # row i <-> index S-1-i
         coefs = torch.cat([coefs, torch.zeros((S, 3), dtype=F32, device=dev)], dim=1).contiguous()
+        # The reference draws torch.randn(shape) on the device at EVERY step, used or not (ddim.py:371 via util.py:264-267: at eta = 0 the
+        # draw is multiplied by sigma = 0).  The same S separate draws are made here, up front and in the same order behind the x_T draw, so
+        # that the device generator leaves a sample() call in the reference's state (seeded runs stay aligned from batch to batch) and, at
+        # eta > 0, the steps see the reference's numbers.
+        if x_noise is None:
+            draws = [torch.randn(shape, device=dev) for _ in range(S)]
         if with_noise:
-            noise_all = x_noise.to(device=dev, dtype=F32) if x_noise is not None else torch.randn((S,) + tuple(shape), device=dev)
+            noise_all = x_noise.to(device=dev, dtype=F32) if x_noise is not None else torch.stack(draws)
 
         flagged = [i for i in range(S) if (S - i - 1) % log_every_t == 0 or i == 0]       # ddim.py:247 (index == total_steps - 1 <=> i == 0)
         per_step_host = bool(callback or img_callback)

@@ -86,13 +86,18 @@ def paths(outdir, sid):
 class OutputWriter:
     """PNG encoding off the launch thread: ``submit`` takes host arrays of one batch and returns at once; ``close`` drains."""
 
-    def __init__(self, outdir, skip_grid=False, depth=4):
+    def __init__(self, outdir, skip_grid=False, depth=4, threads=4):
+        # One job per IMAGE, `threads` workers: the six PNG encodes of an image are ~0.3 s of zlib on incompressible content (zlib runs
+        # outside the GIL), so a single worker caps the CLI at ~3 images/s -- below one MI355X (tools/host_scaling_probe.py: 2.86 s per
+        # batch of 8 with one worker against 0.9 s of device time)
         self.outdir, self.skip_grid = outdir, skip_grid
-        self.q = queue.Queue(maxsize=depth)
+        self.q = queue.Queue(maxsize=depth * 8)
         self.err = None
         self.n = 0
-        self.t = threading.Thread(target=self._run, daemon=True)
-        self.t.start()
+        self.lock = threading.Lock()
+        self.ts = [threading.Thread(target=self._run, daemon=True) for _ in range(max(1, threads))]
+        for t in self.ts:
+            t.start()
 
     def _run(self):
         from PIL import Image
@@ -101,12 +106,12 @@ class OutputWriter:
             if job is None:
                 return
             try:
-                ids, res, tgt, inp, msk, ref = job
-                for i, sid in enumerate(ids):
-                    arrs = compose(res[i], tgt[i], inp[i], msk[i], ref[i], skip_grid=self.skip_grid)
-                    p = paths(self.outdir, sid)
-                    for k, a in arrs.items():
-                        Image.fromarray(a).save(p[k])
+                sid, res, tgt, inp, msk, ref = job
+                arrs = compose(res, tgt, inp, msk, ref, skip_grid=self.skip_grid)
+                p = paths(self.outdir, sid)
+                for k, a in arrs.items():
+                    Image.fromarray(a).save(p[k])
+                with self.lock:
                     self.n += 1
             except Exception as e:          # surfaced on the next submit / close
                 self.err = e
@@ -114,11 +119,14 @@ class OutputWriter:
     def submit(self, ids, result01, target, inpaint_image, inpaint_mask, ref512):
         if self.err is not None:
             raise self.err
-        self.q.put((list(ids), result01, target, inpaint_image, inpaint_mask, ref512))
+        for i, sid in enumerate(ids):
+            self.q.put((sid, result01[i], target[i], inpaint_image[i], inpaint_mask[i], ref512[i]))
 
     def close(self):
-        self.q.put(None)
-        self.t.join()
+        for _ in self.ts:
+            self.q.put(None)
+        for t in self.ts:
+            t.join()
         if self.err is not None:
             raise self.err
         return self.n

@@ -39,6 +39,8 @@ class PLMSSampler(DDIMSampler):
         plan = self._plan(B, H, W, cfg_on, scale, False)
         eng, img, px0 = plan["eng"], plan["img"], plan["px0"]
         img.copy_(torch.randn(shape, device=dev) if x_T is None else x_T.to(device=dev, dtype=F32))
+        for _ in range(total_steps):                              # plms.py:212: one (unused: sigma = 0) device draw per step -- keeps the generator
+            torch.randn(shape, device=dev)                        # state of a seeded run aligned with the reference's from batch to batch
         plan["z"].copy_(z_inpaint.to(device=dev, dtype=F32))
         plan["m"].copy_(mask.to(device=dev, dtype=F32))
         c = cond.to(device=dev, dtype=F32)

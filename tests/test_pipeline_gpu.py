@@ -197,6 +197,32 @@ def test_ddim_no_cfg_matches_oracle():
     assert maxerr(got, ref) < 2e-4, maxerr(got, ref)
 
 
+@pytest.mark.parametrize("which", ["ddim", "plms"])
+def test_sampler_leaves_device_rng_in_reference_state(which):
+    """The reference draws x_T (ddim.py:211 / plms.py:125) and then ONE torch.randn(shape) on the device per step even at eta = 0
+    (ddim.py:371 / plms.py:212 via util.py:264-267).  A seeded run must therefore leave the device generator where S + 1 draws leave it,
+    and start from the same x_T -- batch i + 1 of a seeded CLI run then sees the reference's noise."""
+    from reface_amd.ddim import DDIMSampler
+    from reface_amd.plms import PLMSSampler
+    unet = make_unet(SMALL_UNET, 7)
+    _, z_inp, mask, c, uc = _ddim_inputs()
+    S, shape = 5, (2, 4, 16, 16)
+    sampler = (DDIMSampler if which == "ddim" else PLMSSampler)(_LDMStub(unet))
+    kw = dict(S=S, conditioning=c.to(DEV), batch_size=2, shape=[4, 16, 16], verbose=False, eta=0.0, unconditional_guidance_scale=3.5,
+              unconditional_conditioning=uc.to(DEV), test_model_kwargs={"inpaint_image": z_inp.to(DEV), "inpaint_mask": mask.to(DEV)})
+    torch.manual_seed(1234)
+    got, _ = sampler.sample(x_T=None, **kw)
+    after = torch.randn(shape, device=DEV)
+    torch.manual_seed(1234)
+    x_T = torch.randn(shape, device=DEV)
+    for _ in range(S):
+        torch.randn(shape, device=DEV)
+    expect_after = torch.randn(shape, device=DEV)
+    assert torch.equal(after, expect_after)
+    ref, _ = sampler.sample(x_T=x_T, **kw)
+    assert torch.equal(got, ref)
+
+
 @pytest.mark.parametrize("S", [5, 10])
 def test_plms_vs_reference_golden(golden_dir, S):
     """PLMSSampler on the HIP engine vs the reference's plms.py (CFG 3.5; improved-Euler first step, Adams-Bashforth after)."""
