@@ -86,7 +86,7 @@ def paths(outdir, sid):
 class OutputWriter:
     """PNG encoding off the launch thread: ``submit`` takes host arrays of one batch and returns at once; ``close`` drains."""
 
-    def __init__(self, outdir, skip_grid=False, depth=4, threads=4):
+    def __init__(self, outdir, skip_grid=False, depth=4, threads=8):
         # One job per IMAGE, `threads` workers: the six PNG encodes of an image are ~0.3 s of zlib on incompressible content (zlib runs
         # outside the GIL), so a single worker caps the CLI at ~3 images/s -- below one MI355X (tools/host_scaling_probe.py: 2.86 s per
         # batch of 8 with one worker against 0.9 s of device time)

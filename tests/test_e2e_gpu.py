@@ -345,3 +345,28 @@ def test_bench_two_ranks_share_gpu():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["value"] == d["value"] and d["ms_per_step"] > 0
     assert d["weights_identical_on_all_ranks"] is True and len(d["weights_checksum_per_rank"]) == 2, d.get("weights_checksum_per_rank")
+
+
+def test_one_inference_caller(tmp_path):
+    """SURVEY 8f.3, last caller: scripts/one_inference.py -- `process_images` / `run_inference` of the reference's one-pair endpoint
+    (one_inference.py:447-487, 521-790) for aligned crops: the endpoint's file flow, stage 2 through the shared batch body, JPEG bytes out;
+    the PNG behind them against the CPU oracle chain (<= 1 LSB)."""
+    import json
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from test_host_cpu import _prepared_swap_tree
+    src_tree = str(tmp_path / "prep")
+    _prepared_swap_tree(src_tree, n_tar=1, n_src=1)
+    import one_inference as OI
+    base, out = str(tmp_path / "base"), str(tmp_path / "out")
+    OI.configure(["--outdir", out, "--Base_dir", base, "--config", os.path.join(ROOT, "tests", "configs", "reface_small.yaml"), "--ckpt", "none",
+                  "--n_samples", "1", "--H", "512", "--W", "512", "--precision", "full", "--num_workers", "0", "--clip_vision_config",
+                  json.dumps(SMALL_CLIP), "--dump_tensors", str(tmp_path / "dump")])
+    buf = OI.process_images(os.path.join(src_tree, "source_cropped", "0.png"), os.path.join(src_tree, "source_mask", "0.png"),
+                            os.path.join(src_tree, "target_cropped", "0.png"), os.path.join(src_tree, "mask_frames", "0.png"), steps=4, scale=3.5)
+    jpg = np.asarray(Image.open(buf))
+    assert jpg.shape == (512, 512, 3)
+    png = os.path.join(out, "results", "0", "000000000000.png")
+    u8 = _oracle_chain_check(tmp_path / "dump" / "batch_0000.npz", png, S=4, scale=3.5)
+    assert np.abs(jpg.astype(int) - u8.astype(int)).mean() < 6.0          # JPEG of the same picture

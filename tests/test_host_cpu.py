@@ -464,3 +464,16 @@ def test_swap_video_cli_surface(tmp_path):
     opt = cli.build_parser().parse_args(["--Base_dir", "B", "--outdir", "O", "--target_video", "x/clip7.mp4", "--src_image", "y/face.jpg"])
     assert cli.prepared_paths(opt) == {"frames": os.path.join("B", "clip7cropped_face"), "masks": os.path.join("B", "clip7mask_frames"),
                                        "src": os.path.join("O", "temp_results", "face.png"), "src_mask": os.path.join("O", "temp_results", "face.jpg")}
+
+
+def test_one_inference_surface():
+    """scripts/one_inference.py: the reference's function names around the shared stage 2; the web UI is refused with a pointer."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import one_inference as OI
+    import inference_swap_selected as SEL
+    assert OI.build_parser is SEL.build_parser and callable(OI.run_inference) and callable(OI.process_images)
+    with pytest.raises(SystemExit, match="outside this build's scope"):
+        OI.main(["--serve"])
+    OI._ARGV = None
+    with pytest.raises(RuntimeError, match="configure"):
+        OI.run_inference()
