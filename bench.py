@@ -447,6 +447,15 @@ def main():
             result["parity_mode"] = {"dtype": "f32", "value": B / el32, "unit": "images/s", "ms_per_step": el32 * 1e3, "steps": 1, "warmup": 1,
                                      "note": "exact-fp32 MFMA mode (v_mfma_f32_32x32x2_f32), the mode the 1e-3 oracle gate is stated for"}
             log(f"[bench] fp32 parity mode: {B / el32:.3f} images/s")
+            # (c) the fast form of the parity mode: fp32 storage / accumulation, split-bf16 GEMM operands (3 bf16 MFMA passes), fp32 attention
+            unet.set_compute_dtype("f32x3")
+            sampler = DDIMSampler(ldm)
+            elx3, _ = timed(one_batch, 1, 1)
+            result["parity_mode_f32x3"] = {"dtype": "f32x3", "value": B / elx3, "unit": "images/s", "ms_per_step": elx3 * 1e3, "steps": 1, "warmup": 1,
+                                           "vs_exact_f32": image_parity(unet, vae, ldm, h, S, args.scale, device),
+                                           "note": "fp32 storage, split-bf16 operand pairs (hi + lo) in three bf16 MFMA passes, fp32 accumulate / attention; "
+                                                   "pinned to the CPU oracle by tests/test_fullsize_gpu.py (1e-3-class bound)"}
+            log(f"[bench] f32x3 parity mode: {B / elx3:.3f} images/s, vs exact fp32: {result['parity_mode_f32x3']['vs_exact_f32']}")
             unet.set_compute_dtype(dtype)
             del sampler
             torch.cuda.empty_cache()

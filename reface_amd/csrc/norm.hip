@@ -230,7 +230,7 @@ constexpr int LN_RPW = 1;          // rows per wave.  4 (loads of four rows in f
 template <typename T, typename TO, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int M, int C, int ldx, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, TO* __restrict__ out, int ldo,
-                                                        fp8_t* __restrict__ sc_out = nullptr, int lds_sc = 0) {
+                                                        fp8_t* __restrict__ sc_out = nullptr, int lds_sc = 0, int split = 0) {
     constexpr int VEC = elem<T>::VEC;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
     const int lane = threadIdx.x & 63;
@@ -304,10 +304,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
                     *(u32x4_t*)(orow + v * VEC) = pack16<float>(y);
                     *(u32x4_t*)(orow + v * VEC + 4) = pack16<float>(y + 4);
                 } else {
-                    u32x2_t h;
-                    h[0] = pack_bf2(y[0], y[1]);
-                    h[1] = pack_bf2(y[2], y[3]);
+                    u32x2_t h, l;
+                    split4_bf16(y, h, l);
                     *(u32x2_t*)(orow + v * VEC) = h;
+                    if (split) *(u32x2_t*)(orow + C + v * VEC) = l;          // RF_BF16X3: [C hi | C lo] per row
                 }
             }
         }
@@ -495,14 +495,16 @@ extern "C" int rf_layernorm(int dtype, const void* x, int M, int C, int ldx, con
                             int out_dtype, void* out, int ldo, void* stream) {
     const int vec = dtype == RF_F32 ? 4 : 8;
     RF_CHECK(dtype == RF_F32 || dtype == RF_BF16, "rf_layernorm: bad dtype %d", dtype);
-    RF_CHECK(out_dtype == RF_F32 || out_dtype == RF_BF16, "rf_layernorm: bad out_dtype");
+    const int split = out_dtype == RF_BF16X3 ? 1 : 0;          // split-bf16 pairs [C hi | C lo] per row (ldo >= 2C), fp32 input
+    RF_CHECK(out_dtype == RF_F32 || out_dtype == RF_BF16 || split, "rf_layernorm: bad out_dtype");
+    RF_CHECK(!split || (dtype == RF_F32 && ldo >= 2 * C), "rf_layernorm: split-bf16 output needs fp32 input and ldo >= 2C");
     RF_CHECK(x && gamma && beta && out && M > 0, "rf_layernorm: bad arguments");
     RF_CHECK((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "rf_layernorm: gamma / beta must be 16-byte aligned");
     RF_CHECK(C % vec == 0 && ldx % vec == 0 && ldo % 8 == 0 && C / vec <= 64 * LN_MAXV, "rf_layernorm: C=%d ldx=%d ldo=%d unsupported", C, ldx, ldo);
     dim3 grid((M + 4 * LN_RPW - 1) / (4 * LN_RPW));
     hipStream_t st = (hipStream_t)stream;
     const int nv = (C / vec + 63) / 64;          // 16-byte vectors per lane
-#define LN_(T, TO, NV) hipLaunchKernelGGL((layernorm_kernel<T, TO, NV>), grid, dim3(256), 0, st, (const T*)x, M, C, ldx, gamma, beta, eps, (TO*)out, ldo)
+#define LN_(T, TO, NV) hipLaunchKernelGGL((layernorm_kernel<T, TO, NV>), grid, dim3(256), 0, st, (const T*)x, M, C, ldx, gamma, beta, eps, (TO*)out, ldo, (fp8_t*)nullptr, 0, split)
 #define LN(T, TO) { if (nv <= 1) LN_(T, TO, 1); else if (nv <= 2) LN_(T, TO, 2); else if (nv <= 3) LN_(T, TO, 3); else LN_(T, TO, LN_MAXV); }
     if (dtype == RF_F32 && out_dtype == RF_F32) LN(float, float)
     else if (dtype == RF_F32) LN(float, bf16_t)

@@ -351,8 +351,16 @@ def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, 
     return l
 
 
-def linear(x, W, out, bias=None, *, act=ACT_NONE, residual=None, rowvec=None, rows_per_sample=0, alpha=1.0, act_vec=None, name="linear"):
-    """out[M, N] = act(x[M, K] @ W[N, K]^T + bias) (+ residual).  x / out may be row-strided 2-D views."""
+def linear(x, W, out, bias=None, *, act=ACT_NONE, residual=None, rowvec=None, rows_per_sample=0, alpha=1.0, act_vec=None, x3=False, name="linear"):
+    """out[M, N] = act(x[M, K] @ W[N, K]^T + bias) (+ residual).  x / out may be row-strided 2-D views.  x3: x is the split-bf16 form
+    [M, 2K] of an fp32 matrix and W comes from pack_x3 ([N, 3K])."""
+    if x3:
+        M, K2 = x.shape
+        K, N = K2 // 2, W.shape[0]
+        assert W.shape[1] == 3 * K and x.stride(1) == 1 and out.stride(1) == 1
+        return conv_gemm(x, W, out, M=M, N=N, K=K, C0=K, ld0=x.stride(0), Hin=1, Win=M, Hout=1, Wout=M, bias=bias, act=act, residual=residual,
+                         ldr=(residual.stride(0) if residual is not None else 0), rowvec=rowvec, rows_per_sample=rows_per_sample,
+                         ldv=(rowvec.stride(0) if rowvec is not None else 0), ldo=out.stride(0), alpha=alpha, act_vec=act_vec, x3=True, name=name)
     if isinstance(x, Fp8Act):             # K = the padded channel count (W from quantize_fp8_padded(w, 1, C))
         M, K, ld0 = x.q.shape[0], x.Cp, x.q.stride(0)
     else:
@@ -515,8 +523,9 @@ def layernorm(x, gamma, beta, out, *, eps=1e-5, name="layernorm"):
         return Launch(lib.rf_layernorm_fp8, (_p(x), M, Cc, x.stride(0), _p(gamma), _p(beta), float(eps), _p(out.q), out.q.stride(0), _p(out.scale),
                                              out.scale.stride(0)), (x, gamma, beta, out.q, out.scale), name)
     _require_gpu(x, gamma, beta, out)
-    return Launch(lib.rf_layernorm, (code(x.dtype), _p(x), M, Cc, x.stride(0), _p(gamma), _p(beta), float(eps), code(out.dtype),
-                                     _p(out), out.stride(0)), (x, gamma, beta, out), name)
+    split = x.dtype == torch.float32 and out.dtype == torch.bfloat16 and out.shape[-1] == 2 * Cc          # split-bf16 pairs (RF_BF16X3 operand)
+    return Launch(lib.rf_layernorm, (code(x.dtype), _p(x), M, Cc, x.stride(0), _p(gamma), _p(beta), float(eps),
+                                     RF_BF16X3 if split else code(out.dtype), _p(out), out.stride(0)), (x, gamma, beta, out), name)
 
 
 def attention(q, k, v, out, *, heads, scale, name="attention"):

@@ -73,6 +73,12 @@ class UNetEngine:
         # "fp8": additionally fp8 ACTIVATIONS (e4m3fn + one E8M0 scale per 32 channels, written by the GroupNorm / LayerNorm passes) into the
         # ResBlock convolutions, proj_in, qkv and GEGLU projections, multiplied on the MX-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4);
         # "fp8w": fp8 weights only (bf16 activations on the bf16 MFMA)
+        # "f32x3": fp32 storage, statistics, attention and epilogues; GEMM operands as split-bf16 pairs (hi + lo = 16 significant bits) in three
+        # bf16 MFMA passes with fp32 accumulation (rf_conv_gemm RF_BF16X3) -- the fast form of the exact-fp32 parity mode
+        self.x3 = dtype == "f32x3"
+        if self.x3:
+            dtype = torch.float32
+        self.n_x3 = 0
         self.w8 = dtype in ("fp8", "fp8w")
         self.a8 = dtype == "fp8"
         self.n_a8 = 0
@@ -134,6 +140,29 @@ class UNetEngine:
 
     def aput(self, a):
         self._apool.setdefault(tuple(a.shape), []).append(a)
+
+    def x3_ok(self, K, cin=None):
+        return self.x3 and ops.x3_eligible(K, cin)
+
+    def split_in(self, x):
+        """f32x3 mode: the split-bf16 form of an fp32 GEMM input that no normalisation pass rewrites (a pooled temporary; the caller
+        returns it with self.pool.put once the consuming launch is appended)."""
+        s_ = self.pool.get(tuple(x.shape[:-1]) + (2 * x.shape[-1],), torch.bfloat16)
+        self.main.append(ops.split_bf16(x, s_, name="split_bf16"))
+        return s_
+
+    def lin(self, x, w2d, out, bias, name, **kw):
+        """out = x W^T (+ epilogue) in the engine's GEMM form: bf16 / fp32 / fp8-weight operands, or (f32x3) split-bf16 pairs -- x may
+        already be split ([M, 2K] bf16 from a normalisation pass), else a split pass is inserted."""
+        K = w2d.shape[1]
+        if self.x3_ok(K):
+            xs = x if x.dtype == torch.bfloat16 else self.split_in(x)
+            self.main.append(ops.linear(xs, ops.pack_x3(w2d), out, bias, x3=True, name=name, **kw))
+            self.n_x3 += 1
+            if xs is not x:
+                self.pool.put(xs)
+        else:
+            self.main.append(ops.linear(x, self.gw(w2d), out, bias, name=name, **kw))
 
     def gw8(self, w2d, taps, cin):
         """fp8 weight of an fp8-activation GEMM: every tap's channel run zero-padded to the 128-byte K tile."""
@@ -232,6 +261,9 @@ class UNetEngine:
         cin = x.shape[3]
         if isinstance(x, ops.Fp8Act):
             return ops.conv2d(x, self.gw8(ops.pack_conv_weight(self.sd[wkey], F32), 9, cin), out, self.f32(bkey), name=name, **kw)
+        if self.x3 and x.dtype == torch.bfloat16:          # split-bf16 input (from _gn(split=True) / split_in): cin is half the stored width
+            self.n_x3 += 1
+            return ops.conv2d(x, ops.pack_x3(ops.pack_conv_weight(self.sd[wkey], F32)), out, self.f32(bkey), x3=True, name=name, **kw)
         ko = ops.conv_korder(cin, self.dt) if self.korder_on else 0
         wp = ops.pack_conv_weight(self.sd[wkey], F32, korder=ko)
         return ops.conv2d(x, wp.to(self.dt) if ko else self.gw(wp, cin), out, self.f32(bkey), korder=ko, name=name, **kw)
@@ -241,8 +273,11 @@ class UNetEngine:
         self.main.append(launch)
         return self.tracker.record(out, launch)
 
-    def _gn(self, x, key, eps, silu, fp8=False):
-        out = self.aget(x.shape) if fp8 else self.pool.get(tuple(x.shape), self.dt)
+    def _gn(self, x, key, eps, silu, fp8=False, split=False):
+        if split:
+            out = self.pool.get(tuple(x.shape[:3]) + (2 * x.shape[3],), torch.bfloat16)
+        else:
+            out = self.aget(x.shape) if fp8 else self.pool.get(tuple(x.shape), self.dt)
         fused = None
         if self.gn_fuse:
             prods = self.tracker.producers(x)
@@ -251,28 +286,36 @@ class UNetEngine:
         if fused is not None:
             self.main += fused[2]
             self.main.append(ops.groupnorm_apply(x, self.f32(key + ".weight"), self.f32(key + ".bias"), out, fused[0], fused[1],
-                                                 eps=eps, silu=silu, name=key))
+                                                 eps=eps, silu=silu, split=split, name=key))
             self.gn_fused += 1
         else:
             self.main += ops.groupnorm(x, self.f32(key + ".weight"), self.f32(key + ".bias"), out, self.gn_partial, eps=eps,
-                                       silu=silu, name=key)
+                                       silu=silu, split=split, name=key)
         return out
 
     def _res(self, p, x, cin, cout, dst):
         B, H, W, _ = x.shape
-        t1 = self._gn(x, f"{p}.in_layers.0", 1e-5, True, fp8=self.a8)
+        t1 = self._gn(x, f"{p}.in_layers.0", 1e-5, True, fp8=self.a8, split=self.x3_ok(9 * cin, cin))
         h1 = self.pool.get((B, H, W, cout), self.dt)
         rv = self.emb_vec(p)
         if self.uniform_t:
             rv = rv.as_strided((B, cout), (0, 1), rv.storage_offset())      # every sample reads row 0 (B = this input's batch)
         self._add(self._conv3(t1, f"{p}.in_layers.2.weight", h1, f"{p}.in_layers.2.bias", f"{p}.in_layers.2", rowvec=rv), h1)
         (self.aput if self.a8 else self.pool.put)(t1)
-        t2 = self._gn(h1, f"{p}.out_layers.0", 1e-5, True, fp8=self.a8)
+        t2 = self._gn(h1, f"{p}.out_layers.0", 1e-5, True, fp8=self.a8, split=self.x3_ok(9 * cout, cout))
         self.pool.put(h1)
         if cin != cout:
             skip = self.pool.get((B, H, W, cout), self.dt)
-            self.main.append(ops.conv2d(x, self.gw(self.sd[f"{p}.skip_connection.weight"].reshape(cout, cin)), skip,
-                                        self.f32(f"{p}.skip_connection.bias"), ksize=1, pad=(0, 0), name=f"{p}.skip_connection"))
+            w_sk = self.sd[f"{p}.skip_connection.weight"].reshape(cout, cin)
+            if self.x3_ok(cin, cin):
+                xs = self.split_in(x)
+                self.main.append(ops.conv2d(xs, ops.pack_x3(w_sk), skip, self.f32(f"{p}.skip_connection.bias"), ksize=1, pad=(0, 0), x3=True,
+                                            name=f"{p}.skip_connection"))
+                self.pool.put(xs)
+                self.n_x3 += 1
+            else:
+                self.main.append(ops.conv2d(x, self.gw(w_sk), skip, self.f32(f"{p}.skip_connection.bias"), ksize=1, pad=(0, 0),
+                                            name=f"{p}.skip_connection"))
         else:
             skip = x
         y = dst if dst is not None else self.pool.get((B, H, W, cout), self.dt)
@@ -364,6 +407,59 @@ class UNetEngine:
         self.pool.put(x2)
         return y
 
+    def _st_x3(self, p, x, c, heads, dst, pair=False):
+        """SpatialTransformer of the f32x3 mode: fp32 tensors, every GEMM on split-bf16 operand pairs -- written by the GroupNorm / LayerNorm
+        passes where one precedes the GEMM, by a split pass otherwise; fp32 attention.  Same graph as _st."""
+        B, H, W, _ = x.shape
+        M, d = B * H * W, c // heads
+        t = f"{p}.transformer_blocks.0"
+        nb = 2 if pair else 1
+        BF = torch.bfloat16
+        g = self._gn(x, f"{p}.norm", 1e-6, False, split=True)
+        tok = self.pool.get((M, c), F32)
+        self.lin(g.view(M, 2 * c), self.sd[f"{p}.proj_in.weight"].reshape(c, c), tok, self.f32(f"{p}.proj_in.bias"), f"{p}.proj_in")
+        self.pool.put(g)
+        ln = self.pool.get((M, 2 * c), BF)
+        self.main.append(ops.layernorm(tok, self.f32(f"{t}.norm1.weight"), self.f32(f"{t}.norm1.bias"), ln, name=f"{t}.norm1"))
+        qkv = self.pool.get((M, 3 * c), F32)
+        wqkv = torch.cat([self.sd[f"{t}.attn1.to_q.weight"].float() * (d ** -0.5 * ops.LOG2E), self.sd[f"{t}.attn1.to_k.weight"].float(),
+                          self.sd[f"{t}.attn1.to_v.weight"].float()], 0)
+        self.lin(ln, wqkv, qkv, None, f"{t}.attn1.qkv")
+        self.pool.put(ln)
+        att = self.pool.get((M, c), F32)
+        q3 = qkv.view(B, H * W, 3 * c)
+        self.main.append(ops.attention(q3[..., :c], q3[..., c:2 * c], q3[..., 2 * c:], att.view(B, H * W, c), heads=heads,
+                                       scale=ops.LN2, name=f"{t}.attn1"))
+        x1 = self.pool.get((nb * M, c), F32)
+        atts = self.split_in(att)
+        w_out, b_out, cv = ops.pack_x3(self.sd[f"{t}.attn1.to_out.0.weight"]), self.f32(f"{t}.attn1.to_out.0.bias"), self.ctx_vec(p)
+        for hf in range(nb):
+            self.main.append(ops.linear(atts, w_out, x1[hf * M:(hf + 1) * M], b_out, residual=tok, rowvec=cv[hf * B:(hf + 1) * B],
+                                        rows_per_sample=H * W, x3=True, name=f"{t}.attn1.to_out"))
+            self.n_x3 += 1
+        for buf in (atts, att, qkv, tok):
+            self.pool.put(buf)
+        ln3 = self.pool.get((nb * M, 2 * c), BF)
+        self.main.append(ops.layernorm(x1, self.f32(f"{t}.norm3.weight"), self.f32(f"{t}.norm3.bias"), ln3, name=f"{t}.norm3"))
+        wg, bg = ops.pack_geglu(self.sd[f"{t}.ff.net.0.proj.weight"], self.sd[f"{t}.ff.net.0.proj.bias"], F32)
+        gg = self.pool.get((nb * M, 4 * c), F32)
+        self.lin(ln3, wg, gg, bg, f"{t}.ff.net.0", act=ops.ACT_GEGLU)
+        self.pool.put(ln3)
+        x2 = self.pool.get((nb * M, c), F32)
+        self.lin(gg, self.sd[f"{t}.ff.net.2.weight"], x2, self.f32(f"{t}.ff.net.2.bias"), f"{t}.ff.net.2", residual=x1)
+        self.pool.put(gg)
+        self.pool.put(x1)
+        y = dst if dst is not None else self.pool.get((nb * B, H, W, c), F32)
+        x2s = self.split_in(x2.view(nb * B, H, W, c))
+        w_po, b_po = ops.pack_x3(self.sd[f"{p}.proj_out.weight"].reshape(c, c)), self.f32(f"{p}.proj_out.bias")
+        for hf in range(nb):
+            self._add(ops.conv2d(x2s[hf * B:(hf + 1) * B], w_po, y[hf * B:(hf + 1) * B], b_po, ksize=1, pad=(0, 0), residual=x, x3=True,
+                                 name=f"{p}.proj_out"), y[hf * B:(hf + 1) * B])
+            self.n_x3 += 1
+        self.pool.put(x2s)
+        self.pool.put(x2)
+        return y
+
     def _block(self, prefix, layers, x, dst):
         """TimestepEmbedSequential (openaimodel.py:80-88); the last layer writes into ``dst``."""
         B = self.B
@@ -382,7 +478,7 @@ class UNetEngine:
             elif l[0] == "res":
                 y = self._res(p, x, l[1], l[2], d)
             elif l[0] == "st":
-                y = self._st(p, x, l[1], l[2], d, pair=pair)
+                y = (self._st_x3 if self.x3 and l[1] % 64 == 0 else self._st)(p, x, l[1], l[2], d, pair=pair)
             elif l[0] in ("down", "up"):
                 # fp8 mode: the residual-stream tensor is quantised by its own pass (1.5 bytes per element) -- the 3x3 convolution behind it has
                 # 9 C of K per output and runs ~1.5x faster on the fp8 MFMA
@@ -390,6 +486,8 @@ class UNetEngine:
                 if self.a8:
                     xc = self.aget(x.shape)
                     self.main.append(ops.quantize_act(x, xc, name=f"{p}.quantize"))
+                elif self.x3_ok(9 * x.shape[3], x.shape[3]):
+                    xc = self.split_in(x)
                 if l[0] == "down":
                     y = d if d is not None else self.pool.get((B, H // 2, W // 2, l[1]), self.dt)
                     self._add(self._conv3(xc, f"{p}.op.weight", y, f"{p}.op.bias", f"{p}.op", stride=2), y)
@@ -398,6 +496,8 @@ class UNetEngine:
                     self._add(self._conv3(xc, f"{p}.conv.weight", y, f"{p}.conv.bias", f"{p}.conv", ups=1), y)
                 if self.a8:
                     self.aput(xc)
+                elif xc is not x:
+                    self.pool.put(xc)
             else:
                 raise ValueError(l)
             if j > 0 and x is not None:
@@ -452,8 +552,14 @@ class UNetEngine:
             else:
                 dst = None
             final = self._block(f"output_blocks.{i}", layers, cats[i], dst)
-        g = self._gn(final, "out.0", 1e-5, True)
-        self.main.append(ops.conv2d(g, ops.pack_conv_weight(self.sd["out.2.weight"], self.dt), self.eps, self.f32("out.2.bias"), name="out.2"))
+        c_fin = final.shape[3]
+        g = self._gn(final, "out.0", 1e-5, True, split=self.x3_ok(9 * c_fin, c_fin))
+        if g.dtype == torch.bfloat16 and self.x3:
+            self.main.append(ops.conv2d(g, ops.pack_x3(ops.pack_conv_weight(self.sd["out.2.weight"], F32)), self.eps, self.f32("out.2.bias"), x3=True,
+                                        name="out.2"))
+            self.n_x3 += 1
+        else:
+            self.main.append(ops.conv2d(g, ops.pack_conv_weight(self.sd["out.2.weight"], self.dt), self.eps, self.f32("out.2.bias"), name="out.2"))
         self.cats = cats
 
     # ------------------------------------------------------------------ execution
@@ -512,7 +618,7 @@ class UNetModel(nn.Module):
         """torch.float32 (exact-fp32 parity mode) | torch.bfloat16 (throughput mode) | "fp8" (BASELINE configs[4]: fp8 e4m3fn GEMM weights
         everywhere + fp8 activations with E8M0 block scales into the ResBlock convs / proj_in / qkv / GEGLU on the fp8 MFMA) | "fp8w" (fp8
         weights, bf16 activations, bf16 MFMA)."""
-        if dtype not in (torch.float32, torch.bfloat16, "fp8", "fp8w"):
+        if dtype not in (torch.float32, torch.bfloat16, "fp8", "fp8w", "f32x3"):
             raise ValueError(f"unsupported UNet compute dtype {dtype!r}")
         self.compute_dtype = dtype
         self._engines.clear()

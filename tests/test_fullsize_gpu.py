@@ -106,7 +106,8 @@ def test_unet_full_width_full_size_vs_oracle(full_unet, hw):
     e32 = (y - ref).abs().max().item()
     assert e32 < 2e-4 * max(1.0, scale), (e32, scale)
     # (2) the sampler's engine (uniform timestep, CFG-shared stem, statistics from GEMM epilogues), fp32 and bf16
-    for dt, lim in ((torch.float32, 2e-4), (torch.bfloat16, 0.05)):
+    # ("f32x3": fp32 storage, split-bf16 GEMM operands in three bf16 MFMA passes -- the fast form of the parity mode, under a 1e-3-class bound)
+    for dt, lim in ((torch.float32, 2e-4), ("f32x3", 8e-4), (torch.bfloat16, 0.05)):
         m.set_compute_dtype(dt)
         eng = m.engine(2, hw, hw, uniform_t=True, cfg_pair=True)
         ops.nchw_to_nhwc(x.to(DEV), eng.x_in)()
@@ -118,8 +119,11 @@ def test_unet_full_width_full_size_vs_oracle(full_unet, hw):
         torch.cuda.synchronize()
         out = out.cpu()
         assert torch.isfinite(out).all()
-        if dt == torch.float32:
+        if dt == "f32x3":
+            assert eng.n_x3 >= 150, eng.n_x3          # every GEMM of the step but conv_in and the fp32 timestep / context path
+        if dt != torch.bfloat16:
             e = (out - ref).abs().max().item()
+            print(f"UNet {hw}x{hw} [{dt}]: max |d| vs oracle = {e:.3e} (|eps| max {scale:.2f})")
             assert e < lim * max(1.0, scale), (dt, e, scale)
         else:                                   # bf16: relative L2 of the whole eps tensor + a max-norm bound, stated
             rel = ((out - ref).norm() / ref.norm()).item()
