@@ -221,6 +221,8 @@ class LatentDiffusion(nn.Module, _DeviceMixin):
         self.model.diffusion_model.set_compute_dtype(dtype)
         if dtype in ("fp8", "fp8w"):       # fp8 GEMM operands are a UNet mode; the towers / VAE encoder take the bf16 activations' dtype
             dtype = torch.bfloat16
+        elif dtype == "f32x3":             # split-bf16 UNet operands (fast parity mode): everything around it stays fp32
+            dtype = torch.float32
         if encoders:
             for m in (getattr(self, "cond_stage_model", None), getattr(getattr(self, "face_ID_model", None), "facenet", None)):
                 if m is not None and hasattr(m, "compute_dtype"):

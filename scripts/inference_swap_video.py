@@ -67,7 +67,7 @@ def build_parser():
     p.add_argument("--ckpt", type=str, default="models/REFace/checkpoints/last.ckpt")
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--rank", type=int, default=0)
-    p.add_argument("--precision", type=str, choices=["full", "autocast", "bf16", "fp8"], default="autocast")
+    p.add_argument("--precision", type=str, choices=["full", "fullx3", "autocast", "bf16", "fp8"], default="autocast")
     p.add_argument("--faceParser_name", default="default", type=str)
     p.add_argument("--faceParsing_ckpt", type=str, default="Other_dependencies/face_parsing/79999_iter.pth")
     p.add_argument("--segnext_config", default="", type=str)
@@ -112,6 +112,8 @@ def main(argv=None):
         model.set_compute_dtype(torch.bfloat16, encoders=True)
     elif opt.precision == "fp8":
         model.set_compute_dtype("fp8", encoders=True)
+    elif opt.precision == "fullx3":                 # the fast form of "full": fp32 storage, split-bf16 GEMM operands (3 bf16 MFMA passes)
+        model.set_compute_dtype("f32x3")
     if opt.plms:
         from ldm.models.diffusion.plms import PLMSSampler
         sampler = PLMSSampler(model)
