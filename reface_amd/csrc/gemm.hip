@@ -1654,7 +1654,12 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
         }                                                                                                                        \
     }
     const int esel = packed ? 2 : (direct ? 1 : 0);
-    static const int deep_env = tune_env("RF_GEMM_DEEP", 0);        // largest grid (blocks) that takes the ring; off by default: 4096x1280x5120 68.3 -> 66.7 us alone, GEMM family 12.63 -> 12.69 ms in situ
+    // The ring of four stages for 128x160 launches of at most one block per CU (4096 x 1280 x K <= 6000: the projections, ff.net.2 and 1x1 skips
+    // of the 16x16 level, 25 launches per step): nothing else covers the single tile of look-ahead there.  Alone (warm weights) it is neutral
+    // (4096x1280x5120 68.3 -> 66.7 us); in situ, where every launch streams weights the previous ones pushed out of the caches, -0.9 % per batch
+    // (tools/exp_r03_10.sh: 921.7 -> 913.5 ms, same box, two runs each).  Forcing the 8x8 level (M = 1024) onto this tile + ring: neutral for the
+    // 3x3 convs, +0.9 % for its small projections.
+    static const int deep_env = tune_env("RF_GEMM_DEEP", 256);        // largest grid (blocks) that takes the ring
     constexpr int smem_deep = NSTD * (BM + BN) * 128 > smem ? NSTD * (BM + BN) * 128 : smem;
     const bool deep = DEEP_OK && p.glds && !packed && !p.x3 && (long long)grid.x * grid.y * grid.z <= deep_env;
     if constexpr (A8) {            // fp8 activations: direct-to-LDS kernels only, staged or direct epilogue

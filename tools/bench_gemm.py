@@ -21,6 +21,7 @@ ap.add_argument("--bc", type=int, default=16)
 ap.add_argument("--json", default=None)
 ap.add_argument("--sustain", type=float, default=0.0, help="also report the rate sustained over this many seconds (power-managed clocks)")
 ap.add_argument("--korder", type=int, default=0)
+ap.add_argument("--cold", type=int, default=0, help="time every launch alone behind a pass over a 1 GB buffer (operands come from HBM, as inside the step)")
 ap.add_argument("--gn", type=int, default=0, help="conv cases also emit the fused GroupNorm statistics of their output")
 args = ap.parse_args()
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -118,6 +119,9 @@ lin("ff2 2560->640 @32", Bc * 1024, 640, 2560)
 lin("geglu 1280->10240 @16", Bc * 256, 10240, 1280, ops.ACT_GEGLU)
 lin("ff2 5120->1280 @16", Bc * 256, 1280, 5120)
 lin("skip1x1 2560->1280 @8", Bc * 64, 1280, 2560)
+lin("proj 1280->1280 @8", Bc * 64, 1280, 1280)
+lin("qkv 1280->3840 @8", Bc * 64, 3840, 1280)
+lin("ff2 5120->1280 @8", Bc * 64, 1280, 5120)
 lin("lin big 5760->320 @64", Bc * 4096, 320, 5760)
 lin("lin big 5760->640 @32", Bc * 1024, 640, 5760)
 lin("proj 640->640 @32", Bc * 1024, 640, 640)
@@ -138,6 +142,24 @@ for name, l, work in cases:
         continue
     for _ in range(3):
         l()
+    if args.cold:
+        flush = globals().setdefault("_flush", torch.zeros(256 << 20, dtype=torch.float32, device=dev))
+        ts, gaps = [], []
+        for _ in range(args.reps):
+            flush.add_(1.0)
+            s, e, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            s.record(stream)
+            l()
+            e.record(stream)
+            e2.record(stream)
+            torch.cuda.synchronize()
+            ts.append(s.elapsed_time(e) * 1e3)
+            gaps.append(e.elapsed_time(e2) * 1e3)
+        us = sorted(ts)[len(ts) // 2] - sorted(gaps)[len(gaps) // 2]
+        rate, unit = (work / us / 1e6, "TFLOP/s") if work > 0 else (-work / us / 1e3, "GB/s")
+        results.append(dict(name=name, us=us, rate=rate, unit=unit, cold=True))
+        print(f"{name:32s} {us:10.1f} us  {rate:9.1f} {unit}   (cold)", flush=True)
+        continue
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     s.record(stream)
