@@ -984,10 +984,24 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         // ---- direct epilogue: lane (row lrow of its 32-row block, half lhalf) holds columns 16*lhalf .. 16*lhalf+15 of every
         // 32-column block of its wave tile.  Host guarantees (launch_typed): N % 16 == 0, 16-byte aligned rows of out / residual /
         // bias / rowvec, no PReLU, rowvec uniform per tile, fused GroupNorm statistics only with act NONE.
+        if (p.splitk > 1) {
+            // split-K partial sums in FRAGMENT order: slab [z][tile] = [wave][i][j][q][lane] x 16 bytes, so that every store instruction of a
+            // wave writes one contiguous KiB (direct fp32 ROW segments -- 64 scattered 16-byte pieces per instruction -- measured slower than
+            // the staged rows, 61.7 vs 56.3 us; this form needs neither LDS nor a barrier).  splitk_reduce_frag_kernel reads them back the same way.
+            f32x4_t* const slab = (f32x4_t*)(p.ws + ((long long)blockIdx.z * (p.tiles_m * p.tiles_n) + (tile_m * p.tiles_n + tile_n)) * (long long)(BM * BN)) + lane;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x4_t* const dst = slab + ((wave * TM + i) * TN + j) * 256;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dst[q * 64] = f32x4_t{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                }
+            return;
+        }
         TO* const outp = (TO*)p.out + zb * p.sO;
         const TO* const resp = p.residual ? (const TO*)p.residual + zb * p.sR : nullptr;
-        constexpr int OV = sizeof(TO) == 2 ? 2 : 4;      // 16-byte vectors per 16 output values (split-K launches never come here: direct
-                                                         // fp32 partial rows measured slower than the staged ones, 61.7 vs 56.3 us)
+        constexpr int OV = sizeof(TO) == 2 ? 2 : 4;      // 16-byte vectors per 16 output values
         auto store16 = [&](TO* dst, const float* v) {
             if (RF_DBG(p, 8)) return;                                                          // experiment: no global stores
             if (RF_DBG(p, 16)) dst = (TO*)p.out + (((dst - (TO*)p.out) * (long long)sizeof(TO)) & 0xFFFFF) / (long long)sizeof(TO);   // experiment: all stores into 1 MB
@@ -1550,6 +1564,107 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
     }
 }
 
+// Split-K second pass over FRAGMENT-ordered slabs (written by the direct-epilogue kernels, see there): one block = one 32-row stripe of one
+// wave tile = TN waves, wave j owns the 32x32 block j of the stripe; lane (row lrow, half lhalf) sums its 16 columns over the z slices with
+// contiguous-KiB loads, then does what the direct epilogue does: alpha, bias + per-sample vector, residual, 16-byte stores, and the fused
+// GroupNorm statistics of the values as stored (slot = 32 rows x 32 TN columns).  act = NONE only (host).
+template <typename TO, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * TN) void splitk_reduce_frag_kernel(const GemmParams p) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int tile = blockIdx.x, tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
+    const int w = blockIdx.y / TM, i = blockIdx.y - w * TM, wm = w / WN, wn = w - wm * WN;
+    const int row0 = tile_m * BM + (wm * TM + i) * 32, row = row0 + lrow;
+    const int coln0 = tile_n * BN + wn * TN * 32;                    // first column of the stripe
+    const int col = coln0 + j * 32 + lhalf * 16;
+    const long long zstride = (long long)p.tiles_m * p.tiles_n * (BM * BN / 4);          // (16-byte units)
+    const f32x4_t* src = (const f32x4_t*)p.ws + (long long)tile * (BM * BN / 4) + ((w * TM + i) * TN + j) * 256 + lane;
+    f32x4_t a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = src[q * 64];
+    for (int z = 1; z < p.splitk; ++z) {
+        src += zstride;
+        f32x4_t b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = src[q * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] += b[q];
+    }
+    const bool live = row < p.M && col < p.N;
+    const bool gn_on = p.gn_rows > 0;
+    constexpr int OV = sizeof(TO) == 2 ? 2 : 4, E = 16 / OV;
+    float y[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) y[e] = 0.f;
+    if (live) {
+        TO* const dst = (TO*)p.out + (long long)row * p.ldo + col;
+        const TO* const resp = p.residual ? (const TO*)p.residual + (long long)row * p.ldr + col : nullptr;
+        const float* const rv = p.rowvec ? p.rowvec + (long long)(row / p.rows_per_sample) * p.ldv + col : nullptr;
+        u32x4_t rq[OV];
+        if (resp) {
+#pragma unroll
+            for (int h = 0; h < OV; ++h) rq[h] = ((const u32x4_t*)resp)[h];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) c = ((const f32x4_t*)(p.bias + col))[q];
+            if (rv) c += ((const f32x4_t*)rv)[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[4 * q + e] = a[q][e] * p.alpha + c[e];
+        }
+#pragma unroll
+        for (int h = 0; h < OV; ++h) {
+            float f[E], v[E];
+            if (resp) unpack16<TO>(rq[h], f);
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = y[h * E + e] + (resp ? f[e] : 0.0f);
+            const u32x4_t wv = pack16<TO>(v);
+            ((u32x4_t*)dst)[h] = wv;
+            if (gn_on) {
+                unpack16<TO>(wv, f);              // statistics of the values as stored
+#pragma unroll
+                for (int e = 0; e < E; ++e) y[h * E + e] = f[e];
+            }
+        }
+    }
+    if (gn_on) {
+        __shared__ float gcs[2][32 * TN];             // column sums / sums of squares of the stripe
+        float gx[32];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { gx[k] = y[k]; gx[16 + k] = y[k] * y[k]; }
+        // butterfly reduce-scatter over the 32 lanes of the half-wave (as in the direct epilogue): lane lrow ends up with the total of value lrow
+#pragma unroll
+        for (int st = 0; st < 5; ++st) {
+            const int m = 16 >> st, n = 16 >> st;
+            const unsigned up = (lrow & m) ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int k = 0; k < n; ++k) {
+                const unsigned a_ = __float_as_uint(gx[k]), b_ = __float_as_uint(gx[k + n]);
+                const float send = __uint_as_float((a_ & up) | (b_ & ~up));
+                const float keep = __uint_as_float((b_ & up) | (a_ & ~up));
+                gx[k] = keep + __shfl_xor(send, m, 64);
+            }
+        }
+        gcs[lrow >> 4][j * 32 + lhalf * 16 + (lrow & 15)] = gx[0];
+        __syncthreads();
+        if (tid < 64) {
+            const int c = tid >> 5, g = tid & 31;
+            if (p.gn_part[c]) {
+                const int cpg = p.gn_cpg[c], base = p.gn_coff[c] + coln0;            // consumer channel of the stripe's first column
+                const int lo = max(0, g * cpg - base), hi = min(min(32 * TN, p.N - coln0), (g + 1) * cpg - base);
+                double sa = 0.0, sq = 0.0;
+                for (int k = lo; k < hi; ++k) { sa += (double)gcs[0][k]; sq += (double)gcs[1][k]; }
+                const int b = row0 / p.gn_rows, mt = (row0 - b * p.gn_rows) / 32;
+                double* o = p.gn_part[c] + (((long long)b * p.gn_nch[c] + p.gn_slot[c] + mt * (p.tiles_n * WN) + tile_n * WN + wn) * 32 + g) * 2;
+                o[0] = sa;
+                o[1] = sq;
+            }
+        }
+    }
+}
+
 // Split-K factor for a launch of `tiles` output tiles, by a two-term cost model: GEMM time at ~600 TFLOP/s stretched by the
 // fraction of the 256 CUs left idle, plus the fp32 partial-sum traffic (write + re-read of sk * M * N floats at ~4 TB/s).
 static int pick_splitk(const rf_conv_gemm_desc* d, const GemmParams& p, long long tiles, int bk) {
@@ -1597,9 +1712,15 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     // split-K for launches that cannot fill the chip: each z-slice owns a K range, partial sums go through the caller's workspace
     p.splitk = pick_splitk(d, p, (long long)p.tiles_m * p.tiles_n, 128 / (int)sizeof(T));
     if (p.splitk > 1) p.ws = (float*)d->workspace;
+    // Split-K through fragment-ordered slabs (direct-epilogue kernels + splitk_reduce_frag_kernel): wherever the reduce pass has nothing to do
+    // but alpha / bias / per-sample vector / residual (+ statistics) on 16-byte aligned rows
+    static const int frag_env = tune_env("RF_SK_FRAG", 1);
+    constexpr bool FRAG_OK = (WM * WN == 8) || (TM * TN == 5) || (TM * TN >= 16) || std::is_same<T, fp8_t>::value;      // (= DIRECT_OK below)
+    const bool frag = FRAG_OK && frag_env && p.splitk > 1 && p.glds && p.epi2_ok && d->act == RF_ACT_NONE && !p.oscale && d->batch == 1 &&
+                      (long long)p.splitk * p.tiles_m * p.tiles_n * BM * BN * 4 <= d->workspace_bytes;
     // statistics tiling: the GEMM tile, or the reduce pass's tile when split-K moves the epilogue there
     const int skr = sk_rows_for(p.M, p.N);
-    const int st_rows = p.splitk > 1 ? skr : BM, st_cols = p.splitk > 1 ? SK_COLS : BN;
+    const int st_rows = p.splitk > 1 ? (frag ? 32 : skr) : BM, st_cols = p.splitk > 1 ? (frag ? 32 * TN : SK_COLS) : BN;
     if (W8 || A8) RF_CHECK(p.glds, "rf_conv_gemm: fp8 operands need the direct-to-LDS main loop (one source, K and channel count multiples of the K tile)");
     if (p.oscale) {            // fp8 GEGLU output exists only in the direct epilogue: decided here so that rf_conv_gemm_plan reports it
         constexpr bool DOK = (WM * WN == 8) || (TM * TN == 5) || (TM * TN >= 16) || A8;
@@ -1653,7 +1774,7 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
             hipLaunchKernelGGL(k, grid, block, smem_l, st, p);                                                                   \
         }                                                                                                                        \
     }
-    const int esel = packed ? 2 : (direct ? 1 : 0);
+    const int esel = packed ? 2 : ((direct || frag) ? 1 : 0);
     // The ring of four stages for 128x160 launches of at most one block per CU (4096 x 1280 x K <= 6000: the projections, ff.net.2 and 1x1 skips
     // of the 16x16 level, 25 launches per step): nothing else covers the single tile of look-ahead there.  Alone (warm weights) it is neutral
     // (4096x1280x5120 68.3 -> 66.7 us); in situ, where every launch streams weights the previous ones pushed out of the caches, -0.9 % per batch
@@ -1680,7 +1801,10 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
         RF_LAUNCH_VARIANT(false, false, 0)
     }
 #undef RF_LAUNCH_VARIANT
-    if (p.splitk > 1)
+    if (p.splitk > 1 && frag) {
+        if constexpr (FRAG_OK)
+            hipLaunchKernelGGL((splitk_reduce_frag_kernel<TO, WM, WN, TM, TN>), dim3(p.tiles_m * p.tiles_n, WM * WN * TM), dim3(64 * TN), 0, st, p);
+    } else if (p.splitk > 1)
     {
         if (skr == 8) hipLaunchKernelGGL((splitk_reduce_kernel<TO, 8>), dim3((p.N + SK_COLS - 1) / SK_COLS, (p.M + 7) / 8), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((splitk_reduce_kernel<TO, 32>), dim3((p.N + SK_COLS - 1) / SK_COLS, (p.M + 31) / 32), dim3(256), 0, st, p);
@@ -1761,6 +1885,15 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
             // too short for split-K to bring the 128x320 grid to size (4096 x 1280 x 1280: 23 us, against 26 us on 128x128 tiles).
             static const int shortk = tune_env("RF_SHORTK", 6000);
             if (n320 && p.K <= shortk && mt128 * (N / 160) >= 256) return launch_cfg<T, TO, 4, 1, 1, 5, W8>(d, p, conv, st);
+            // 64-128 tiles of 256 rows (the 3x3 convs of the 16x16 level, the long-K N = 640 convs of the 32x32 level): split-K 2-4 over the
+            // 256-row tiles rather than 128-row tiles -- the 64x160 wave tile's main loop runs 1.0-1.25 PF where the 32x160 one stays below
+            // 0.95 (6 KB of fragment reads per 5 MFMAs), and the fragment-ordered slabs keep the partial sums cheap
+            static const int sk256_on = tune_env("RF_SK256", 1);
+            if (sk256_on && d->act == RF_ACT_NONE) {
+                const long long blocks = mt256 * nt * pick_splitk(d, p, mt256 * nt, bk);
+                if (blocks > mt256 * nt && blocks <= 4 * mt256 * nt && blocks >= 192 && blocks <= 256)
+                    return n320 ? launch_cfg<T, TO, 4, 2, 2, 5, W8>(d, p, conv, st) : launch_cfg<T, TO, 4, 2, 2, 4, W8>(d, p, conv, st);
+            }
             if (mt128 * nt * pick_splitk(d, p, mt128 * nt, bk) >= 192) {
                 return n320 ? launch_cfg<T, TO, 4, 2, 1, 5, W8>(d, p, conv, st) : launch_cfg<T, TO, 4, 2, 1, 4, W8>(d, p, conv, st);
             }

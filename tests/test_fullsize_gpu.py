@@ -422,6 +422,8 @@ BENCH_GEMMS = [
     ("ib.5.0.in_layers.2 3x3 @32 C640", 16384, 640, 5760, "conv3", None, False),
     ("ob.3.0.in_layers.2 3x3 @16 C2560->1280", 4096, 1280, 23040, "conv3", None, False),
     ("ib.10 3x3 @8 C1280", 1024, 1280, 11520, "conv3", None, True),
+    ("ib.8.0.out_layers.3 3x3 @16 C1280", 4096, 1280, 11520, "conv3", None, True),
+    ("ob.6.0.in_layers.2 3x3 @32 C1280->640", 16384, 640, 11520, "conv3", None, True),
     ("ff.net.0 GEGLU @64", 65536, 2560, 320, "geglu", (256, 256), False),
     ("ff.net.0 GEGLU @32", 16384, 5120, 640, "geglu", (256, 256), False),
     ("ff.net.2 @64", 65536, 320, 1280, "linear_res", (256, 320), False),

@@ -384,6 +384,41 @@ def test_conv_split_k(dt):
     check(out, ref, dt)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,hw,Ci,Co", [(16, 16, 704, 1280), (16, 8, 1280, 1280), (4, 32, 1280, 640)])
+def test_conv_split_k_fragment_slabs(dt, B, hw, Ci, Co):
+    """Split-K through fragment-ordered slabs (direct-epilogue kernels + splitk_reduce_frag_kernel): the 3x3 convs of the 16x16 / 8x8 levels and the
+    long-K N = 640 convs of the 32x32 level, with everything the reduce pass carries -- bias, per-sample vector, residual and the fused
+    GroupNorm statistics of the stored values."""
+    x, xr = q(rnd((B, hw, hw, Ci), 143) * 0.5, dt)
+    w = rnd((Co, Ci, 3, 3), 144) / math.sqrt(Ci * 9)
+    b = rnd((Co,), 145)
+    rv = rnd((B, Co), 146)
+    res, rr = q(rnd((B, hw, hw, Co), 147), dt)
+    out = torch.empty((B, hw, hw, Co), dtype=dt, device=DEV)
+    l = ops.conv2d(x, ops.pack_conv_weight(w, dt).to(DEV), out, b.to(DEV), rowvec=rv.to(DEV), residual=res)
+    bm, bn, sk = ops.gemm_plan(l)
+    assert sk > 1 and bm == 32 and bn in (160, 128), (bm, bn, sk)          # the stripe of the fragment reduce pass
+    fused = ops.fuse_groupnorm_stats(out, [(l, 0, B * hw * hw, 0, Co)])
+    assert fused is not None
+    l()
+    ops.run(fused[2])
+    g, be = rnd((Co,), 148) * 0.2 + 1, rnd((Co,), 149) * 0.2
+    y = torch.empty_like(out)
+    ops.groupnorm_apply(out, g.to(DEV), be.to(DEV), y, fused[0], fused[1], eps=1e-5, silu=True)()
+    torch.cuda.synchronize()
+    wq = w.to(dt).float()
+    ref = (F.conv2d(xr.to(DEV).permute(0, 3, 1, 2), wq.to(DEV), b.to(DEV), padding=1).permute(0, 2, 3, 1).cpu() + rv[:, None, None, :] + rr)
+    check(out, ref, dt)
+    refn = F.silu(F.group_norm(out.float().cpu().permute(0, 3, 1, 2), 32, g, be, 1e-5)).permute(0, 2, 3, 1)
+    check(y, refn, dt)
+    # run-to-run identical (fixed summation order over the z slices)
+    o1 = out.clone()
+    l()
+    torch.cuda.synchronize()
+    assert torch.equal(o1, out)
+
+
 # ------------------------------------------------------------------------------------------------ fp8 weight path (BASELINE configs[4])
 def _fp8_ref(w):
     """CPU reference of rf_quantize_fp8_rows: smallest power-of-two scale with amax / scale <= 448, RNE to OCP e4m3fn."""
