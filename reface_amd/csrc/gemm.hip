@@ -207,6 +207,26 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             if (p.rowvec) colc += p.rowvec[(long long)(m0 / p.rows_per_sample) * p.ldv + n0 + tid];
         }
     }
+#if RF_RES_TOUCH
+    // experiment: pull the residual rows of this tile into L2 now (one dword per 128-byte line, data discarded), so that the epilogue's residual
+    // segments do not wait out HBM latency three times per wave tile
+    uint32_t touch_[4] = {0u, 0u, 0u, 0u};
+    if constexpr (EPI == 1) {
+        if (p.residual && p.splitk == 1) {
+            constexpr int EPL = 128 / (int)sizeof(TO), LPR = (BN + EPL - 1) / EPL;
+            const TO* const rbase = (const TO*)p.residual + zb * p.sR;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = tid + k * NT;
+                const int row = m0 + i / LPR, c = n0 + (i % LPR) * EPL;
+                if (i < BM * LPR && row < p.M && c < p.N) {
+                    const TO* ptr = rbase + (long long)row * p.ldr + c;
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(touch_[k]) : "v"(ptr) : "memory");
+                }
+            }
+        }
+    }
+#endif
     const int r0 = tid >> 3;
     // GLDS: the LDS image of a direct-to-LDS load is lane-linear, so the XOR swizzle moves to the SOURCE: the lane that
     // lands on 16-byte position p of row r fetches k-slot p ^ ((r >> 1) & 7)  (r0 + 32*i keeps (r >> 1) & 7 for every i)
@@ -574,6 +594,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
                 for (int j = 0; j < TN; ++j) ld_b(j, curB, 0);
             }
+#if RF_RES_TOUCH
+            // (the touch loads are older than every piece: the prologue's wait covered them; their registers are free from here on)
+            if (nk == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" ::"v"(touch_[0]), "v"(touch_[1]), "v"(touch_[2]), "v"(touch_[3]));
+#endif
             for (int kt = 0; kt < nk; ++kt) {
                 const int stage = kt & 1;
                 const bool more = kt + 2 < nk;
@@ -754,6 +779,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
             for (int j = 0; j < TN; ++j) load_b(0, j, curB + j * 4096 + (fkb[0] ^ curPar));
         }
+#if RF_RES_TOUCH
+        // (the touch loads are older than every piece: the prologue's wait covered them; their registers are free from here on)
+        if (nk == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::"v"(touch_[0]), "v"(touch_[1]), "v"(touch_[2]), "v"(touch_[3]));
+#endif
         if constexpr (NST > 2) {
             // ring of NST stages: tile kt is multiplied out of stage kt % NST while tiles kt+1 .. kt+NST-1 are in LDS or in flight; the
             // stage it frees takes tile kt+NST.  For launches of at most one block per CU, where no second block covers the latency
@@ -1084,7 +1114,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             // flight.  sched_barrier(0) after every block keeps hipcc from hoisting every load of the unrolled nest to the top (the 2x5
             // wave tile then spills ~170 registers per lane).
             constexpr int NBLK = TM * TN;
-            constexpr int PFD = sizeof(TO) == 2 ? (NBLK < 4 ? NBLK : 4) : 2;      // residual blocks in flight (8 / 16 registers each): the
+#ifndef RF_EPI_PFD
+#define RF_EPI_PFD 4
+#endif
+            constexpr int PFD = sizeof(TO) == 2 ? (NBLK < RF_EPI_PFD ? NBLK : RF_EPI_PFD) : 2;      // residual blocks in flight (8 / 16 registers each): the
                                                                                   // fragment registers of the main loop are free now
             u32x4_t rq[PFD][OV];
             auto load_res = [&](int blk, u32x4_t* r) {
@@ -1677,8 +1710,10 @@ static int pick_splitk(const rf_conv_gemm_desc* d, const GemmParams& p, long lon
     double best_cost = 1e30;
     for (int sk = 1; sk <= maxsk; ++sk) {
         if ((long long)sk * p.M * p.N * 4 > d->workspace_bytes) break;
-        const double fill = (double)(tiles * sk) / 256.0;
-        const double cost = t_gemm / (fill < 1.0 ? fill : 1.0) + (sk > 1 ? (double)sk * p.M * p.N * 8.0 / 4e12 + 3e-6 : 0.0);
+        // (more blocks than CUs: whole rounds -- 288 blocks of one block per CU are two rounds with the second 12 % full)
+        const long long blocks = tiles * sk;
+        const double fill = (double)blocks / (256.0 * (double)((blocks + 255) / 256));
+        const double cost = t_gemm / fill + (sk > 1 ? (double)sk * p.M * p.N * 8.0 / 4e12 + 3e-6 : 0.0);
         if (cost < best_cost) { best_cost = cost; best = sk; }
     }
     return best;
@@ -1876,8 +1911,12 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
             if (mt256 * nt >= 192) {
                 // wave quantisation: 288 tiles of 256 rows (M = 73728, the 96x96 level at B = 4) are two rounds with the second one
                 // 12 % full; quarter-size tiles at two blocks per CU fill the tail (768^2 bench: GEMM family 17.32 -> 16.77 ms per step)
-                const double rounds = (double)(mt256 * nt) / 256.0;
-                if (n320 && rounds / (double)((mt256 * nt + 255) / 256) < 0.6) return launch_cfg<T, TO, 4, 1, 1, 5, W8>(d, p, conv, st);
+                // (also 1.5 rounds: qkv of the 32x32 level, 384 tiles -> 1536 quarter tiles = three full rounds at two blocks per CU; and the
+                //  K = C projections with a residual at the 64x64 level -- 107 FLOP per byte of compulsory traffic, bandwidth-bound: two
+                //  co-resident blocks keep loads, residual reads and stores of different tiles in flight together, 61 -> 48 us with cold
+                //  operands; together -0.7 % per batch, tools/exp_r03_14.sh)
+                const double rounds = (double)(mt256 * nt) / 256.0, rfill = rounds / (double)((mt256 * nt + 255) / 256);
+                if (n320 && (rfill < 0.6 || (rfill < 0.8 && rounds > 1.0) || (d->residual && p.K <= 320))) return launch_cfg<T, TO, 4, 1, 1, 5, W8>(d, p, conv, st);
                 return n320 ? launch_cfg<T, TO, 4, 2, 2, 5, W8>(d, p, conv, st) : launch_cfg<T, TO, 4, 2, 2, 4, W8>(d, p, conv, st);
             }
             // K up to ~90 tiles: two co-resident 4-wave 128x160 blocks per CU (each other's prologue / epilogue cover) beat one

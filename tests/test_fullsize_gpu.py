@@ -91,6 +91,11 @@ def _gemm_tiles(eng):
     return {(l.keep[0].M, l.keep[0].N): ops.gemm_plan(l)[:2] for l in eng.main if l.fn.__name__ == "rf_conv_gemm"}
 
 
+def _gemm_tile_set(eng, M, N):
+    """every (tile rows, tile cols) the launches of one output shape take (the K = C projections with a residual take quarter tiles)"""
+    return {ops.gemm_plan(l)[:2] for l in eng.main if l.fn.__name__ == "rf_conv_gemm" and (l.keep[0].M, l.keep[0].N) == (M, N)}
+
+
 # ------------------------------------------------------------------------------------------------ UNet at 64x64 / 96x96
 @pytest.mark.parametrize("hw", [64, 96])
 def test_unet_full_width_full_size_vs_oracle(full_unet, hw):
@@ -240,7 +245,7 @@ def test_unet_fp8_c4_engine_shape_matches_oracle_rows(full_unet, mode):
     assert eng.n_fp8 >= 150, eng.n_fp8
     tiles = _gemm_tiles(eng)
     if mode == "fp8w":
-        assert tiles[(2 * B * hw * hw, 320)] == (256, 320), tiles[(2 * B * hw * hw, 320)]
+        assert (256, 320) in _gemm_tile_set(eng, 2 * B * hw * hw, 320), _gemm_tile_set(eng, 2 * B * hw * hw, 320)
     else:
         n_a8 = sum(1 for l in eng.main if l.fn.__name__ == "rf_conv_gemm" and l.keep[0].dtype == 2)
         assert n_a8 >= 85 and eng.n_a8 == n_a8, (n_a8, eng.n_a8)          # 44 ResBlock convs + 16 x (proj_in, qkv, GEGLU), stem shared
@@ -429,7 +434,9 @@ BENCH_GEMMS = [
     ("ff.net.2 @64", 65536, 320, 1280, "linear_res", (256, 320), False),
     ("attn1.qkv @64", 65536, 960, 320, "linear", (256, 320), False),
     ("attn1.qkv @16", 4096, 3840, 1280, "linear", None, False),
-    ("proj_out @64", 65536, 320, 320, "linear_res", (256, 320), False),
+    ("proj_out @64", 65536, 320, 320, "linear_res", (128, 160), False),          # bandwidth-bound (residual, K = C): two co-resident quarter tiles
+    ("proj_in @64", 65536, 320, 320, "linear", (256, 320), False),
+    ("attn1.qkv @32", 16384, 1920, 640, "linear", (128, 160), False),              # 384 tiles of 256 rows = 1.5 rounds -> 1536 quarter tiles
     # BASELINE configs[3] (96x96 latent, CFG batch 8): M = 73728 is 288 tiles of 256 rows -> the quarter-tile wave-quantisation branch
     ("c3 ib.2.0.in_layers.2 3x3 @96 C320", 73728, 320, 2880, "conv3", (128, 160), False),
     ("c3 ob.9.0.in_layers.2 3x3 @96 C960->320", 73728, 320, 8640, "conv3", (128, 160), False),

@@ -52,12 +52,12 @@ def conv(name, cin, cout, hw, *, c1=0, stride=1, ups=0):
     cases.append((name, l, 2.0 * Bc * ho * ho * cout * 9 * (cin + c1)))
 
 
-def lin(name, M, N, K, act=ops.ACT_NONE):
+def lin(name, M, N, K, act=ops.ACT_NONE, res=False):
     x = r(M, K)
     w = r(N, K, scale=1 / math.sqrt(K))
     b = r(N, dtype=torch.float32)
     out = torch.empty(M, N // 2 if act == ops.ACT_GEGLU else N, device=dev, dtype=dt)
-    cases.append((name, ops.linear(x, w, out, b, act=act, name=name), 2.0 * M * N * K))
+    cases.append((name, ops.linear(x, w, out, b, act=act, residual=r(M, N) if res else None, name=name), 2.0 * M * N * K))
 
 
 def attn(name, heads, d, N):
@@ -114,6 +114,10 @@ lin("geglu 320->2560 @64", Bc * 4096, 2560, 320, ops.ACT_GEGLU)
 lin("ff2 1280->320 @64", Bc * 4096, 320, 1280)
 lin("qkv 320->960 @64", Bc * 4096, 960, 320)
 lin("proj 320->320 @64", Bc * 4096, 320, 320)
+lin("proj+res 320->320 @64", Bc * 4096, 320, 320, res=True)
+lin("proj+res 640->640 @32", Bc * 1024, 640, 640, res=True)
+lin("proj+res 1280->1280 @16", Bc * 256, 1280, 1280, res=True)
+lin("ff2+res 1280->320 @64", Bc * 4096, 320, 1280, res=True)
 lin("geglu 640->5120 @32", Bc * 1024, 5120, 640, ops.ACT_GEGLU)
 lin("ff2 2560->640 @32", Bc * 1024, 640, 2560)
 lin("geglu 1280->10240 @16", Bc * 256, 10240, 1280, ops.ACT_GEGLU)
