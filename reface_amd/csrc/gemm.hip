@@ -769,6 +769,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 issue_pieces(1, 0, NP);
                 if (nk > 2) next_tile();
                 if constexpr (W8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile 1 may have had no W pieces: no fixed count
+                else if (RF_DBG(p, 128)) {}          // timing decomposition: the first tile is not waited for (upper bound of what a tile loop that
+                                                      // issues the next tile's first pieces ahead of the epilogue could hide)
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
