@@ -199,6 +199,12 @@ def pmc_traffic(family, workload):
             if meta.get("workload") != workload or fam is None:
                 continue
             val = fam["hbm_read_bytes_per_launch"] + fam["hbm_write_bytes_per_launch_uncalibrated"]
+            if family.startswith("rf_conv_gemm"):
+                # a split-K rf_conv_gemm call is two kernels: the bytes of the reduce passes (their own kernel names in the PMC table) belong to
+                # the GEMM launches that issued them -- all of them are charged to this (the dominant) GEMM family
+                for k in ("rf_splitk_reduce", "rf_splitk_reduce_frag"):
+                    if k in d:
+                        val += (d[k]["hbm_read_bytes_per_launch"] + d[k]["hbm_write_bytes_per_launch_uncalibrated"]) * d[k]["launches"] / max(fam["launches"], 1)
             if meta.get("lib_digest") == dig:
                 return val, os.path.basename(fn), False
             if stale is None:          # newest pass of the same workload by another build of the library: reported, flagged
