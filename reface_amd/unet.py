@@ -98,7 +98,9 @@ class UNetEngine:
         # GEGLU + ff.net.2 of the C = 320 transformer blocks as one kernel (csrc/ffn.hip, bf16 mode).  Opt-in: correct (tests) but at 219 us
         # against 139 + 52 us for the two GEMMs on the same box (r02h) -- one wave per SIMD exposes every LDS / barrier wait and
         # serialises the GEGLU VALU work with the MFMAs; it needs a software-pipelined schedule to pay.
-        self.ffn_fuse = os.environ.get("REFACE_FFN_FUSE", "0") == "1"
+        # GEGLU + ff.net.2 of the C = 320 blocks as ONE kernel (csrc/ffn.hip): 213 us against 150 + 80 for the pair inside the step -- the pair's
+        # epilogues are store-bound and ff.net.2's residual segments cost ~20 us; -0.4 % per batch, same box (tools/exp_r03_17.sh).  =0: the pair
+        self.ffn_fuse = os.environ.get("REFACE_FFN_FUSE", "1") == "1"
         self.gn_fused = 0
         self.pool = _Pool(device)
         self.tracker = ProducerTracker()
