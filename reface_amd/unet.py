@@ -95,12 +95,10 @@ class UNetEngine:
         self.korder_on = os.environ.get("REFACE_KORDER", "0") == "1"
         # GroupNorm statistics come out of the epilogue of the GEMM that produced the tensor wherever its tile plan allows
         self.gn_fuse = os.environ.get("REFACE_GN_FUSE", "1") == "1"
-        # GEGLU + ff.net.2 of the C = 320 transformer blocks as one kernel (csrc/ffn.hip, bf16 mode).  Opt-in: correct (tests) but at 219 us
-        # against 139 + 52 us for the two GEMMs on the same box (r02h) -- one wave per SIMD exposes every LDS / barrier wait and
-        # serialises the GEGLU VALU work with the MFMAs; it needs a software-pipelined schedule to pay.
         # GEGLU + ff.net.2 of the C = 320 blocks as ONE kernel (csrc/ffn.hip): 213 us against 150 + 80 for the pair inside the step -- the pair's
         # epilogues are store-bound and ff.net.2's residual segments cost ~20 us; -0.4 % per batch, same box (tools/exp_r03_17.sh).  =0: the pair
         self.ffn_fuse = os.environ.get("REFACE_FFN_FUSE", "1") == "1"
+        self.n_cu = torch.cuda.get_device_properties(device).multi_processor_count if torch.cuda.is_available() else 256
         self.gn_fused = 0
         self.pool = _Pool(device)
         self.tracker = ProducerTracker()
@@ -370,7 +368,11 @@ class UNetEngine:
             ln = self.aget((nb * M, c)) if a8 else self.pool.get((nb * M, c), self.dt)
         self.main.append(ops.layernorm(x1, self.f32(f"{t}.norm3.weight"), self.f32(f"{t}.norm3.bias"), ln, name=f"{t}.norm3"))
         wg, bg = ops.pack_geglu(self.sd[f"{t}.ff.net.0.proj.weight"], self.sd[f"{t}.ff.net.0.proj.bias"], F32)
-        if self.ffn_fuse and c == 320 and self.dt == torch.bfloat16 and not self.w8:
+        # (one block of the fused kernel per 128 tokens and CU: only where those blocks come in nearly whole rounds -- 576 blocks at configs[3]
+        #  are 2.25 rounds of 256 CUs and lose 0.5 % per batch against the pair, tools/exp_r03_20.sh)
+        nblk = (nb * M + 127) // 128
+        whole = nblk / (self.n_cu * ((nblk + self.n_cu - 1) // self.n_cu))
+        if self.ffn_fuse and c == 320 and self.dt == torch.bfloat16 and not self.w8 and whole >= 0.9:
             # one kernel: the [M, 4C] hidden tensor (168 MB at 64x64) stays in registers (csrc/ffn.hip)
             x2 = self.pool.get((nb * M, c), self.dt)
             self.main.append(ops.ffn_geglu(ln, wg.to(self.dt).contiguous(), bg, ops.pack_ffn_w2(self.sd[f"{t}.ff.net.2.weight"], self.dt),
