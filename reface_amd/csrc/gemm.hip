@@ -141,6 +141,25 @@ template <typename TO> __device__ __forceinline__ float load_out(const TO* p);
 template <> __device__ __forceinline__ float load_out<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float load_out<bf16_t>(const bf16_t* p) { return bf2f(*p); }
 
+// Reduce-scatter over the 32 lanes of a half-wave: every lane brings 32 values (index k), lane `lrow` leaves with the total of value index
+// lrow in gx[0].  After the stage with mask m a lane keeps the half of its values selected by its own bit m: 16 + 8 + 4 + 2 + 1 exchanges.
+// (bit select, not ?: -- the compiler turns a select between two array elements into a lane-indexed array access, i.e. a 32-way compare
+//  chain per value)
+__device__ __forceinline__ void halfwave_reduce_scatter32(float (&gx)[32], int lrow) {
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int m = 16 >> st, n = 16 >> st;           // lane mask, values kept after this stage
+        const unsigned up = (lrow & m) ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int k = 0; k < n; ++k) {
+            const unsigned a = __float_as_uint(gx[k]), b = __float_as_uint(gx[k + n]);
+            const float send = __uint_as_float((a & up) | (b & ~up));
+            const float keep = __uint_as_float((b & up) | (a & ~up));
+            gx[k] = keep + __shfl_xor(send, m, 64);
+        }
+    }
+}
+
 // EPI = 1: "direct" epilogue.  The MFMA operands are swapped (W fragment as the row operand, A fragment as the column operand)
 // and the W rows of each 32-row block are read in the order  row(i') = 16*((i'>>2)&1) + 4*(i'>>3) + (i'&3), so that lane
 // (m = l & 31, h = l >> 5) ends up with accumulator register r = output column 16*h + r of its row: 16 CONTIGUOUS columns per
@@ -1190,22 +1209,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                     }
                 }
                 if (gn_on) {
-                    // butterfly reduce-scatter over the 32 lanes of this half-wave: after the stage with mask m a lane keeps the half of
-                    // its values selected by its own bit m; 16 + 8 + 4 + 2 + 1 exchanges
-#pragma unroll
-                    for (int st = 0; st < 5; ++st) {
-                        const int m = 16 >> st, n = 16 >> st;           // lane mask, values kept after this stage
-                        // (bit select, not ?: -- the compiler turns a select between two array elements into a lane-indexed array
-                        //  access, i.e. a 32-way compare chain per value)
-                        const unsigned up = (lrow & m) ? 0xffffffffu : 0u;
-#pragma unroll
-                        for (int k = 0; k < n; ++k) {
-                            const unsigned a = __float_as_uint(gx[k]), b = __float_as_uint(gx[k + n]);
-                            const float send = __uint_as_float((a & up) | (b & ~up));
-                            const float keep = __uint_as_float((b & up) | (a & ~up));
-                            gx[k] = keep + __shfl_xor(send, m, 64);
-                        }
-                    }
+                    halfwave_reduce_scatter32(gx, lrow);
                     // lane lrow now holds the total of value index lrow: column lrow (sums) / column lrow - 16 (squares)
                     gcs[((lrow >> 4) * WM + wm) * BN + (wn * TN + j) * 32 + lhalf * 16 + (lrow & 15)] = gx[0];
                 }
@@ -1669,19 +1673,7 @@ __global__ __launch_bounds__(64 * TN) void splitk_reduce_frag_kernel(const GemmP
         float gx[32];
 #pragma unroll
         for (int k = 0; k < 16; ++k) { gx[k] = y[k]; gx[16 + k] = y[k] * y[k]; }
-        // butterfly reduce-scatter over the 32 lanes of the half-wave (as in the direct epilogue): lane lrow ends up with the total of value lrow
-#pragma unroll
-        for (int st = 0; st < 5; ++st) {
-            const int m = 16 >> st, n = 16 >> st;
-            const unsigned up = (lrow & m) ? 0xffffffffu : 0u;
-#pragma unroll
-            for (int k = 0; k < n; ++k) {
-                const unsigned a_ = __float_as_uint(gx[k]), b_ = __float_as_uint(gx[k + n]);
-                const float send = __uint_as_float((a_ & up) | (b_ & ~up));
-                const float keep = __uint_as_float((b_ & up) | (a_ & ~up));
-                gx[k] = keep + __shfl_xor(send, m, 64);
-            }
-        }
+        halfwave_reduce_scatter32(gx, lrow);          // (as in the direct epilogue)
         gcs[lrow >> 4][j * 32 + lhalf * 16 + (lrow & 15)] = gx[0];
         __syncthreads();
         if (tid < 64) {
@@ -1907,7 +1899,14 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
     if (p.glds && d->batch == 1) {
         const int bk = 128 / (int)sizeof(T);
         const long long mt256 = (p.M + 255) / 256, mt128 = (p.M + 127) / 128;
-        const bool n320 = d->act != RF_ACT_GEGLU && N % 320 == 0, n256 = N % 256 == 0 && !n320;
+        bool n320 = d->act != RF_ACT_GEGLU && N % 320 == 0;
+        if (n320 && N % 256 == 0 && mt256 * (N / 320) >= 192) {
+            // both widths divide N: whole rounds of 256 blocks decide -- qkv of the 16x16 level (4096 x 3840) is 192 tiles of 256x320 (one
+            // round, a quarter of the CUs idle) or 240 of 256x256
+            const long long t320 = mt256 * (N / 320), t256 = mt256 * (N / 256);
+            if (((t256 + 255) / 256) * 256 < ((t320 + 255) / 256) * 320) n320 = false;
+        }
+        const bool n256 = N % 256 == 0 && !n320;
         const long long nt = n320 ? N / 320 : (n256 ? N / 256 : 0);
         if (nt > 0) {
             if (mt256 * nt >= 192) {
