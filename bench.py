@@ -187,7 +187,19 @@ def pmc_traffic(family, workload):
     the microarchitecture guide prescribes) and commits profiles/rNN_pmc_hbm_traffic.json stamped with the library digest and
     the workload.  A pass of a different build or workload is NOT reported: the field is then null."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")), key=os.path.getmtime)
+    import re
+
+    def order(fn):
+        # newest LAST, by what the pass itself says -- never by file time (a checkout sets those arbitrarily): the collection time the
+        # script stamped into _meta, else the round tag of the file name (r03j < r04a)
+        try:
+            with open(fn) as f:
+                t = json.load(f).get("_meta", {}).get("collected_unix")
+        except Exception:
+            t = None
+        m = re.match(r"r(\d+)([a-z]*)", os.path.basename(fn))
+        return (float(t) if t else 0.0, int(m.group(1)) if m else -1, m.group(2) if m else "")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")), key=order)
     dig = lib_digest()
     stale = None
     for fn in reversed(files):
@@ -263,6 +275,73 @@ def image_parity(unet, vae, ldm, h, S, scale, device, B=2):
                     "(that mode is the one pinned to the CPU oracle within 1e-3 by tests/test_fullsize_gpu.py)"}
 
 
+def family_key(fam, dname):
+    """The dominant GEMM family of a mode and the MFMA peak of the instruction THAT family issues (a run whose own family is absent
+    falls back to the bf16 family and is then priced against the bf16 peak)."""
+    key = {"bf16": "rf_conv_gemm[bf16]", "f32": "rf_conv_gemm[f32]", "fp8": "rf_conv_gemm[fp8]", "fp8w": "rf_conv_gemm[fp8w]",
+           "f32x3": "rf_conv_gemm[bf16x3]"}[dname]
+    peak_of = {"rf_conv_gemm[bf16]": PEAK["bf16"], "rf_conv_gemm[f32]": PEAK["f32"], "rf_conv_gemm[fp8]": PEAK["fp8"],
+               "rf_conv_gemm[fp8w]": PEAK["fp8w"], "rf_conv_gemm[bf16x3]": PEAK["bf16"] / 3.0}
+    if key not in fam:
+        key = "rf_conv_gemm[bf16]"
+    return key, peak_of[key]
+
+
+def roofline_of(fam, dname, cname, B, h, S, ms_per_step, dec_ms, step_ms, workload, with_traffic=True):
+    key, peak = family_key(fam, dname)
+    dom = fam[key]
+    unet_alg = F_UNET[h] * 2 * B if h in F_UNET else None
+    traffic, tsrc, tstale = pmc_traffic(key, workload) if with_traffic else (None, "not collected for this line", False)
+    roof = {"bound": "mfma", "kernel": key, "achieved": dom["tflops_per_s"], "peak": peak, "unit": "TFLOP/s",
+            "frac": dom["tflops_per_s"] / peak, "traffic": traffic, "traffic_source": tsrc, "traffic_digest_mismatch": tstale,
+            "launches_per_ddim_step": dom["calls"], "avg_launch_us": dom["ms"] / dom["calls"] * 1e3,
+            "alg_flop_per_ddim_step": dom["flops"], "ddim_step_ms_sum_of_kernels": step_ms,
+            "ddim_step_ms_wall": (ms_per_step - dec_ms) / S}
+    if unet_alg:
+        # whole-step utilisation is priced against the peak of the mode's MAIN matrix instruction (bf16 2.5 PF; fp8 5 PF; exact fp32 157 TF)
+        upeak = PEAK.get(dname, PEAK["bf16"] / 3.0 if dname == "f32x3" else PEAK["bf16"])
+        roof["unet_mfma_util_whole_step"] = unet_alg / (step_ms * 1e-3) / 1e12 / upeak
+        roof["unet_mfma_util_wall"] = unet_alg / ((ms_per_step - dec_ms) / S * 1e-3) / 1e12 / upeak
+    return roof
+
+
+def other_config_line(oc, unet, vae, ldm, args, device, timed, steps=3, warmup=1):
+    """One more BASELINE config on the models already resident: `steps` timed batches + the event-timed launch list of one DDIM step."""
+    from reface_amd import ops, profiler
+    from reface_amd.ddim import DDIMSampler
+    conf = CONFIGS[oc]
+    B, h, dname, S = conf["batch"], conf["latent"], conf["dtype"], args.ddim_steps
+    unet.set_compute_dtype({"bf16": torch.bfloat16, "f32": torch.float32, "fp8": "fp8", "fp8w": "fp8w"}[dname])
+    torch.cuda.empty_cache()
+    sampler = DDIMSampler(ldm)
+    x_T, z_inp, mask, c, uc = synthetic_inputs(B, h, 42, device)
+    img_out = torch.empty((B, 3, 8 * h, 8 * h), dtype=torch.float32, device=device)
+
+    def one_batch():
+        samples, _ = sampler.sample(S=S, conditioning=c, batch_size=B, shape=[4, h, h], verbose=False, unconditional_guidance_scale=args.scale,
+                                    unconditional_conditioning=uc, eta=0.0, x_T=x_T, test_model_kwargs={"inpaint_image": z_inp, "inpaint_mask": mask})
+        x = vae.decode(samples, inv_scale=1.0 / 0.18215)
+        ops.to_image(x, img_out)()
+        return img_out
+
+    elapsed, out = timed(one_batch, warmup, steps)
+    assert torch.isfinite(out).all(), f"{oc}: non-finite output image"
+    ms_per_step = elapsed / steps * 1e3
+    plan = list(sampler._plans.values())[0]
+    timed_l = profiler.time_launches(plan["step"], reps=3)
+    fam = profiler.summarize(timed_l)
+    step_ms = sum(ms for _, ms in timed_l)
+    dec_ms = sum(ms for _, ms in profiler.time_launches(vae._engine("dec", B, h, h).launches, reps=2))
+    px = 8 * h
+    workload = f"{oc}:{px}x{px}:S{S}:B{B}:{dname}"
+    line = {"config": f"BASELINE configs[{conf['idx']}]", "id": workload, "value": B * steps / elapsed, "unit": "images/s", "ms_per_step": ms_per_step,
+            "steps": steps, "warmup": warmup, "dtype": dname, "vae_decode_mode": vae.decode_mode,
+            "roofline": roofline_of(fam, dname, oc, B, h, S, ms_per_step, dec_ms, step_ms, workload),
+            "unet_step": {k: {"calls": v["calls"], "ms": round(v["ms"], 4), "tflops_per_s": round(v["tflops_per_s"], 2)} for k, v in fam.items() if v["ms"] > 0.05}}
+    del sampler
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,6 +360,8 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the bf16-vs-fp32 image error report and the fp32 parity-mode line")
     ap.add_argument("--share-gpu", action="store_true", help="debug: every rank uses cuda:0 and the gloo backend (exercises the multi-rank path on one GPU)")
     ap.add_argument("--profile-json", default=None, help="write the per-kernel-family table here")
+    ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
+                    help="skip the short configs[3] (768x768) / configs[4] (fp8) lines the default c1 run appends under `other_configs`")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -371,6 +452,10 @@ def main():
                    "parallelism": f"dp{world} (pairs sharded, no collective in the step loop)"},
     }
 
+    # self-describing multi-GPU line: which collective library carried the start-up broadcast / barriers, and on how many ranks
+    result["distributed"] = {"ranks": world, "backend": (("gloo (ranks share one GPU: debug form)" if args.share_gpu else "nccl = RCCL over xGMI") if world > 1 else None),
+                             "rccl_ranks": (0 if (world == 1 or args.share_gpu) else world),
+                             "collectives_in_step_loop": 0, "sharding": "image pairs r::world, seeds 42 + rank"}
     if wsums is not None:
         result["weights_checksum_per_rank"] = wsums
         result["weights_identical_on_all_ranks"] = all(w == wsums[0] for w in wsums)
@@ -381,7 +466,8 @@ def main():
         timed_l = profiler.time_launches(plan["step"], reps=5)
         fam = profiler.summarize(timed_l)
         step_ms = sum(ms for _, ms in timed_l)
-        audit = {"event_gap_ms_subtracted_per_launch": profiler.time_launches.last_gap_ms, "launches_at_half_floor": profiler.time_launches.last_floored,
+        audit = {"empty_event_interval_ms": profiler.time_launches.last_gap_ms, "event_gap_ms_subtracted_per_launch": profiler.time_launches.last_sub_ms,
+                 "launches_at_half_floor": profiler.time_launches.last_floored,
                  "raw_ms_per_family": {k: round(v, 4) for k, v in profiler.time_launches.last_raw_ms.items()}}
         dec = vae._engine("dec", B, h, h)
         dtimed = profiler.time_launches(dec.launches, reps=3)
@@ -403,21 +489,7 @@ def main():
             vae._engines = {k: v for k, v in vae._engines.items() if v is not e32}
             del e32, f32_img, fast_img
             torch.cuda.empty_cache()
-        key = {"bf16": "rf_conv_gemm[bf16]", "f32": "rf_conv_gemm[f32]", "fp8": "rf_conv_gemm[fp8]", "fp8w": "rf_conv_gemm[fp8w]"}[dname]
-        if key not in fam:
-            key = "rf_conv_gemm[bf16]"
-        dom = fam[key]
-        nb = 2 * B
-        unet_alg = F_UNET[h] * nb if h in F_UNET else None
-        traffic, tsrc, tstale = pmc_traffic(key, workload)
-        roof = {"bound": "mfma", "kernel": key, "achieved": dom["tflops_per_s"], "peak": PEAK[dname], "unit": "TFLOP/s",
-                "frac": dom["tflops_per_s"] / PEAK[dname], "traffic": traffic, "traffic_source": tsrc, "traffic_digest_mismatch": tstale,
-                "launches_per_ddim_step": dom["calls"], "avg_launch_us": dom["ms"] / dom["calls"] * 1e3,
-                "alg_flop_per_ddim_step": dom["flops"], "ddim_step_ms_sum_of_kernels": step_ms,
-                "ddim_step_ms_wall": (ms_per_step - dec_ms) / S}
-        if unet_alg:
-            roof["unet_mfma_util_whole_step"] = unet_alg / (step_ms * 1e-3) / 1e12 / PEAK[dname]
-            roof["unet_mfma_util_wall"] = unet_alg / ((ms_per_step - dec_ms) / S * 1e-3) / 1e12 / PEAK[dname]
+        roof = roofline_of(fam, dname, cname, B, h, S, ms_per_step, dec_ms, step_ms, workload)
         result["roofline"] = roof
         result["breakdown"] = {
             "ddim_step_ms": step_ms, "vae_decode_ms": dec_ms, "vae_decode_mode": vae.decode_mode, "vae_decode_exact_f32": dec_f32,
@@ -449,15 +521,19 @@ def main():
             # (b) the parity mode as a driver-visible throughput line (same workload, one timed batch)
             unet.set_compute_dtype(torch.float32)
             sampler = DDIMSampler(ldm)
+            fast_decode = vae.decode_mode
+            vae.decode_mode = "f32"                 # the parity mode is exact fp32 end to end: UNet AND decode on v_mfma_f32_32x32x2_f32
             el32, _ = timed(one_batch, 1, 1)
-            result["parity_mode"] = {"dtype": "f32", "value": B / el32, "unit": "images/s", "ms_per_step": el32 * 1e3, "steps": 1, "warmup": 1,
-                                     "note": "exact-fp32 MFMA mode (v_mfma_f32_32x32x2_f32), the mode the 1e-3 oracle gate is stated for"}
+            result["parity_mode"] = {"dtype": "f32", "vae_decode_mode": vae.decode_mode, "value": B / el32, "unit": "images/s", "ms_per_step": el32 * 1e3,
+                                     "steps": 1, "warmup": 1,
+                                     "note": "exact-fp32 MFMA mode (v_mfma_f32_32x32x2_f32) for the UNet and the VAE decode, the mode the 1e-3 oracle gate is stated for"}
+            vae.decode_mode = fast_decode
             log(f"[bench] fp32 parity mode: {B / el32:.3f} images/s")
             # (c) the fast form of the parity mode: fp32 storage / accumulation, split-bf16 GEMM operands (3 bf16 MFMA passes), fp32 attention
             unet.set_compute_dtype("f32x3")
             sampler = DDIMSampler(ldm)
             elx3, _ = timed(one_batch, 1, 1)
-            result["parity_mode_f32x3"] = {"dtype": "f32x3", "value": B / elx3, "unit": "images/s", "ms_per_step": elx3 * 1e3, "steps": 1, "warmup": 1,
+            result["parity_mode_f32x3"] = {"dtype": "f32x3", "vae_decode_mode": vae.decode_mode, "value": B / elx3, "unit": "images/s", "ms_per_step": elx3 * 1e3, "steps": 1, "warmup": 1,
                                            "vs_exact_f32": image_parity(unet, vae, ldm, h, S, args.scale, device),
                                            "note": "fp32 storage, split-bf16 operand pairs (hi + lo) in three bf16 MFMA passes, fp32 accumulate / attention; "
                                                    "pinned to the CPU oracle by tests/test_fullsize_gpu.py (1e-3-class bound)"}
@@ -467,6 +543,20 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:
             result["parity_mode"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and args.other_configs and cname == "c1" and args.batch is None and args.latent is None and args.dtype is None:
+        # BASELINE configs[3] / configs[4] as short driver-visible lines (inside this run's wall clock): same models, same timed region
+        # (barrier + synchronize around `steps` whole batches), their own roofline from the same event-timed launch list
+        result["other_configs"] = {}
+        for oc in ("c3", "c4"):
+            try:
+                result["other_configs"][oc] = other_config_line(oc, unet, vae, ldm, args, device, timed)
+                r = result["other_configs"][oc]
+                log(f"[bench] {oc}: {r['value']:.3f} images/s, {r['ms_per_step']:.1f} ms per batch, dominant family frac {r['roofline']['frac']:.3f}")
+            except Exception as e:
+                result["other_configs"][oc] = {"error": repr(e)}
+        unet.set_compute_dtype(dtype)
+        vae._engines = {k: v for k, v in vae._engines.items() if (k[1], k[2]) == (B, h)}          # drop the other configs' decoders
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_conditioning:
         try:
             result["conditioning"] = conditioning_line(vae, B, h, device)

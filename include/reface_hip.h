@@ -241,6 +241,14 @@ int rf_to_image(const float* x, float* y, int64_t n, void* stream);
 int rf_u8_to_norm(const void* x_u8, int B, int HW, const float* mean3, const float* std3, float* out, void* stream);
 int rf_label_mask(const void* labels_u8, int64_t n, const void* lut256_u8, int invert, float* out, void* stream);
 int rf_mul_mask(const float* x, const float* mask, int B, int C, int HW, float* out, void* stream);
+/*
+ * rf_resize_u8_linear : cv2.resize(img, (Wo, Ho), interpolation=cv2.INTER_LINEAR) of uint8 HWC images [B, H, W, C] (image b at
+ * x + b * image_stride bytes) -> uint8 [B, Ho, Wo, C]: what albumentations' A.Resize(224, 224) runs on the source face
+ * (ldm/data/test_bench_dataset.py:141-148, 324; scripts/inference_swap_selected.py:525-553).  OpenCV's integer algorithm bit for bit
+ * (half-pixel centres, two taps per axis, 11-bit weights, NO antialiasing; exact 2:1 -> the fast-area average); cv2 itself is a
+ * third-party dependency absent from /root/reference and from this image: see reface_amd/data.py::resize_u8_linear for the restatement.
+ */
+int rf_resize_u8_linear(const void* x_u8, int B, int H, int W, int C, int64_t image_stride, int Ho, int Wo, void* out_u8, void* stream);
 /* elementwise y = silu(x) on fp32 (emb path, openaimodel.py:219) */
 int rf_silu_f32(const float* x, float* y, int64_t n, void* stream);
 

@@ -3,6 +3,7 @@
 hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so
 travels to the GPU box with the repo snapshot.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -16,38 +17,85 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # per-file extras.  attention: keep MFMA accumulators in VGPRs -- the online softmax reads every score and rescales O each
 # tile, and with AGPR accumulators hipcc emitted ~160 v_accvgpr_read/write per KV tile (40 % of the loop's VALU work).
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "reface_hip.h")]
 
 
 
-def _stale(obj, deps):
-    if not os.path.exists(obj):
-        return True
-    t = os.path.getmtime(obj)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(paths, extra):
+    """sha256 over the bytes of `paths` (in order) and the strings in `extra`."""
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    for e in extra:
+        h.update(e.encode())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def _hipcc_id(hipcc):
+    try:
+        out = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+        return " ".join(l.strip() for l in out.splitlines() if "version" in l.lower())          # (no install paths: the key must not depend on them)
+    except OSError:
+        return "unknown"
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def unit_key(unit, hipcc=None):
+    """Content key of one compile unit: sha256 of (source, headers, compile flags, compiler version).  Stored next to the object as
+    `<unit>.o.key`; an object whose key file does not match is rebuilt -- file times play no part (a checkout or a snapshot copy
+    sets them arbitrarily)."""
+    hipcc = hipcc or os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    src = os.path.join(CSRC, unit)
+    return _digest([src] + HEADERS, FLAGS + EXTRA_FLAGS.get(unit, []) + [_hipcc_id(hipcc)])
 
 
 def build(force=False, verbose=True):
+    """Compile what is out of date BY CONTENT and link.  Returns the library path; `build.last_report` lists, per unit, the key and whether
+    it was compiled in this call (the round's "does it build" evidence)."""
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "reface_hip.h")]
-    objs, procs = [], []
+    force = force or os.environ.get("REFACE_BUILD_FORCE", "0") == "1"
+    objs, procs, report = [], [], {}
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src] + hdrs):
+        key = unit_key(s, hipcc)
+        fresh = (not force) and os.path.exists(obj) and _read(obj + ".key") == key
+        report[s] = {"key": key[:16], "compiled": not fresh}
+        if not fresh:
             cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            procs.append((s, subprocess.Popen(cmd)))
-    for s, p in procs:
+            if os.path.exists(obj + ".key"):
+                os.remove(obj + ".key")
+            procs.append((s, obj, key, subprocess.Popen(cmd)))
+        elif verbose:
+            print(f"[build] {s}: up to date (content key {key[:16]})", flush=True)
+    for s, obj, key, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
-    if force or procs or _stale(LIB, objs):
+        with open(obj + ".key", "w") as f:
+            f.write(key + "\n")
+    # the library's key = the keys of its objects: relinked whenever one of them changed
+    lib_key = _digest([], [report[s]["key"] for s in SOURCES])
+    if force or procs or not os.path.exists(LIB) or _read(LIB + ".key") != lib_key:
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(LIB + ".key", "w") as f:
+            f.write(lib_key + "\n")
         # hipcc's host pass can drop a kernel stub without a diagnostic (seen with a call expression inside a builtin's argument
         # list): the library then links but fails to load.  Catch it here.
         und = subprocess.run(["nm", "-u", "-C", LIB], capture_output=True, text=True).stdout
@@ -55,6 +103,7 @@ def build(force=False, verbose=True):
         if bad:
             os.remove(LIB)
             raise RuntimeError("libreface_hip.so has undefined rf:: symbols (host stubs missing): " + "; ".join(bad[:4]))
+    build.last_report = report
     return LIB
 
 

@@ -165,6 +165,49 @@ __global__ void mul_mask_kernel(const float* __restrict__ x, const float* __rest
     out[i] = x[i] * mask[(long long)b * HW + p];
 }
 
+// cv2.resize(img, (Wo, Ho), interpolation=cv2.INTER_LINEAR) of uint8 HWC images (A.Resize(224, 224) on the source face,
+// ldm/data/test_bench_dataset.py:141-148, 324), bit for bit in OpenCV's integer arithmetic (resize.cpp: HResizeLinear<uchar, int, short,
+// 2048> + the u8 VResizeLinear): two taps per axis at half-pixel centres, 11-bit weights rounded to nearest-even, columns clamped
+// with their weight ((s, f) = (0, 0) left of the image, (W - 1, 0) from the last column on), rows clipped with the weights kept;
+//   out = (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2,   Hk = S[yk][sx] * a0 + S[yk][sx + 1] * a1.
+// An exact 2:1 reduction on both axes is OpenCV's fast-area case: (a + b + c + d + 2) >> 2.  One thread per output pixel.
+__device__ __forceinline__ void cv_linear_tap(int d, double scale, int n_src, bool clamp, int& s, int& w0, int& w1) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    s = (int)floorf(f);
+    f -= (float)s;
+    if (clamp) {
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= n_src - 1) { f = 0.f; s = n_src - 1; }
+    }
+    w1 = __float2int_rn(f * 2048.0f);
+    w0 = __float2int_rn((1.0f - f) * 2048.0f);
+}
+__global__ void resize_u8_linear_kernel(const uint8_t* __restrict__ x, int B, int H, int W, int C, long long sb, int Ho, int Wo,
+                                        uint8_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // over B * Ho * Wo
+    if (i >= (long long)B * Ho * Wo) return;
+    const int dx = (int)(i % Wo), dy = (int)((i / Wo) % Ho), b = (int)(i / ((long long)Wo * Ho));
+    const uint8_t* img = x + (long long)b * sb;
+    uint8_t* o = out + i * C;
+    if (H == 2 * Ho && W == 2 * Wo) {
+        const uint8_t* p0 = img + ((long long)(2 * dy) * W + 2 * dx) * C;
+        const uint8_t* p1 = p0 + (long long)W * C;
+        for (int c = 0; c < C; ++c) o[c] = (uint8_t)(((int)p0[c] + (int)p0[C + c] + (int)p1[c] + (int)p1[C + c] + 2) >> 2);
+        return;
+    }
+    int sx, a0, a1, sy, b0, b1;
+    cv_linear_tap(dx, (double)W / (double)Wo, W, true, sx, a0, a1);
+    cv_linear_tap(dy, (double)H / (double)Ho, H, false, sy, b0, b1);
+    const int sx1 = min(sx + 1, W - 1), y0 = min(max(sy, 0), H - 1), y1 = min(max(sy + 1, 0), H - 1);
+    const uint8_t* r0 = img + (long long)y0 * W * C;
+    const uint8_t* r1 = img + (long long)y1 * W * C;
+    for (int c = 0; c < C; ++c) {
+        const int h0 = ((int)r0[sx * C + c] * a0 + (int)r0[sx1 * C + c] * a1) >> 4;
+        const int h1 = ((int)r1[sx * C + c] * a0 + (int)r1[sx1 * C + c] * a1) >> 4;
+        o[c] = (uint8_t)((((b0 * h0) >> 16) + ((b1 * h1) >> 16) + 2) >> 2);
+    }
+}
+
 }  // namespace rf
 
 using namespace rf;
@@ -282,5 +325,16 @@ extern "C" int rf_mul_mask(const float* x, const float* mask, int B, int C, int 
     const long long n = (long long)B * C * HW;
     hipLaunchKernelGGL(mul_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, mask, B, C, HW, out);
     RF_LAUNCH_CHECK("rf_mul_mask");
+    return 0;
+}
+
+extern "C" int rf_resize_u8_linear(const void* x, int B, int H, int W, int C, int64_t image_stride, int Ho, int Wo, void* out, void* stream) {
+    using namespace rf;
+    RF_CHECK(x && out && B > 0 && H > 0 && W > 0 && C > 0 && C <= 4 && Ho > 0 && Wo > 0 && image_stride >= (int64_t)H * W * C,
+             "rf_resize_u8_linear: bad arguments (B=%d H=%d W=%d C=%d Ho=%d Wo=%d)", B, H, W, C, Ho, Wo);
+    const long long n = (long long)B * Ho * Wo;
+    hipLaunchKernelGGL(resize_u8_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)x, B, H, W, C,
+                       (long long)image_stride, Ho, Wo, (uint8_t*)out);
+    RF_LAUNCH_CHECK("rf_resize_u8_linear");
     return 0;
 }

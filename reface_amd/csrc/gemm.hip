@@ -628,6 +628,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 t = curB; curB = othB; othB = t;
                 t = curS; curS = othS; othS = t;
             }
+            // the MFMAs are asm statements: hipcc's hazard recognizer pads nothing between the last of them (16 passes) and the epilogue's first
+            // VALU read of an accumulator -- 2 x 16 wait states here cover the required 18 whatever the barrier below costs
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
             __syncthreads();
         } else {
         // Fragment pipeline: the ds_reads of k-step kk+1 are issued while the MFMAs of k-step kk run, so the matrix pipe does not
@@ -1678,13 +1681,16 @@ __global__ __launch_bounds__(64 * TN) void splitk_reduce_frag_kernel(const GemmP
         __syncthreads();
         if (tid < 64) {
             const int c = tid >> 5, g = tid & 31;
-            if (p.gn_part[c]) {
+            // (a stripe of a ragged tile that lies beyond M or N has no slot: M < BM with split-K -- CFG off at the 8x8 level -- would otherwise
+            //  write past the end of `partial`; slots are numbered by the GLOBAL 32 TN-column stripe, which is what the host sizes them by)
+            if (p.gn_part[c] && row0 < p.M && coln0 < p.N) {
                 const int cpg = p.gn_cpg[c], base = p.gn_coff[c] + coln0;            // consumer channel of the stripe's first column
                 const int lo = max(0, g * cpg - base), hi = min(min(32 * TN, p.N - coln0), (g + 1) * cpg - base);
                 double sa = 0.0, sq = 0.0;
                 for (int k = lo; k < hi; ++k) { sa += (double)gcs[0][k]; sq += (double)gcs[1][k]; }
                 const int b = row0 / p.gn_rows, mt = (row0 - b * p.gn_rows) / 32;
-                double* o = p.gn_part[c] + (((long long)b * p.gn_nch[c] + p.gn_slot[c] + mt * (p.tiles_n * WN) + tile_n * WN + wn) * 32 + g) * 2;
+                const int nstripe = (p.N + 32 * TN - 1) / (32 * TN);
+                double* o = p.gn_part[c] + (((long long)b * p.gn_nch[c] + p.gn_slot[c] + mt * nstripe + coln0 / (32 * TN)) * 32 + g) * 2;
                 o[0] = sa;
                 o[1] = sq;
             }

@@ -2,10 +2,12 @@
 ``(target[3,H,W] in [-1,1], prior, {inpaint_image, inpaint_mask, ref_imgs}, id_str)``.
 
 ``SyntheticPairs`` produces seeded items of that contract (no dataset is reachable offline).  ``CelebAdataset`` reads the
-CelebAMask-HQ folder layout the reference's test split uses (test_bench_dataset.py:130-222, 253-370), with PIL + numpy only:
-the reference goes through cv2 / albumentations for the 224x224 resize of the source face (cv2 INTER_LINEAR), which are not in
-this image -- PIL's bilinear filter stands in, so that one resize is "parity unpinned" (the tensors' shapes, ranges, mask
-semantics and normalisations are the reference's)."""
+CelebAMask-HQ folder layout the reference's test split uses (test_bench_dataset.py:130-222, 253-370), with PIL + numpy only.  The
+reference resizes the source face to 224x224 with albumentations' ``A.Resize`` = ``cv2.resize(..., INTER_LINEAR)``; cv2 is a third-party
+dependency that is neither under /root/reference nor in this image, so ``resize_u8_linear`` restates OpenCV's published uint8
+INTER_LINEAR algorithm (two taps, 11-bit fixed point, no antialiasing) and the readers use it -- PIL's BILINEAR, which widens its
+kernel when shrinking, is NOT equivalent (mean |d| of 37 grey levels on a 1024 -> 224 noise image).  Images are decoded by PIL (the
+reference: ``cv2.imread``; both wrap libjpeg / libpng -- decode parity itself is unpinned)."""
 import os
 
 import numpy as np
@@ -36,6 +38,70 @@ class SyntheticPairs(Dataset):
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+INTER_RESIZE_COEF_BITS = 11
+INTER_RESIZE_COEF_SCALE = 1 << INTER_RESIZE_COEF_BITS
+
+
+def _linear_taps(n_src, n_dst, clamp_high):
+    """Source index and the two 11-bit fixed-point weights of every destination coordinate, as OpenCV's `resize` builds its xofs / alpha
+    (yofs / beta) tables for INTER_LINEAR (modules/imgproc/src/resize.cpp, `cv::hal::resize`): half-pixel centres,
+    f = float((d + 0.5) * scale - 0.5) with scale in double, s = floor(f), weights (1 - f, f) scaled by 2048 and rounded to nearest-even
+    to int16 (`saturate_cast<short>`).  Columns (`clamp_high`): s < 0 -> (s, f) = (0, 0); s >= n_src - 1 -> (n_src - 1, 0).  Rows keep
+    their weights and have the two source rows clipped to [0, n_src - 1] instead."""
+    scale = float(n_src) / float(n_dst)                           # double, as `scale_x = 1. / inv_scale_x` for an integer dsize
+    d = np.arange(n_dst, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int32)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    if clamp_high:
+        lo = s < 0
+        f[lo], s[lo] = 0.0, 0
+        hi = s >= n_src - 1
+        f[hi], s[hi] = 0.0, n_src - 1
+    w1 = np.rint(f * np.float32(INTER_RESIZE_COEF_SCALE)).astype(np.int32)                      # rint: round half to even (cvRound)
+    w0 = np.rint((np.float32(1.0) - f) * np.float32(INTER_RESIZE_COEF_SCALE)).astype(np.int32)
+    return s, w0, w1
+
+
+def resize_u8_linear(img, out_h, out_w):
+    """`cv2.resize(img, (out_w, out_h), interpolation=cv2.INTER_LINEAR)` for uint8 images [H, W] / [H, W, C] -- what albumentations'
+    `A.Resize(height, width)` runs on the source face (ldm/data/test_bench_dataset.py:141-148, 296-324; scripts/inference_swap_selected.py:
+    525-553).  cv2 is not in this image; this restates OpenCV's published u8 algorithm (resize.cpp: `resizeGeneric_` with
+    `HResizeLinear<uchar, int, short, 2048>` and the u8 specialisation of `VResizeLinear`), bit for bit in integer arithmetic:
+
+      * two taps per axis at half-pixel centres, NO antialiasing whatever the ratio (PIL's BILINEAR widens its kernel when shrinking);
+      * horizontal pass in int32:  Hrow[x] = S[sx] * a0 + S[sx + 1] * a1  with 11-bit weights (a0 + a1 = 2048);
+      * vertical pass:  out = ((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2;
+      * an exact 2:1 reduction on both axes is rerouted by OpenCV to its fast INTER_AREA kernel: (a + b + c + d + 2) >> 2.
+
+    Not restated (builds of OpenCV that take them may differ in the last bit): the IPP / OpenCL back-ends."""
+    a = np.ascontiguousarray(img)
+    if a.dtype != np.uint8 or a.ndim not in (2, 3):
+        raise TypeError("resize_u8_linear: uint8 [H, W] or [H, W, C] image expected")
+    squeeze = a.ndim == 2
+    if squeeze:
+        a = a[:, :, None]
+    H, W, _ = a.shape
+    if (H, W) == (out_h, out_w):
+        out = a.copy()
+    elif H == 2 * out_h and W == 2 * out_w:
+        v = a.astype(np.int32)
+        out = ((v[0::2, 0::2] + v[0::2, 1::2] + v[1::2, 0::2] + v[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    else:
+        sx, a0, a1 = _linear_taps(W, out_w, True)
+        sy, b0, b1 = _linear_taps(H, out_h, False)
+        sx1 = np.minimum(sx + 1, W - 1)                           # (weight 0 wherever sx + 1 would leave the row)
+        y0, y1 = np.clip(sy, 0, H - 1), np.clip(sy + 1, 0, H - 1)
+        a0_, a1_ = a0[None, :, None], a1[None, :, None]
+
+        def hpass(rows):                                          # horizontal pass of the source rows a destination row needs: [out_h, out_w, C] int32
+            r = a[rows]
+            return r[:, sx, :].astype(np.int32) * a0_ + r[:, sx1, :].astype(np.int32) * a1_
+        h0, h1 = hpass(y0) >> 4, hpass(y1) >> 4
+        out = ((((b0[:, None, None] * h0) >> 16) + ((b1[:, None, None] * h1) >> 16) + 2) >> 2).astype(np.uint8)
+    return out[:, :, 0] if squeeze else out
 
 
 def _to_tensor(img):
@@ -74,7 +140,7 @@ class CelebAdataset(Dataset):
         self.gray_outer_mask = bool(gray_outer_mask)
         # raw=True: items are the decoded / resized uint8 arrays only (target HWC, its label map, 224x224 source HWC, its label map, id);
         # normalisation, label masks and the mask products then run on the GPU (reface_amd/prep.py)
-        self.raw = bool(raw)
+        self.raw = "full" if raw == "full" else bool(raw)
         if preserve_mask is not None:
             remove_mask_tar = preserve_mask_src = preserve_mask
         self.remove_tar = list(remove_mask_tar if remove_mask_tar is not None else [1, 2, 4, 5, 8, 9, 6, 7, 10, 11, 12, 17])
@@ -100,14 +166,20 @@ class CelebAdataset(Dataset):
         Image = self.Image
         img_p = Image.open(self.imgs[index]).convert("RGB").resize((512, 512))                 # PIL default filter, as the reference
         if self.raw:
-            ref = Image.open(self.ref_imgs[index]).convert("RGB").resize((224, 224), Image.BILINEAR)
+            # raw = True: the 224x224 source is resized here (host); raw = "full": the decoded source goes to the GPU at its own size and
+            # rf_resize_u8_linear does the same arithmetic there (DevicePrep; sources of one batch must then share a size, else `raw_collate`
+            # keeps them as a list)
+            ref = np.asarray(Image.open(self.ref_imgs[index]).convert("RGB"), dtype=np.uint8)
+            if self.raw != "full":
+                ref = resize_u8_linear(ref, 224, 224)
             u8 = lambda im: torch.from_numpy(np.asarray(im, dtype=np.uint8).copy())
             return (u8(img_p), u8(Image.open(self.labels[index]).convert("L")), u8(ref),
                     u8(Image.open(self.ref_labels[index]).convert("L")), str(index).zfill(12))
         image_tensor = _normalize(_to_tensor(img_p), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
         tar_labels = self.remove_tar if self.gray_outer_mask else self.preserve_src
         mask_tensor = 1.0 - _to_tensor(self._label_mask(self.labels[index], tar_labels))     # 1 = keep, 0 = region to generate
-        ref = Image.open(self.ref_imgs[index]).convert("RGB").resize((224, 224), Image.BILINEAR)   # A.Resize(224, 224): cv2 linear
+        # A.Resize(224, 224) = cv2.resize(..., INTER_LINEAR) on the cv2.imread image (test_bench_dataset.py:141-148, 296-324)
+        ref = resize_u8_linear(np.asarray(Image.open(self.ref_imgs[index]).convert("RGB"), dtype=np.uint8), 224, 224)
         ref_tensor = _normalize(_to_tensor(ref), CLIP_MEAN, CLIP_STD)
         if self.gray_outer_mask:
             ref_mask = _to_tensor(self._label_mask(self.ref_labels[index], self.preserve_src))
@@ -177,15 +249,29 @@ class VideoDataset(Dataset):
 
 
 def load_source_reference(img_path, mask_path, preserve):
-    """The ONE source face of the selected-swap callers (inference_swap_selected.py:525-553): RGB image resized to 224x224 (the reference
-    uses A.Resize = cv2 INTER_LINEAR; PIL bilinear stands in, as in the test-bench readers: parity unpinned for that resize), CLIP
-    normalisation, times its preserved-label mask resized to 224x224 (bilinear on the tensor) -> [1, 3, 224, 224]."""
+    """The ONE source face of the selected-swap callers (inference_swap_selected.py:525-553): RGB image resized to 224x224 (A.Resize =
+    cv2 INTER_LINEAR: `resize_u8_linear`), CLIP normalisation, times its preserved-label mask resized to 224x224 (bilinear on the
+    tensor) -> [1, 3, 224, 224]."""
     from PIL import Image
-    ref = Image.open(img_path).convert("RGB").resize((224, 224), Image.BILINEAR)
+    ref = resize_u8_linear(np.asarray(Image.open(img_path).convert("RGB"), dtype=np.uint8), 224, 224)
     lab = np.array(Image.open(mask_path).convert("L"))
     m = _to_tensor(Image.fromarray(np.where(np.isin(lab, preserve), 255, 0).astype(np.uint8)).convert("L"))
     m = torch.nn.functional.interpolate(m[None], size=(224, 224), mode="bilinear", align_corners=False)[0]
     return (_normalize(_to_tensor(ref), CLIP_MEAN, CLIP_STD) * m).unsqueeze(0)
+
+
+def raw_collate(items):
+    """Collate of raw (uint8) items: every field stacked as default_collate does, except that full-size sources / their label maps of
+    different sizes stay lists (DevicePrep resizes them one by one)."""
+    from torch.utils.data import default_collate
+    cols = list(zip(*items))
+    out = []
+    for col in cols:
+        if torch.is_tensor(col[0]) and any(c.shape != col[0].shape for c in col):
+            out.append(list(col))
+        else:
+            out.append(default_collate(list(col)))
+    return out
 
 
 def shard_indices(n, rank, world):

@@ -178,6 +178,7 @@ class LatentDiffusion(nn.Module, _DeviceMixin):
         else:
             self.register_buffer("scale_factor", torch.tensor(scale_factor))
         self.first_stage_model = instantiate_from_config(first_stage_config).eval()
+        self._sync_decode_mode(torch.float32)          # the model starts in the exact-fp32 parity mode: exact-fp32 decode too
         if cond_stage_config in ("__is_first_stage__", "__is_unconditional__"):
             raise NotImplementedError("REFace uses a CLIP cond stage")
         self.cond_stage_model = instantiate_from_config(cond_stage_config).eval()
@@ -219,6 +220,7 @@ class LatentDiffusion(nn.Module, _DeviceMixin):
         ``encoders=True`` also switches the CLIP ViT-L/14 / ArcFace towers and the VAE *encoder* (conditioning stage 4x faster; the
         conditioning vector and the inpaint latent then deviate ~1 % from fp32 -- throughput mode only; the VAE decode stays fp32)."""
         self.model.diffusion_model.set_compute_dtype(dtype)
+        self._sync_decode_mode(dtype)
         if dtype in ("fp8", "fp8w"):       # fp8 GEMM operands are a UNet mode; the towers / VAE encoder take the bf16 activations' dtype
             dtype = torch.bfloat16
         elif dtype == "f32x3":             # split-bf16 UNet operands (fast parity mode): everything around it stays fp32
@@ -229,6 +231,13 @@ class LatentDiffusion(nn.Module, _DeviceMixin):
                     m.compute_dtype = dtype
             if hasattr(self, "first_stage_model"):
                 self.first_stage_model.encode_dtype = dtype        # the masked-target latent feeds a UNet of this dtype anyway
+
+    def _sync_decode_mode(self, dtype):
+        """The fp32 VAE decode follows the UNet mode unless REFACE_VAE_DECODE pins it: exact fp32 MFMA beside the exact-fp32 UNet (the mode the
+        1e-3 gate is stated for), split-bf16 operand pairs (5e-5 from the oracle, 2.4x faster) beside every faster UNet mode."""
+        fsm = getattr(self, "first_stage_model", None)
+        if fsm is not None and hasattr(fsm, "decode_mode") and "REFACE_VAE_DECODE" not in os.environ:
+            fsm.decode_mode = "f32" if dtype == torch.float32 else "bf16x3"
 
     # ------------------------------------------------------------------ conditioning (ddpm.py:859-1045, 1068-1099)
     def get_learned_conditioning(self, c):

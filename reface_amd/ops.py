@@ -620,6 +620,16 @@ def u8_to_norm(x_u8, mean, std, out, name="u8_to_norm"):
     return Launch(lib.rf_u8_to_norm, (_p(x_u8), B, H * W_, _p(mean), _p(std), _p(out)), (x_u8, mean, std, out), name)
 
 
+def resize_u8_linear(x_u8, out, name="resize_u8_linear"):
+    """x_u8 [B, H, W, C] uint8 (HWC, contiguous images) -> out [B, Ho, Wo, C] uint8: cv2.resize(..., INTER_LINEAR) bit for bit."""
+    lib = _lib.load()
+    _require_gpu(x_u8, out)
+    B, H, W_, Cc = x_u8.shape
+    assert x_u8.dtype == torch.uint8 and out.dtype == torch.uint8 and out.is_contiguous() and out.shape[0] == B and out.shape[3] == Cc
+    assert x_u8.stride(3) == 1 and x_u8.stride(2) == Cc and x_u8.stride(1) == W_ * Cc
+    return Launch(lib.rf_resize_u8_linear, (_p(x_u8), B, H, W_, Cc, x_u8.stride(0), out.shape[1], out.shape[2], _p(out)), (x_u8, out), name)
+
+
 def label_mask(labels_u8, lut256, out, *, invert, name="label_mask"):
     lib = _lib.load()
     _require_gpu(labels_u8, lut256, out)

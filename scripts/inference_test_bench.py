@@ -157,7 +157,7 @@ def main(argv=None):
             test_args["dataset_dir"] = opt.dataset_dir
         test_args.setdefault("state", "test")
         if opt.gpu_prep:
-            test_args["raw"] = True
+            test_args["raw"] = "full"           # decode only: the 224x224 source resize (cv2 INTER_LINEAR arithmetic) runs on the GPU too
         if opt.dataset == "FF++" and opt.dataset_dir is not None:       # inference_test_bench.py:383: the flag overrides the config
             test_args["dataset_dir"] = opt.dataset_dir
         full = {"CelebA": CelebAdataset, "FFHQ": FFHQdataset, "FF++": FFdataset}[opt.dataset](**test_args)
@@ -166,7 +166,11 @@ def main(argv=None):
         raise NotImplementedError(f"--dataset {opt.dataset}: CelebA, FFHQ, FF++ and synthetic are available")
     # inference_test_bench.py:386-391: 4 worker processes, pinned host memory (the PIL decode / resize of batch i+1 overlaps batch i)
     nw = 0 if opt.dataset == "synthetic" else opt.num_workers
-    loader = torch.utils.data.DataLoader(test_dataset, batch_size=batch_size, num_workers=nw, pin_memory=True, shuffle=False,
+    collate = None
+    if opt.gpu_prep and opt.dataset != "synthetic":
+        from reface_amd.data import raw_collate
+        collate = raw_collate                       # full-size sources of different sizes stay a list
+    loader = torch.utils.data.DataLoader(test_dataset, batch_size=batch_size, num_workers=nw, pin_memory=True, shuffle=False, collate_fn=collate,
                                          drop_last=False, persistent_workers=False)
 
     start_code = None

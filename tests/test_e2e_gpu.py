@@ -316,6 +316,14 @@ def test_device_prep_matches_host(tmp_path):
         items = [raw[i] for i in range(2)]
         target, out = prep(*(torch.stack([it[k] for it in items]) for k in range(4)))
         torch.cuda.synchronize()
+        # raw="full" (what --gpu_prep asks for): the source face arrives undecimated and rf_resize_u8_linear resizes it -- same tensors
+        from reface_amd.data import raw_collate
+        full = CelebAdataset(raw="full", **kw)
+        fitems = raw_collate([full[i] for i in range(2)])
+        assert tuple(fitems[2].shape[1:3]) == (96, 80)
+        target_f, out_f = prep(*fitems[:4])
+        torch.cuda.synchronize()
+        assert torch.equal(target_f, target) and torch.equal(out_f["ref_imgs"], out["ref_imgs"]) and torch.equal(out_f["inpaint_image"], out["inpaint_image"])
         for i in range(2):
             t, _, hk, sid = host[i]
             assert sid == items[i][4]
@@ -325,6 +333,33 @@ def test_device_prep_matches_host(tmp_path):
             # the source face goes through a 512 -> 224 bilinear resize of its mask (non-integer ratio): last-bit differences of the
             # interpolation weights against torch's CPU kernel, <= 1 fp32 ulp of the O(1) products
             assert (out["ref_imgs"][i].cpu() - hk["ref_imgs"]).abs().max().item() < 2e-6
+
+
+def test_resize_u8_linear_kernel_matches_host():
+    """rf_resize_u8_linear (cv2 INTER_LINEAR arithmetic on the GPU, --gpu_prep) is bit-identical to the host restatement
+    `reface_amd.data.resize_u8_linear` -- down- and upscales, non-square, the exact 2:1 fast-area case, a strided batch -- and the
+    `raw="full"` reader + DevicePrep (stacked and ragged batches) gives the tensors of the `raw=True` reader, which resizes on the host."""
+    from reface_amd import ops
+    from reface_amd.data import resize_u8_linear
+    from reface_amd.prep import DevicePrep
+    rng = np.random.default_rng(11)
+    for (B, H, W, oh, ow) in ((2, 1024, 1024, 224, 224), (3, 300, 517, 224, 224), (1, 96, 80, 224, 224), (2, 448, 448, 224, 224), (1, 37, 53, 37, 53),
+                              (2, 512, 512, 224, 224)):
+        x = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+        xd = torch.from_numpy(x).cuda()
+        out = torch.empty((B, oh, ow, 3), dtype=torch.uint8, device="cuda")
+        ops.resize_u8_linear(xd, out)()
+        torch.cuda.synchronize()
+        for b in range(B):
+            assert np.array_equal(out[b].cpu().numpy(), resize_u8_linear(x[b], oh, ow)), (B, H, W, oh, ow, b)
+    prep = DevicePrep([1, 2, 4], [1, 2, 4, 13], True)
+    refs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for (h, w) in ((300, 200), (1024, 1024))]
+    got = prep.resize_sources([torch.from_numpy(r) for r in refs])
+    for i, r in enumerate(refs):
+        assert np.array_equal(got[i].cpu().numpy(), resize_u8_linear(r, 224, 224))
+    st = np.stack([refs[1], refs[1][::-1].copy()])
+    got = prep.resize_sources(torch.from_numpy(st))
+    assert np.array_equal(got[1].cpu().numpy(), resize_u8_linear(st[1], 224, 224))
 
 
 def test_bench_two_ranks_share_gpu():

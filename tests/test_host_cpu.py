@@ -477,3 +477,52 @@ def test_one_inference_surface():
     OI._ARGV = None
     with pytest.raises(RuntimeError, match="configure"):
         OI.run_inference()
+
+
+def test_resize_u8_linear_is_cv2_inter_linear():
+    """the source-face resize is cv2.resize(..., INTER_LINEAR) (A.Resize(224, 224), test_bench_dataset.py:141-148, 324).  cv2 is
+    absent; `resize_u8_linear` restates OpenCV's uint8 algorithm.  Pinned here by (a) vectors computed by hand from the published
+    formulas (half-pixel centres, 11-bit weights, the >> 4 / >> 16 / + 2 >> 2 vertical pass), (b) the properties the algorithm has --
+    identity at equal size, constants preserved, replicated borders, the exact 2:1 fast-area average, separability -- (c) <= 1 grey
+    level from the float bilinear (no antialias) of torch at arbitrary ratios and from PIL at an integer UPscale, where PIL's kernel has
+    the same support, and (d) that it is NOT PIL's antialiased BILINEAR when shrinking."""
+    from PIL import Image
+    from reface_amd.data import _linear_taps, resize_u8_linear
+    # (a) hand vectors: one row [0, 100, 200, 50]
+    r = np.array([[0, 100, 200, 50]], dtype=np.uint8)
+    assert resize_u8_linear(r, 1, 2).tolist() == [[50, 125]]                  # dx 0: f = 0.5 -> (0 + 100) / 2; dx 1: s = 2 -> (200 + 50) / 2
+    assert resize_u8_linear(r, 1, 3).tolist() == [[17, 150, 75]]              # scale 4/3: f = 1/6, 1.5, 2 + 5/6
+    assert resize_u8_linear(r, 1, 8).tolist() == [[0, 25, 75, 125, 175, 163, 88, 50]]      # x2 upscale: borders replicate, 1/4 - 3/4 blends
+    # fixed-point weights: 5 -> 3 columns, f = 1/3 and 2/3 are not dyadic: 2048 / 3 = 682.67 -> 683, and the pair still sums to 2048
+    s_, w0, w1 = _linear_taps(5, 3, True)
+    assert s_.tolist() == [0, 2, 3] and w1.tolist() == [683, 0, 1365] and (w0 + w1 == 2048).all()
+    c = np.array([[10, 20, 40, 80, 160]], dtype=np.uint8)
+    # out = ((2048 * ((a * w0 + b * w1) >> 4)) >> 16 + 2) >> 2 with the row weights (2048, 0)
+    exp = [(((2048 * ((10 * 1365 + 20 * 683) >> 4)) >> 16) + 2) >> 2, 40, (((2048 * ((80 * 683 + 160 * 1365) >> 4)) >> 16) + 2) >> 2]
+    assert resize_u8_linear(c, 1, 3).tolist() == [exp] and exp == [13, 40, 133]
+    # (b) properties
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(resize_u8_linear(a, 37, 53), a)
+    assert (resize_u8_linear(np.full((20, 30, 3), 77, np.uint8), 224, 224) == 77).all()
+    big = resize_u8_linear(a, 224, 224)
+    assert big.shape == (224, 224, 3) and big.dtype == np.uint8
+    assert np.array_equal(big[0, 0], a[0, 0]) and np.array_equal(big[-1, -1], a[-1, -1])        # corners: both taps on the border pixel
+    e = rng.integers(0, 256, (64, 48, 3), dtype=np.uint8)
+    v = e.astype(np.int32)
+    assert np.array_equal(resize_u8_linear(e, 32, 24), ((v[0::2, 0::2] + v[0::2, 1::2] + v[1::2, 0::2] + v[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+    assert np.array_equal(resize_u8_linear(a[:, :, 1], 100, 90), resize_u8_linear(a, 100, 90)[:, :, 1])       # channels are independent
+    # (c) against float bilinear without antialiasing (any ratio) and against PIL where its support is also two taps (integer upscale)
+    for (H, W, oh, ow) in ((1024, 1024, 224, 224), (300, 500, 224, 224), (96, 80, 224, 224), (512, 512, 224, 224)):
+        x = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        got = resize_u8_linear(x, oh, ow).astype(np.float32)
+        ref = torch.nn.functional.interpolate(torch.from_numpy(x).permute(2, 0, 1)[None].float(), size=(oh, ow), mode="bilinear",
+                                              align_corners=False)[0].permute(1, 2, 0).numpy()
+        assert np.abs(got - ref).max() < 1.0, (H, W, np.abs(got - ref).max())
+    x = rng.integers(0, 256, (56, 56, 3), dtype=np.uint8)
+    pil = np.asarray(Image.fromarray(x).resize((224, 224), Image.BILINEAR)).astype(np.int32)
+    assert np.abs(resize_u8_linear(x, 224, 224).astype(np.int32) - pil).max() <= 1
+    # (d) shrinking: PIL's BILINEAR antialiases (support grows with the ratio), cv2's INTER_LINEAR does not -- different tensors
+    x = rng.integers(0, 256, (1024, 1024, 3), dtype=np.uint8)
+    pil = np.asarray(Image.fromarray(x).resize((224, 224), Image.BILINEAR)).astype(np.int32)
+    assert np.abs(resize_u8_linear(x, 224, 224).astype(np.int32) - pil).mean() > 20

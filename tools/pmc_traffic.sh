@@ -35,7 +35,8 @@ import sys
 sys.path.insert(0, ".")
 import bench
 c = bench.CONFIGS["$cfg"]
-out["_meta"] = {"lib_digest": bench.lib_digest(), "workload": "$cfg:%dx%d:S50:B%d:%s" % (8 * c["latent"], 8 * c["latent"], c["batch"], c["dtype"]),
+import time
+out["_meta"] = {"collected_unix": time.time(), "lib_digest": bench.lib_digest(), "workload": "$cfg:%dx%d:S50:B%d:%s" % (8 * c["latent"], 8 * c["latent"], c["batch"], c["dtype"]),
                 "command": "tools/pmc_traffic.sh ${tag} $cfg (REFACE_NO_GRAPH=1, --steps 1 --warmup 0: one batch of eager launches per PMC pass)"}
 json.dump(out, open("gpurun_out/${tag}_traffic.json", "w"), indent=1)
 for k, v in sorted(((k, v) for k, v in out.items() if k != "_meta"), key=lambda kv: -kv[1].get("FETCH_SIZE_KB_raw_total", 0)):
