@@ -5,7 +5,7 @@
  * set of ATen calls issued by ldm/modules/diffusionmodules/openaimodel.py, ldm/modules/attention.py,
  * ldm/modules/diffusionmodules/model.py and ldm/models/diffusion/ddim.py.
  * Each entry point below replaces one family of those calls; the reference line it stands in for
- * is cited next to it.  The Python host layer (reface_amd/*.py) binds these with ctypes; the
+ * is cited next to it.  The Python host layer (the modules of reface_amd) binds these with ctypes; the
  * binding a reference maintainer would add is shown in INTEGRATION.md.
  *
  * Conventions
@@ -122,9 +122,12 @@ int rf_conv_gemm_plan(const rf_conv_gemm_desc* d, int32_t* bm, int32_t* bn, int3
  * accumulate, GELU on the tanh form (the bf16 mode's).  The [M, 4C] hidden tensor stays in registers (tokens on lanes, see ffn.hip).
  *   w1p / b1p : ff.net.0.proj [8C, C] / [8C] with rows interleaved in blocks of 32 (value | gate), as rf_conv_gemm's GEGLU takes them
  *   w2q       : ff.net.2 [C, 4C] with the columns of every 16-group in the order 0-3, 8-11, 4-7, 12-15
+ *   ln_eps > 0: every row of x is LayerNorm-ed first, in registers (two-pass fp32 statistics, normalised values rounded to bf16 as
+ *               rf_layernorm stores them; NO affine: the host folds norm3's gamma into w1p's columns and W1 beta into b1p) -- the kernel then
+ *               also replaces `self.norm3` (attention.py:231-233, 243) and x is the un-normalised residual stream.
  * Replaces FeedForward.forward (attention.py:40-76) + the residual add of BasicTransformerBlock (attention.py:243). */
 int rf_ffn_geglu(const void* x, int ldx, const void* w1p, const float* b1p, const void* w2q, const float* b2, const void* residual, int ldr,
-                 void* out, int ldo, int M, int C, void* stream);
+                 void* out, int ldo, int M, int C, float ln_eps, void* stream);
 
 /* Per-row fp8 quantisation of a weight matrix for the w_dtype = RF_FP8_E4M3 path: w [N][K] fp32 (row pitch K) ->
  * q [N][ldq] e4m3fn bytes (ldq >= K, a multiple of 128; the pad bytes are written as zero) and scale [N] = the smallest power of

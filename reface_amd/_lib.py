@@ -47,7 +47,7 @@ _SIGS = {
     "rf_conv_gemm": (C.c_int, [C.POINTER(ConvGemmDesc), C.c_void_p]),
     "rf_conv_gemm_plan": (C.c_int, [C.POINTER(ConvGemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rf_ffn_geglu": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
-                               C.c_int, C.c_int, C.c_void_p]),
+                               C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "rf_quantize_fp8_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rf_groupnorm_stats": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "rf_groupnorm_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

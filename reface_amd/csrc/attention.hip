@@ -345,6 +345,294 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 && NW == 4) ? 2 : 1) void attenti
 }
 
 
+// ---- fp32 attention on split-bf16 operand pairs (dtype RF_BF16X3: the "f32x3" parity mode of the UNet) ----
+// q / k / v / out are fp32 in memory.  Every operand value x enters the matrix pipe as hi = bf16(x), lo = bf16(x - hi) (16 significant
+// bits) and a product is accumulated in fp32 as hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_bf16 -- the operand form of rf_conv_gemm's
+// RF_BF16X3 mode -- for BOTH contractions:  S^T = Khi Qhi + Khi Qlo + Klo Qhi  and  O^T += Vhi Phi + Vhi Plo + Vlo Phi  with the softmax
+// probabilities split in registers (P = exp2(..) in fp32, Phi = bf16(P), Plo = bf16(P - Phi)).  Softmax state, rescaling and the output
+// stay fp32.  42 bf16 MFMAs (1344 matrix-pipe cycles) per 64 keys x 32 queries at d = 40 against 104 exact-fp32 MFMAs (6656 cycles) of
+// attention_kernel<float>; relative error ~2^-16 per product instead of 2^-24.  Same transposed formulation, staging and LDS geometry as
+// attention_kernel<bf16_t> (two images per operand: hi, lo); the spare V^T row of ones (softmax denominator) lives in the hi image only.
+template <int D, int KV_TILE = 64>
+__global__ __launch_bounds__(256, 1) void attention_x3_kernel(const AttnParams p) {
+    constexpr int NT = 256;
+    constexpr int KSTEP = 16, STEPS = (D + KSTEP - 1) / KSTEP, DVB = (D + 31) / 32;
+    constexpr int KROW = STEPS * 32 + 16, VROW = KV_TILE * 2 + 16, VPR = D / 8;
+    constexpr int K_IMG = KV_TILE * KROW, V_IMG = DVB * 32 * VROW;
+    constexpr int TILE_BYTES = 2 * (K_IMG + V_IMG);          // one stage: K hi, K lo, V^T hi, V^T lo
+    constexpr int NS = (2 * TILE_BYTES <= 160 * 1024) ? 2 : 1;
+    constexpr bool ONES = (D % 32) != 0;
+    constexpr int L_I = D / 32, L_R = ((D % 32) / 8) * 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, lh = lane >> 5;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bh = bid / p.nqb, qblk = bid - bh * p.nqb;
+    const int b = bh / p.heads, h = bh % p.heads;
+    const int q0 = qblk * 128 + wave * 32;
+    const float* Q = (const float*)p.q + b * p.sq + h * D;
+    const float* K = (const float*)p.k + b * p.sk + h * D;
+    const float* V = (const float*)p.v + b * p.sv + h * D;
+    float* O = (float*)p.out + b * p.so + h * D;
+
+    // 8 fp32 -> (hi, lo) fragments of 8 bf16
+    auto split8 = [](const f32x4_t& a, const f32x4_t& c, u32x4_t& hi, u32x4_t& lo) {
+        const float f0[4] = {a[0], a[1], a[2], a[3]}, f1[4] = {c[0], c[1], c[2], c[3]};
+        u32x2_t h0, l0, h1, l1;
+        split4_bf16(f0, h0, l0);
+        split4_bf16(f1, h1, l1);
+        hi = u32x4_t{h0[0], h0[1], h1[0], h1[1]};
+        lo = u32x4_t{l0[0], l0[1], l1[0], l1[1]};
+    };
+    const f32x4_t z4 = {0.f, 0.f, 0.f, 0.f};
+    u32x4_t qh[STEPS], ql[STEPS];
+    {
+        const int qi = q0 + lq;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int c = s * KSTEP + lh * 8;
+            f32x4_t a = z4, c4 = z4;
+            if (qi < p.Nq && c < D) {
+                const float* src = Q + (long long)qi * p.ldq + c;
+                a = *(const f32x4_t*)src;
+                c4 = *(const f32x4_t*)(src + 4);
+                if (p.scale_log2e != 1.0f) { a *= p.scale_log2e; c4 *= p.scale_log2e; }          // scores in the exp2 domain (fp32: no extra rounding issue)
+            }
+            split8(a, c4, qh[s], ql[s]);
+        }
+    }
+    for (int i = tid; i < NS * TILE_BYTES / 16; i += NT) ((u32x4_t*)smem)[i] = u32x4_t{0u, 0u, 0u, 0u};
+    if constexpr (ONES) {
+        __syncthreads();
+        if (tid < NS * KV_TILE) {
+            const int stg = tid / KV_TILE, kcol = tid - stg * KV_TILE;
+            *(bf16_t*)(smem + stg * TILE_BYTES + 2 * K_IMG + D * VROW + kcol * 2) = (bf16_t)0x3f80;          // hi image only
+        }
+    }
+    f32x16_t o[DVB];
+#pragma unroll
+    for (int i = 0; i < DVB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    constexpr int NKV = (KV_TILE * VPR + NT - 1) / NT, NVP = ((KV_TILE / 2) * VPR + NT - 1) / NT;
+    f32x4_t rk[NKV][2], rv0[NVP][2], rv1[NVP][2];
+    auto load_kv = [&](int kv0) {
+#pragma unroll
+        for (int u = 0; u < NKV; ++u) {
+            const int idx = tid + u * NT;
+            const int r = idx / VPR, c = idx - r * VPR;
+            rk[u][0] = rk[u][1] = z4;
+            if (idx < KV_TILE * VPR && kv0 + r < p.Nk) {
+                const float* src = K + (long long)(kv0 + r) * p.ldk + c * 8;
+                rk[u][0] = *(const f32x4_t*)src;
+                rk[u][1] = *(const f32x4_t*)(src + 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NVP; ++u) {
+            const int idx = tid + u * NT;
+            const int c = idx / (KV_TILE / 2), pr = idx - c * (KV_TILE / 2);
+            rv0[u][0] = rv0[u][1] = rv1[u][0] = rv1[u][1] = z4;
+            if (idx < (KV_TILE / 2) * VPR) {
+                const int kv = kv0 + 2 * pr;
+                if (kv < p.Nk) {
+                    const float* src = V + (long long)kv * p.ldv + c * 8;
+                    rv0[u][0] = *(const f32x4_t*)src;
+                    rv0[u][1] = *(const f32x4_t*)(src + 4);
+                }
+                if (kv + 1 < p.Nk) {
+                    const float* src = V + (long long)(kv + 1) * p.ldv + c * 8;
+                    rv1[u][0] = *(const f32x4_t*)src;
+                    rv1[u][1] = *(const f32x4_t*)(src + 4);
+                }
+            }
+        }
+    };
+    auto store_kv = [&](int stage) {
+        char* const kH = smem + stage * TILE_BYTES;
+        char* const kL = kH + K_IMG;
+        char* const vH = kH + 2 * K_IMG;
+        char* const vL = vH + V_IMG;
+#pragma unroll
+        for (int u = 0; u < NKV; ++u) {
+            const int idx = tid + u * NT;
+            if (idx < KV_TILE * VPR) {
+                const int r = idx / VPR, c = idx - r * VPR;
+                u32x4_t hi, lo;
+                split8(rk[u][0], rk[u][1], hi, lo);
+                *(u32x4_t*)(kH + r * KROW + c * 16) = hi;
+                *(u32x4_t*)(kL + r * KROW + c * 16) = lo;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NVP; ++u) {
+            const int idx = tid + u * NT;
+            if (idx < (KV_TILE / 2) * VPR) {
+                const int c = idx / (KV_TILE / 2), pr = idx - c * (KV_TILE / 2);
+                const int r = 2 * pr;
+                const int pos = (r & ~15) + vt_pos<bf16_t>(r & 15);          // even; key r+1 sits at pos+1
+                u32x4_t h0, l0, h1, l1;
+                split8(rv0[u][0], rv0[u][1], h0, l0);
+                split8(rv1[u][0], rv1[u][1], h1, l1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    *(uint32_t*)(vH + (c * 8 + 2 * e) * VROW + pos * 2) = (h0[e] & 0xffffu) | (h1[e] << 16);
+                    *(uint32_t*)(vH + (c * 8 + 2 * e + 1) * VROW + pos * 2) = (h0[e] >> 16) | (h1[e] & 0xffff0000u);
+                    *(uint32_t*)(vL + (c * 8 + 2 * e) * VROW + pos * 2) = (l0[e] & 0xffffu) | (l1[e] << 16);
+                    *(uint32_t*)(vL + (c * 8 + 2 * e + 1) * VROW + pos * 2) = (l0[e] >> 16) | (l1[e] & 0xffff0000u);
+                }
+            }
+        }
+    };
+    auto mma = [](f32x16_t& acc, const u32x4_t& a, const u32x4_t& bq) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bq), acc, 0, 0, 0);
+    };
+
+    const int ntiles = (p.Nk + KV_TILE - 1) / KV_TILE;
+    load_kv(0);
+    __syncthreads();
+    store_kv(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t * KV_TILE;
+        const char* const kH = smem + (NS == 2 ? (t & 1) : 0) * TILE_BYTES;
+        const char* const kL = kH + K_IMG;
+        const char* const vH = kH + 2 * K_IMG;
+        const char* const vL = vH + V_IMG;
+        if (t + 1 < ntiles) load_kv(kv0 + KV_TILE);
+#pragma unroll
+        for (int sub = 0; sub < KV_TILE / KV_SUB; ++sub) {
+            const int kvs = kv0 + sub * KV_SUB;
+            if (sub > 0 && kvs >= p.Nk) break;
+            f32x16_t s[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                s[kb] = f32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < STEPS; ++st) {
+                    const int off = (sub * KV_SUB + kb * 32 + lq) * KROW + st * 32 + lh * 16;
+                    const u32x4_t kfh = *(const u32x4_t*)(kH + off), kfl = *(const u32x4_t*)(kL + off);
+                    mma(s[kb], kfl, qh[st]);          // small terms first
+                    mma(s[kb], kfh, ql[st]);
+                    mma(s[kb], kfh, qh[st]);
+                }
+            }
+            if (kvs + KV_SUB > p.Nk) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kvs + kb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3) >= p.Nk) s[kb][r] = -INFINITY;
+            }
+            float mx = s[0][0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            if (__any(m_new != m_run)) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < DVB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+                m_run = m_new;
+            }
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+                    s[kb][r] = e;
+                    if constexpr (!ONES) psum += e;
+                }
+            if constexpr (!ONES) l_run += psum;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {          // 16 keys per MFMA triple
+                    u32x4_t ph, pl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = s[kb][8 * g + 2 * e], c = s[kb][8 * g + 2 * e + 1];
+                        ph[e] = pack_bf2(a, c);
+                        pl[e] = pack_bf2(a - as_f32(ph[e] << 16), c - as_f32(ph[e] & 0xffff0000u));
+                    }
+#pragma unroll
+                    for (int i = 0; i < DVB; ++i) {
+                        const int off = (i * 32 + lq) * VROW + (sub * KV_SUB + kb * 32 + g * 16) * 2 + lh * 16;
+                        const u32x4_t vfh = *(const u32x4_t*)(vH + off), vfl = *(const u32x4_t*)(vL + off);
+                        mma(o[i], vfl, ph);
+                        mma(o[i], vfh, pl);
+                        mma(o[i], vfh, ph);
+                    }
+                }
+        }
+        if (t + 1 < ntiles) {
+            if (NS == 1) __syncthreads();
+            store_kv(NS == 2 ? ((t + 1) & 1) : 0);
+        }
+        __syncthreads();
+    }
+    {
+        float l_tot;
+        if constexpr (ONES) l_tot = __shfl(o[L_I][L_R], lq, 64);
+        else l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int qi = q0 + lq;
+        if (qi < p.Nq) {
+#pragma unroll
+            for (int i = 0; i < DVB; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int dv = i * 32 + 8 * g + 4 * lh;
+                    if (dv < D) *(f32x4_t*)(O + (long long)qi * p.ldo + dv) = f32x4_t{o[i][4 * g] * inv, o[i][4 * g + 1] * inv, o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv};
+                }
+        }
+    }
+}
+
+template <int D>
+static int launch_attn_x3(const AttnParams& p, int B, hipStream_t st) {
+    constexpr int KV_TILE = 64, STEPS = (D + 15) / 16, DVB = (D + 31) / 32;
+    constexpr int tile_bytes = 2 * (KV_TILE * (STEPS * 32 + 16) + DVB * 32 * (KV_TILE * 2 + 16));
+    constexpr int smem = (2 * tile_bytes <= 160 * 1024 ? 2 : 1) * tile_bytes;
+    auto k = attention_x3_kernel<D, KV_TILE>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+    AttnParams pp = p;
+    pp.nqb = (p.Nq + 127) / 128;
+    hipLaunchKernelGGL(k, dim3(pp.nqb * B * p.heads), dim3(256), smem, st, pp);
+    RF_LAUNCH_CHECK("rf_attention");
+    return 0;
+}
+
+static int dispatch_attn_x3(const AttnParams& p, int B, hipStream_t st) {
+    switch (p.d) {
+        case 40: return launch_attn_x3<40>(p, B, st);
+        case 64: return launch_attn_x3<64>(p, B, st);
+        case 80: return launch_attn_x3<80>(p, B, st);
+        case 160: return launch_attn_x3<160>(p, B, st);
+        case 8: return launch_attn_x3<8>(p, B, st);
+        case 16: return launch_attn_x3<16>(p, B, st);
+        case 32: return launch_attn_x3<32>(p, B, st);
+        default: break;
+    }
+    set_error("rf_attention: head dim %d not instantiated (have 8,16,32,40,64,80,160)", p.d);
+    return 1;
+}
+
 // max of a value with its partner lane in the other half of the wave (lane ^ 32): v_permlane32_swap, a VALU operation -- the
 // ds_bpermute of __shfl_xor waits for every LDS read in flight (the prefetched fragments) on the softmax's critical path.
 __device__ __forceinline__ float max_xor32(float v) {
@@ -725,9 +1013,9 @@ static int dispatch_attn(const AttnParams& p, int B, hipStream_t st) {
 extern "C" int rf_attention(int dtype, const void* q, const void* k, const void* v, void* out, int B, int heads, int d, int Nq, int Nk,
                             int ldq, int ldk, int ldv, int ldo, int64_t sq, int64_t sk, int64_t sv, int64_t so, float scale, void* stream) {
     using namespace rf;
-    RF_CHECK(dtype == RF_F32 || dtype == RF_BF16, "rf_attention: bad dtype %d", dtype);
+    RF_CHECK(dtype == RF_F32 || dtype == RF_BF16 || dtype == RF_BF16X3, "rf_attention: bad dtype %d", dtype);
     RF_CHECK(q && k && v && out && B > 0 && heads > 0 && Nq > 0 && Nk > 0, "rf_attention: bad arguments");
-    const int vec = dtype == RF_F32 ? 4 : 8;
+    const int vec = dtype == RF_BF16 ? 8 : 4;
     RF_CHECK(d % 8 == 0 && ldq % vec == 0 && ldk % vec == 0 && ldv % vec == 0 && ldo % 4 == 0, "rf_attention: d/ld alignment (d=%d)", d);
     RF_CHECK(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16 == 0, "rf_attention: operands must be 16-byte aligned");
     RF_CHECK((long long)B * heads * ((Nq + 127) / 128) < (1LL << 31), "rf_attention: grid too large");
@@ -737,6 +1025,7 @@ extern "C" int rf_attention(int dtype, const void* q, const void* k, const void*
     p.sq = sq; p.sk = sk; p.sv = sv; p.so = so;
     p.scale_log2e = scale * 1.4426950408889634f;
     if (fabsf(p.scale_log2e - 1.0f) < 1e-6f) p.scale_log2e = 1.0f;       // scale = ln 2: the caller's scores are already in the exp2 domain
+    if (dtype == RF_BF16X3) return dispatch_attn_x3(p, B, (hipStream_t)stream);          // fp32 in memory, split-bf16 operand pairs on the bf16 MFMA
     if (dtype == RF_F32) return dispatch_attn<float>(p, B, (hipStream_t)stream);
     return dispatch_attn<bf16_t>(p, B, (hipStream_t)stream);
 }

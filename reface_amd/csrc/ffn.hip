@@ -24,6 +24,7 @@ struct FfnParams {
     const bf16_t* res; int ldr;
     bf16_t* out; int ldo;
     int M;
+    float ln_eps;          // > 0: x rows are LayerNorm-ed in registers first (no affine: gamma / beta are folded into w1 / b1 by the host)
 };
 
 __device__ __forceinline__ int ffn_lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
@@ -61,6 +62,47 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
     for (int s_ = 0; s_ < CK * 4; ++s_) {
         xq[s_] = u32x4_t{0u, 0u, 0u, 0u};
         if (row < p.M) xq[s_] = *(const u32x4_t*)(p.x + (long long)row * p.ldx + s_ * 16 + lhalf * 8);
+    }
+
+    // LayerNorm of the token's row in registers (attention.py:231-233 `norm3` in front of the feed-forward): the lane pair (tok, half 0 / 1)
+    // holds all C values of the row -- two-pass statistics in fp32 as rf_layernorm computes them, the normalised values rounded to bf16
+    // as that pass stores them.  gamma rides in W1's columns, beta in b1 (host), so the separate pass (one read + one write of [M, C]) and
+    // its launch are gone.
+    if (p.ln_eps > 0.f) {
+        float sum = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < CK * 4; ++s_) {
+            float f[8];
+            unpack16<bf16_t>(xq[s_], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += f[e];
+        }
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(as_u32(sum), as_u32(sum), false, false);
+            sum = as_f32(sw[0]) + as_f32(sw[1]);
+        }
+        const float mu = sum / (float)C;
+        float sq = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < CK * 4; ++s_) {
+            float f[8];
+            unpack16<bf16_t>(xq[s_], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = f[e] - mu; sq += d * d; }
+        }
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(as_u32(sq), as_u32(sq), false, false);
+            sq = as_f32(sw[0]) + as_f32(sw[1]);
+        }
+        const float rstd = 1.0f / sqrtf(sq / (float)C + p.ln_eps);
+#pragma unroll
+        for (int s_ = 0; s_ < CK * 4; ++s_) {
+            float f[8];
+            unpack16<bf16_t>(xq[s_], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (f[e] - mu) * rstd;
+            xq[s_] = pack16<bf16_t>(f);
+        }
     }
 
     const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, (unsigned)(2 * F * C * 2), 0x00020000);
@@ -241,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
 }  // namespace rf
 
 extern "C" int rf_ffn_geglu(const void* x, int ldx, const void* w1p, const float* b1p, const void* w2q, const float* b2, const void* residual,
-                            int ldr, void* out, int ldo, int M, int C, void* stream) {
+                            int ldr, void* out, int ldo, int M, int C, float ln_eps, void* stream) {
     using namespace rf;
     RF_CHECK(x && w1p && b1p && w2q && b2 && out && M > 0, "rf_ffn_geglu: bad arguments");
     RF_CHECK(C == 320, "rf_ffn_geglu: built for C = 320 (the 64x64 level), got %d", C);
@@ -251,7 +293,7 @@ extern "C" int rf_ffn_geglu(const void* x, int ldx, const void* w1p, const float
     RF_CHECK((long long)M * ldx * 2 < 0x7fff0000LL, "rf_ffn_geglu: x too large for 31-bit byte offsets");
     FfnParams p;
     p.x = (const bf16_t*)x; p.ldx = ldx; p.w1 = (const bf16_t*)w1p; p.b1 = b1p; p.w2 = (const bf16_t*)w2q; p.b2 = b2;
-    p.res = (const bf16_t*)residual; p.ldr = ldr; p.out = (bf16_t*)out; p.ldo = ldo; p.M = M;
+    p.res = (const bf16_t*)residual; p.ldr = ldr; p.out = (bf16_t*)out; p.ldo = ldo; p.M = M; p.ln_eps = ln_eps;
     constexpr int smem = 4 * 16384 + 2 * 320 * 128 + 2 * 4 * 512;
     auto k = ffn_geglu_kernel<320>;
     static bool attr = false;

@@ -118,8 +118,16 @@ def pack_ffn_w2(w2, dtype=torch.bfloat16):
     return w2[:, idx].to(dtype).contiguous()
 
 
-def ffn_geglu(x, w1p, b1p, w2q, b2, out, *, residual=None, name="ffn_geglu"):
-    """out[M, C] = (GEGLU(x W1^T + b1)) W2^T + b2 (+ residual), one kernel, hidden tensor on chip (C = 320, bf16)."""
+def fold_layernorm_geglu(w1, b1, gamma, beta):
+    """LayerNorm's affine folded into the GEGLU projection behind it:  (xhat * gamma + beta) W1^T + b1 = xhat (W1 diag(gamma))^T + (b1 + W1 beta).
+    w1 [2F, C], b1 [2F], gamma / beta [C] (reference layout, fp32) -> (w1', b1') for pack_geglu; the kernel then only normalises (ln_eps)."""
+    w1f = w1.float()
+    return w1f * gamma.float()[None, :], b1.float() + w1f @ beta.float()
+
+
+def ffn_geglu(x, w1p, b1p, w2q, b2, out, *, residual=None, ln_eps=0.0, name="ffn_geglu"):
+    """out[M, C] = (GEGLU(x W1^T + b1)) W2^T + b2 (+ residual), one kernel, hidden tensor on chip (C = 320, bf16).  ln_eps > 0: the rows
+    of x are LayerNorm-ed in registers first (no affine -- fold gamma / beta with fold_layernorm_geglu)."""
     lib = _lib.load()
     _require_gpu(x, w1p, b1p, w2q, b2, out, residual)
     M, Cc = x.shape
@@ -127,7 +135,7 @@ def ffn_geglu(x, w1p, b1p, w2q, b2, out, *, residual=None, name="ffn_geglu"):
     assert w1p.shape == (8 * Cc, Cc) and w2q.shape == (Cc, 4 * Cc) and w1p.is_contiguous() and w2q.is_contiguous()
     assert x.stride(1) == 1 and out.stride(1) == 1 and (residual is None or (residual.stride(1) == 1 and residual.dtype == out.dtype))
     return Launch(lib.rf_ffn_geglu, (_p(x), x.stride(0), _p(w1p), _p(b1p), _p(w2q), _p(b2), _p(residual),
-                                     residual.stride(0) if residual is not None else 0, _p(out), out.stride(0), M, Cc),
+                                     residual.stride(0) if residual is not None else 0, _p(out), out.stride(0), M, Cc, float(ln_eps)),
                   (x, w1p, b1p, w2q, b2, out, residual), name)
 
 
@@ -528,15 +536,17 @@ def layernorm(x, gamma, beta, out, *, eps=1e-5, name="layernorm"):
                                      RF_BF16X3 if split else code(out.dtype), _p(out), out.stride(0)), (x, gamma, beta, out), name)
 
 
-def attention(q, k, v, out, *, heads, scale, name="attention"):
-    """q/k/v/out: [B, N, heads*d] views (last dim contiguous; may be slices of a fused qkv buffer)."""
+def attention(q, k, v, out, *, heads, scale, x3=False, name="attention"):
+    """q/k/v/out: [B, N, heads*d] views (last dim contiguous; may be slices of a fused qkv buffer).  x3: fp32 tensors multiplied as
+    split-bf16 operand pairs (hi hi + hi lo + lo hi on the bf16 MFMA, both contractions; fp32 softmax, accumulation and output) -- the
+    attention of the "f32x3" parity mode, 2^-16 relative error per product instead of the exact-fp32 MFMA's 2^-24 at a fifth of its time."""
     lib = _lib.load()
     _require_gpu(q, k, v, out)
     B, Nq, Cc = q.shape
     Nk = k.shape[1]
     d = Cc // heads
-    assert q.dtype == k.dtype == v.dtype == out.dtype
-    return Launch(lib.rf_attention, (code(q.dtype), _p(q), _p(k), _p(v), _p(out), B, heads, d, Nq, Nk, q.stride(1), k.stride(1),
+    assert q.dtype == k.dtype == v.dtype == out.dtype and (not x3 or q.dtype == torch.float32)
+    return Launch(lib.rf_attention, (RF_BF16X3 if x3 else code(q.dtype), _p(q), _p(k), _p(v), _p(out), B, heads, d, Nq, Nk, q.stride(1), k.stride(1),
                                      v.stride(1), out.stride(1), q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale)),
                   (q, k, v, out), name)
 

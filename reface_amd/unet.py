@@ -98,6 +98,9 @@ class UNetEngine:
         # GEGLU + ff.net.2 of the C = 320 blocks as ONE kernel (csrc/ffn.hip): 213 us against 150 + 80 for the pair inside the step -- the pair's
         # epilogues are store-bound and ff.net.2's residual segments cost ~20 us; -0.4 % per batch, same box (tools/exp_r03_17.sh).  =0: the pair
         self.ffn_fuse = os.environ.get("REFACE_FFN_FUSE", "1") == "1"
+        # norm3 inside the fused feed-forward kernel (C = 320 blocks): REFACE_LN_FOLD=0 keeps the separate LayerNorm pass
+        self.ln_fold = os.environ.get("REFACE_LN_FOLD", "1") == "1"
+        self.n_ln_folded = 0
         self.n_cu = torch.cuda.get_device_properties(device).multi_processor_count if torch.cuda.is_available() else 256
         self.gn_fused = 0
         self.pool = _Pool(device)
@@ -366,18 +369,29 @@ class UNetEngine:
         if pair or a8:
             self.pool.put(ln)
             ln = self.aget((nb * M, c)) if a8 else self.pool.get((nb * M, c), self.dt)
-        self.main.append(ops.layernorm(x1, self.f32(f"{t}.norm3.weight"), self.f32(f"{t}.norm3.bias"), ln, name=f"{t}.norm3"))
-        wg, bg = ops.pack_geglu(self.sd[f"{t}.ff.net.0.proj.weight"], self.sd[f"{t}.ff.net.0.proj.bias"], F32)
         # (one block of the fused kernel per 128 tokens and CU: only where those blocks come in nearly whole rounds -- 576 blocks at configs[3]
         #  are 2.25 rounds of 256 CUs and lose 0.5 % per batch against the pair, tools/exp_r03_20.sh)
         nblk = (nb * M + 127) // 128
         whole = nblk / (self.n_cu * ((nblk + self.n_cu - 1) // self.n_cu))
-        if self.ffn_fuse and c == 320 and self.dt == torch.bfloat16 and not self.w8 and whole >= 0.9:
+        fused_ffn = self.ffn_fuse and c == 320 and self.dt == torch.bfloat16 and not self.w8 and whole >= 0.9
+        fold = fused_ffn and self.ln_fold
+        w1s, b1s = self.sd[f"{t}.ff.net.0.proj.weight"], self.sd[f"{t}.ff.net.0.proj.bias"]
+        if fold:
+            # ... and norm3 inside that kernel too: a lane pair holds the token's whole row, so the LayerNorm is ~400 VALU operations per lane in
+            # registers; gamma rides in W1's columns, beta in b1 -- the rf_layernorm pass over [M, C] and its launch are gone
+            self.pool.put(ln)
+            w1s, b1s = ops.fold_layernorm_geglu(w1s, b1s, self.sd[f"{t}.norm3.weight"], self.sd[f"{t}.norm3.bias"])
+            self.n_ln_folded += 1
+        else:
+            self.main.append(ops.layernorm(x1, self.f32(f"{t}.norm3.weight"), self.f32(f"{t}.norm3.bias"), ln, name=f"{t}.norm3"))
+        wg, bg = ops.pack_geglu(w1s, b1s, F32)
+        if fused_ffn:
             # one kernel: the [M, 4C] hidden tensor (168 MB at 64x64) stays in registers (csrc/ffn.hip)
             x2 = self.pool.get((nb * M, c), self.dt)
-            self.main.append(ops.ffn_geglu(ln, wg.to(self.dt).contiguous(), bg, ops.pack_ffn_w2(self.sd[f"{t}.ff.net.2.weight"], self.dt),
-                                           self.f32(f"{t}.ff.net.2.bias"), x2, residual=x1, name=f"{t}.ff"))
-            self.pool.put(ln)
+            self.main.append(ops.ffn_geglu(x1 if fold else ln, wg.to(self.dt).contiguous(), bg, ops.pack_ffn_w2(self.sd[f"{t}.ff.net.2.weight"], self.dt),
+                                           self.f32(f"{t}.ff.net.2.bias"), x2, residual=x1, ln_eps=1e-5 if fold else 0.0, name=f"{t}.ff"))
+            if not fold:
+                self.pool.put(ln)
         else:
             wg = self.gw8(wg, 1, c) if a8 else self.gw(wg)
             # fp8 mode: the gated hidden tensor leaves the GEGLU epilogue as fp8 + block scales (half the bytes of the widest tensor of the
@@ -432,8 +446,9 @@ class UNetEngine:
         self.pool.put(ln)
         att = self.pool.get((M, c), F32)
         q3 = qkv.view(B, H * W, 3 * c)
+        # split-bf16 operand pairs for both contractions of the attention too (REFACE_X3_ATTN=0: the exact-fp32 MFMA kernel)
         self.main.append(ops.attention(q3[..., :c], q3[..., c:2 * c], q3[..., 2 * c:], att.view(B, H * W, c), heads=heads,
-                                       scale=ops.LN2, name=f"{t}.attn1"))
+                                       scale=ops.LN2, x3=os.environ.get("REFACE_X3_ATTN", "1") == "1", name=f"{t}.attn1"))
         x1 = self.pool.get((nb * M, c), F32)
         atts = self.split_in(att)
         w_out, b_out, cv = ops.pack_x3(self.sd[f"{t}.attn1.to_out.0.weight"]), self.f32(f"{t}.attn1.to_out.0.bias"), self.ctx_vec(p)

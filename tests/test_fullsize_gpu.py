@@ -112,7 +112,8 @@ def test_unet_full_width_full_size_vs_oracle(full_unet, hw):
     assert e32 < 2e-4 * max(1.0, scale), (e32, scale)
     # (2) the sampler's engine (uniform timestep, CFG-shared stem, statistics from GEMM epilogues), fp32 and bf16
     # ("f32x3": fp32 storage, split-bf16 GEMM operands in three bf16 MFMA passes -- the fast form of the parity mode, under a 1e-3-class bound)
-    for dt, lim in ((torch.float32, 2e-4), ("f32x3", 8e-4), (torch.bfloat16, 0.05)):
+    # (bf16: 1.0 % measured at both sizes -- the bound is 2 %, so that a 2x regression of the throughput mode fails)
+    for dt, lim in ((torch.float32, 2e-4), ("f32x3", 8e-4), (torch.bfloat16, 0.02)):
         m.set_compute_dtype(dt)
         eng = m.engine(2, hw, hw, uniform_t=True, cfg_pair=True)
         ops.nchw_to_nhwc(x.to(DEV), eng.x_in)()
@@ -133,7 +134,8 @@ def test_unet_full_width_full_size_vs_oracle(full_unet, hw):
         else:                                   # bf16: relative L2 of the whole eps tensor + a max-norm bound, stated
             rel = ((out - ref).norm() / ref.norm()).item()
             emax = (out - ref).abs().max().item()
-            assert rel < lim and emax < 0.25 * scale, (dt, rel, emax, scale)
+            print(f"UNet {hw}x{hw} [bf16]: rel L2 {rel:.4f}, max |d| {emax:.4f} of {scale:.2f}")
+            assert rel < lim and emax < 0.12 * scale, (dt, rel, emax, scale)
         m._engines.clear()
         del eng
         torch.cuda.empty_cache()
@@ -167,7 +169,8 @@ def test_unet_bf16_batch16_cfg_matches_oracle_rows(full_unet):
     out = out.cpu()
     got = torch.stack([out[0], out[B]])
     rel = ((got - ref).norm() / ref.norm()).item()
-    assert torch.isfinite(out).all() and rel < 0.05, rel
+    print(f"c1 engine (CFG batch 16 @64x64, bf16) vs oracle pair: rel L2 {rel:.4f}")
+    assert torch.isfinite(out).all() and rel < 0.02, rel          # 1.0 % measured
     # the plan really is the big-tile one
     tiles = set()
     for l in eng.main:
@@ -199,7 +202,7 @@ def test_unet_bf16_c3_engine_shape_matches_oracle_rows(full_unet):
     rel = ((got - ref).norm() / ref.norm()).item()
     emax = (got - ref).abs().max().item()
     print(f"c3 engine (CFG batch 8 @96x96, bf16) vs oracle pair: rel L2 {rel:.4f}, max |d| {emax:.4f} of {ref.abs().max().item():.3f}")
-    assert torch.isfinite(out).all() and rel < 0.05 and emax < 0.25 * ref.abs().max().item(), (rel, emax)
+    assert torch.isfinite(out).all() and rel < 0.02 and emax < 0.12 * ref.abs().max().item(), (rel, emax)          # 1.0 % measured
     tiles = _gemm_tiles(eng)
     assert tiles[(8 * hw * hw, 320)] == (128, 160), tiles[(8 * hw * hw, 320)]        # the quarter-tile branch
     assert (256, 320) in set(tiles.values()) or (128, 320) in set(tiles.values()), set(tiles.values())
@@ -258,7 +261,7 @@ def test_unet_fp8_c4_engine_shape_matches_oracle_rows(full_unet, mode):
     got = torch.stack([out[0], out[B]])
     rel_q = ((got - ref_q).norm() / ref_q.norm()).item()
     print(f"c4 engine (CFG batch 32 @64x64, {mode}) vs oracle(dequantised weights): rel L2 {rel_q:.4f} ({nq} tensors quantised)")
-    assert torch.isfinite(out).all() and rel_q < (0.05 if mode == "fp8w" else 0.12), rel_q
+    assert torch.isfinite(out).all() and rel_q < (0.02 if mode == "fp8w" else 0.06), rel_q          # measured: 0.9 % (fp8w) / 4.0 % (fp8)
 
 
 # ------------------------------------------------------------------------------------------------ conditioning encoders at full size
@@ -674,6 +677,69 @@ def test_full_width_ddim5_decode_vs_oracle(full_unet, full_vae, mode):
     # the gate is the pixel one (north_star: |d| < 1e-3 on the decoded image); the latents (|z| up to ~5 before the 1 / 0.18215 rescale) of the
     # split-bf16 form carry its dropped lo x lo products (2^-16 relative per product) through 10 UNet evaluations: 3.5e-3 measured, 5e-3 stated
     assert e_lat < (5e-3 if mode == "f32x3" else 1e-3) and e_img < 1e-3, (e_lat, e_img)
+    m._engines.clear()
+    m.set_compute_dtype(torch.float32)
+    torch.cuda.empty_cache()
+
+
+_DDIM50_REF = {}
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("mode", [torch.float32, "f32x3"])
+def test_full_width_ddim50_decode_vs_reference_golden(full_unet, full_vae, mode, golden_dir):
+    """SURVEY 8d, the gate at FULL S and FULL width: 50 CFG DDIM steps at 64x64, B = 2, scale 3.5, + VAE decode -- against what the
+    REFERENCE ITSELF produced for the same seeded weights and inputs (tests/golden/ddim_full_S50_B2.npz: the reference's UNetModel under the
+    reference's DDIMSampler, ddim.py:141-251, then the reference's AutoencoderKL.decode; tools/gen_golden.py ddim_full, ~20 CPU-minutes in
+    the build container).  The fixture holds the final latents, the last pred_x0 and every 8th pixel of the decoded images; the full
+    reference image is the ORACLE's decode of the stored latents, and that decode is first checked against the stored pixels.
+    Gate: |d| < 1e-3 per pixel in the exact-fp32 mode (fp32 decode) and in its fast form "f32x3" (split-bf16 decode)."""
+    import types
+    import numpy as np
+    from oracle import vae as ovae
+    from reface_amd.ddim import DDIMSampler
+    from reface_amd.schedule import ddpm_buffers
+    path = os.path.join(golden_dir, "ddim_full_S50_B2.npz")
+    g = np.load(path)
+    m, usd = full_unet
+    vae, vsd = full_vae
+    assert int(g["seed_unet"]) == 1234 and int(g["seed_vae"]) == 55 and int(g["S"]) == 50
+    ref_lat = torch.from_numpy(g["samples"])
+    if not _DDIM50_REF:
+        _oracle_threads()
+        with torch.no_grad():
+            _DDIM50_REF["img"] = ovae.decode_first_stage(vsd, vae.cfg, ref_lat)
+        # the oracle's full-size decode against the reference's own decode of the same latents, at the stored pixels
+        e_dec = (_DDIM50_REF["img"][:, :, ::8, ::8] - torch.from_numpy(g["image_stride8"])).abs().max().item()
+        print(f"oracle decode vs reference decode (every 8th pixel of 2 x 512x512): max |d| = {e_dec:.2e}")
+        assert e_dec < 1e-4, e_dec
+    ref_img = _DDIM50_REF["img"]
+    m.set_compute_dtype(mode)
+    b = ddpm_buffers(1000, 0.00085, 0.0120)
+    ldm = types.SimpleNamespace(num_timesteps=1000, betas=b["betas"], alphas_cumprod=b["alphas_cumprod"],
+                                alphas_cumprod_prev=b["alphas_cumprod_prev"], device=torch.device(DEV),
+                                model=types.SimpleNamespace(diffusion_model=m))
+    B, h, S = 2, 64, 50
+    x_T = rnd((B, 4, h, h), 480)
+    mask = (rnd((B, 1, h, h), 482) > 0).float()
+    z_inp = rnd((B, 4, h, h), 481) * mask
+    c, uc = rnd((B, 1, 768), 483), rnd((1, 1, 768), 484).repeat(B, 1, 1)
+    got, inter = DDIMSampler(ldm).sample(S=S, conditioning=c.to(DEV), batch_size=B, shape=[4, h, h], verbose=False, log_every_t=100,
+                                        unconditional_guidance_scale=3.5, unconditional_conditioning=uc.to(DEV), eta=0.0, x_T=x_T.to(DEV),
+                                        test_model_kwargs={"inpaint_image": z_inp.to(DEV), "inpaint_mask": mask.to(DEV)})
+    keep = vae.decode_mode
+    vae.decode_mode = "f32" if mode == torch.float32 else "bf16x3"
+    img = vae.decode(got, inv_scale=1.0 / 0.18215)
+    vae.decode_mode = keep
+    torch.cuda.synchronize()
+    e_lat = (got.cpu() - ref_lat).abs().max().item()
+    e_x0 = (inter["pred_x0"][-1].cpu() - torch.from_numpy(g["pred_x0_last"])).abs().max().item()
+    e_img = (img.cpu() - ref_img).abs().max().item()
+    print(f"50-step CFG DDIM B=2 + decode [{mode}] vs the reference's run: latents max |d| = {e_lat:.3e}, last pred_x0 {e_x0:.3e}, "
+          f"pixels max |d| = {e_img:.3e} (image absmax {float(g['image_absmax']):.2f})")
+    # the gate is the pixel one (north_star: |d| < 1e-3 on the decoded image); the latents are stated beside it
+    assert e_img < 1e-3, (e_lat, e_img)
+    assert e_lat < (5e-3 if mode == "f32x3" else 1e-3), e_lat
     m._engines.clear()
     m.set_compute_dtype(torch.float32)
     torch.cuda.empty_cache()

@@ -242,6 +242,30 @@ def test_attention(dt, heads, d, N):
     check(out, ref, dt)
 
 
+@pytest.mark.parametrize("heads,d,N", [(8, 40, 256), (8, 80, 144), (8, 160, 64), (2, 160, 200), (16, 64, 257), (4, 8, 36), (8, 40, 1024), (8, 40, 4096)])
+def test_attention_x3_vs_fp64(heads, d, N):
+    """rf_attention dtype RF_BF16X3 (the attention of the "f32x3" parity mode): fp32 tensors, both contractions on split-bf16 operand
+    pairs (three bf16 MFMA passes), fp32 softmax -- against an fp64 reference (attention.py:206-220), beside the exact-fp32 kernel's
+    distance to the same reference.  Logits of realistic spread (|s| up to ~10 in the exp2 domain)."""
+    B = 2
+    C_ = heads * d
+    qkv = (rnd((B, N, 3 * C_), 130) * 1.0).to(DEV)
+    qq, kk, vv = qkv[..., :C_], qkv[..., C_:2 * C_], qkv[..., 2 * C_:]
+    scale = d ** -0.5 * 2.0
+    out = torch.empty((B, N, C_), dtype=torch.float32, device=DEV)
+    out32 = torch.empty_like(out)
+    ops.attention(qq, kk, vv, out, heads=heads, scale=scale, x3=True)()
+    ops.attention(qq, kk, vv, out32, heads=heads, scale=scale)()
+    torch.cuda.synchronize()
+    q64, k64, v64 = (t.double().cpu().reshape(B, N, heads, d).permute(0, 2, 1, 3) for t in (qq, kk, vv))
+    att = torch.softmax(q64 @ k64.transpose(-1, -2) * scale, dim=-1)
+    ref = (att @ v64).permute(0, 2, 1, 3).reshape(B, N, C_)
+    e3 = (out.double().cpu() - ref).abs().max().item()
+    e32 = (out32.double().cpu() - ref).abs().max().item()
+    print(f"attention x3 (heads {heads}, d {d}, N {N}): max |d| vs fp64 = {e3:.2e} (exact-fp32 kernel: {e32:.2e}; |out| max {ref.abs().max().item():.2f})")
+    assert torch.isfinite(out).all() and e3 < 1e-4 * max(1.0, ref.abs().max().item()), (e3, e32)
+
+
 def test_attention_spike_forces_rescale():
     """Online-softmax rescale branch: one key dominates from a late tile (guide rule 26)."""
     B, heads, d, N = 1, 1, 40, 320
@@ -419,6 +443,36 @@ def test_conv_split_k_fragment_slabs(dt, B, hw, Ci, Co):
     assert torch.equal(o1, out)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_split_k_fragment_slabs_ragged_m_with_fused_stats(dt):
+    """M < BM with split-K through fragment slabs AND fused GroupNorm statistics (CFG off, one sample at the 8x8 level: M = 64 on a 128-row
+    tile): the reduce pass's stripes with row0 >= M have no statistics slot.  Two launches, one per sample, write one [2, 8, 8, C] tensor;
+    sample 1's producer runs FIRST -- a stripe of sample 0's launch that wrote a slot beyond its M would zero sample 1's statistics
+    (or, for the last sample, write past the end of the buffer: the round-3 advisor finding)."""
+    B, hw, Ci, Co = 2, 8, 1280, 320
+    x, xr = q(rnd((B, hw, hw, Ci), 150) * 0.5, dt)
+    w = rnd((Co, Ci, 3, 3), 151) / math.sqrt(Ci * 9)
+    b = rnd((Co,), 152)
+    out = torch.empty((B, hw, hw, Co), dtype=dt, device=DEV)
+    wp = ops.pack_conv_weight(w, dt).to(DEV)
+    ls = [ops.conv2d(x[i:i + 1], wp, out[i:i + 1], b.to(DEV)) for i in range(B)]
+    bm, bn, sk = ops.gemm_plan(ls[0])
+    assert sk > 1 and bm == 32 and hw * hw < 128, (bm, bn, sk)          # fragment reduce pass (32-row stripes) under a 128-row tile
+    fused = ops.fuse_groupnorm_stats(out, [(ls[i], i * hw * hw, hw * hw, 0, Co) for i in range(B)])
+    assert fused is not None
+    ls[1]()
+    ls[0]()
+    ops.run(fused[2])
+    g, be = rnd((Co,), 153) * 0.2 + 1, rnd((Co,), 154) * 0.2
+    y = torch.empty_like(out)
+    ops.groupnorm_apply(out, g.to(DEV), be.to(DEV), y, fused[0], fused[1], eps=1e-5, silu=True)()
+    torch.cuda.synchronize()
+    ref = F.conv2d(xr.to(DEV).permute(0, 3, 1, 2), w.to(dt).float().to(DEV), b.to(DEV), padding=1).permute(0, 2, 3, 1).cpu()
+    check(out, ref, dt)
+    refn = F.silu(F.group_norm(out.float().cpu().permute(0, 3, 1, 2), 32, g, be, 1e-5)).permute(0, 2, 3, 1)
+    check(y, refn, dt)
+
+
 # ------------------------------------------------------------------------------------------------ fp8 weight path (BASELINE configs[4])
 def _fp8_ref(w):
     """CPU reference of rf_quantize_fp8_rows: smallest power-of-two scale with amax / scale <= 448, RNE to OCP e4m3fn."""
@@ -497,7 +551,7 @@ def test_conv_fp8_weights():
     check(out, ref, dt)
 
 
-@pytest.mark.parametrize("M", [128, 300, 4096])
+@pytest.mark.parametrize("M", [128, 300, 4096, 65536])          # 65536 = the benchmark's launch (512 blocks: two rounds of 256 CUs)
 def test_ffn_geglu_fused(M):
     """rf_ffn_geglu (C = 320): GEGLU projection + ff.net.2 + residual in one kernel, against an fp32 reference on the bf16-rounded operands
     (with the hidden activations rounded to bf16, as both the fused and the unfused path store / feed them) and against the two unfused
@@ -524,6 +578,41 @@ def test_ffn_geglu_fused(M):
     ref = F.linear(hid_ref, w2.to(dt).float(), b2) + rr
     check(out, ref, dt)
     assert (out.float() - out_u.float()).abs().max().item() <= 2.0 ** -6 * max(1.0, ref.abs().max().item())       # <= 2 bf16 ulps apart
+
+
+@pytest.mark.parametrize("M", [300, 4096])
+def test_ffn_geglu_fused_with_layernorm(M):
+    """rf_ffn_geglu with ln_eps > 0: `norm3` (attention.py:231-233, 243) runs inside the kernel -- two-pass fp32 statistics of the token's row in
+    registers, the normalised values rounded to bf16, gamma / beta folded into W1 / b1 by ops.fold_layernorm_geglu.  Against an fp32
+    reference with the same roundings, and against the unfused chain rf_layernorm -> rf_ffn_geglu (a few bf16 ulps: the affine is
+    applied before resp. after the rounding of the normalised value)."""
+    dt, Cc = torch.bfloat16, 320
+    x, xr = q(rnd((M, Cc), 180) * 1.7 + 0.4, dt)                     # rows with a mean: the statistics matter
+    gamma, beta = rnd((Cc,), 181) * 0.3 + 1.0, rnd((Cc,), 182) * 0.2
+    w1 = rnd((8 * Cc, Cc), 81) / math.sqrt(Cc)
+    b1 = rnd((8 * Cc,), 82) * 0.5
+    w2 = rnd((Cc, 4 * Cc), 83) / math.sqrt(4 * Cc)
+    b2 = rnd((Cc,), 84)
+    w1f, b1f = ops.fold_layernorm_geglu(w1, b1, gamma, beta)
+    w1p, b1p = ops.pack_geglu(w1f, b1f, dt)
+    out = torch.empty((M, Cc), dtype=dt, device=DEV)
+    ops.ffn_geglu(x, w1p.to(DEV), b1p.to(DEV), ops.pack_ffn_w2(w2.to(DEV), dt), b2.to(DEV), out, residual=x, ln_eps=1e-5)()
+    # unfused chain: the LayerNorm pass (affine applied, bf16 output), then the fused feed-forward on it
+    ln = torch.empty((M, Cc), dtype=dt, device=DEV)
+    ops.layernorm(x, gamma.to(DEV), beta.to(DEV), ln)()
+    w1u, b1u = ops.pack_geglu(w1, b1, dt)
+    out_u = torch.empty_like(out)
+    ops.ffn_geglu(ln, w1u.to(DEV), b1u.to(DEV), ops.pack_ffn_w2(w2.to(DEV), dt), b2.to(DEV), out_u, residual=x)()
+    torch.cuda.synchronize()
+    xhat = F.layer_norm(xr, (Cc,), None, None, 1e-5).to(dt).float()
+    hsum = F.linear(xhat, w1f.to(dt).float(), b1f)
+    a, g = hsum.chunk(2, -1)
+    hid = (a * F.gelu(g, approximate="tanh")).to(dt).float()
+    ref = F.linear(hid, w2.to(dt).float(), b2) + xr
+    check(out, ref, dt)
+    d = (out.float() - out_u.float()).abs().max().item()
+    print(f"ffn + in-kernel LayerNorm vs LayerNorm pass + ffn (M = {M}): max |d| = {d:.3e} at |out| max {ref.abs().max().item():.2f}")
+    assert d <= 2.0 ** -5 * max(1.0, ref.abs().max().item())
 
 
 # ------------------------------------------------------------------------------------------------ split-bf16 (RF_BF16X3) operands

@@ -285,3 +285,21 @@ def test_output_tree_vs_reference_golden(golden_dir):
     for k in range(4):
         pad[2:2 + H, 2 + k * (H + 2):2 + k * (H + 2) + H] = False
     assert (g["grid"][pad] == 0).all() and np.array_equal(o["grid"][pad], g["grid"][pad])
+
+
+@pytest.mark.slow
+def test_oracle_full_width_decode_vs_reference_ddim50_golden(golden_dir):
+    """The full-S full-width fixture (tests/golden/ddim_full_S50_B2.npz: the REFERENCE's UNet + DDIMSampler + AutoencoderKL.decode, 50 CFG steps,
+    B = 2) holds every 8th pixel of the reference's decoded images: the oracle's full-width 512x512 decode of the stored latents must
+    reproduce them -- the GPU gate test compares the HIP path's image with this oracle decode."""
+    import numpy as np
+    from oracle import vae as ovae
+    from reface_amd import params as P
+    g = np.load(os.path.join(golden_dir, "ddim_full_S50_B2.npz"))
+    cfg = P.VAEConfig()
+    vsd = P.seeded_state_dict(P.vae_param_specs(cfg), int(g["seed_vae"]))
+    with torch.no_grad():
+        img = ovae.decode_first_stage(vsd, cfg, torch.from_numpy(g["samples"][:1]))
+    e = (img[:, :, ::8, ::8] - torch.from_numpy(g["image_stride8"][:1])).abs().max().item()
+    assert e < 1e-4, e
+    assert abs(float(g["image_absmax"])) < 50 and np.isfinite(g["samples"]).all() and np.isfinite(g["pred_x0_last"]).all()

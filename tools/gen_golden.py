@@ -29,7 +29,7 @@ from reface_amd import params as P  # noqa: E402
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
 torch.set_grad_enabled(False)
-torch.set_num_threads(8)
+torch.set_num_threads(int(os.environ.get("GEN_THREADS", "8")))
 
 
 rnd = P.seeded_randn     # inputs are regenerated from (shape, seed) by the tests; only outputs are stored
@@ -192,6 +192,34 @@ def gen_ddim():
     torch.manual_seed(99)
     noises = torch.stack([torch.randn((B, 4, h, h)) for _ in range(5)])
     save("ddim_small_S5_eta5", samples=samples, noises=noises, seed=7, scale=3.5)
+
+
+def gen_ddim_full():
+    """SURVEY 8d gate at FULL S and FULL width: the reference's own UNet (859.5 M parameters, seeded weights 1234) under the reference's
+    DDIMSampler (ddim.py:96-251, 323-375), S = 50, B = 2 at 64x64 latents, CFG scale 3.5, eta 0, inpainting kwargs -- then the reference's
+    full-width AutoencoderKL.decode (seeded weights 55) of the samples / 0.18215 (ddpm.py:1102-1113).  ~20 minutes on 8 CPU threads.
+    Stored: the latents after 50 steps, the last pred_x0 and every 8th pixel of the decoded images (the full images would be 6 MB:
+    the test decodes the stored latents with the oracle and checks that decode against these pixels)."""
+    from ldm.models.diffusion.ddim import DDIMSampler
+    DDIMSampler.register_buffer = lambda self, n, a: setattr(self, n, a)
+    m, _ = _ref_unet(P.UNetConfig(), 1234)
+    sampler = DDIMSampler(_StubLDM(m))
+    B, h, S = 2, 64, 50
+    x_T = rnd((B, 4, h, h), 480)
+    mask = (rnd((B, 1, h, h), 482) > 0).float()
+    z_inp = rnd((B, 4, h, h), 481) * mask
+    c = rnd((B, 1, 768), 483)
+    uc = rnd((1, 1, 768), 484).repeat(B, 1, 1)
+    t0 = time.time()
+    samples, inter = sampler.sample(S=S, conditioning=c, batch_size=B, shape=[4, h, h], verbose=False, unconditional_guidance_scale=3.5,
+                                    unconditional_conditioning=uc, eta=0.0, x_T=x_T, log_every_t=100,
+                                    test_model_kwargs={"inpaint_image": z_inp, "inpaint_mask": mask})
+    print(f"  reference DDIM S={S} B={B} full width: {time.time() - t0:.0f}s")
+    del m, sampler
+    vae, _ = _ref_vae(P.VAEConfig(), 55)
+    img = vae.decode(samples / 0.18215)
+    save("ddim_full_S50_B2", samples=samples, pred_x0_last=inter["pred_x0"][-1], image_stride8=img[:, :, ::8, ::8].contiguous(),
+         image_absmax=img.abs().max(), seed_unet=1234, seed_vae=55, scale=3.5, S=S)
 
 
 def gen_plms():
@@ -458,11 +486,11 @@ def gen_e2e():
     save("e2e_png", grid=g0, mask=written["a_mask.png"])
 
 
-GROUPS = dict(plms=gen_plms, schedule=gen_schedule, unet_ops=gen_unet_ops, unet_small=gen_unet_small, unet_full=gen_unet_full,
+GROUPS = dict(ddim_full=gen_ddim_full, plms=gen_plms, schedule=gen_schedule, unet_ops=gen_unet_ops, unet_small=gen_unet_small, unet_full=gen_unet_full,
               ddim=gen_ddim, vae=gen_vae, arcface=gen_arcface, clip=gen_clip, e2e=gen_e2e)
 
 if __name__ == "__main__":
-    sel = sys.argv[1:] or list(GROUPS)
+    sel = sys.argv[1:] or [g for g in GROUPS if g != "ddim_full"]          # (ddim_full: 20 minutes; ask for it by name)
     for g in sel:
         print(f"[{g}]")
         t0 = time.time()
