@@ -251,6 +251,17 @@ int rf_mul_mask(const float* x, const float* mask, int B, int C, int HW, float* 
  * (half-pixel centres, two taps per axis, 11-bit weights, NO antialiasing; exact 2:1 -> the fast-area average); cv2 itself is a
  * third-party dependency absent from /root/reference and from this image: see reface_amd/data.py::resize_u8_linear for the restatement.
  */
+/*
+ * rf_compose_outputs_u8 : the CLI's output files as uint8 HWC arrays, one packed record per image:
+ *     [result | mask (grey replicated) | GT | inpaint | ref]  5 x [H][W][3],  then (with_grid) the 4-panel make_grid image
+ *     [H + 4][4 W + 10][3] of (GT, inpaint, ref, result) with 2-pixel padding (pad bytes untouched: zero them once).
+ * Every conversion is the reference's (255. * x).astype(np.uint8) of fp32 values (scripts/inference_test_bench.py:500-552:
+ * un_norm, un_norm_clip, make_grid, rearrange + astype): truncation toward zero, low byte.  Inputs NCHW fp32 on the device:
+ * result01 = clamp((x + 1) / 2, 0, 1), target / inpaint in [-1, 1], mask [B, 1, H, W] in {0, 1}, ref = the CLIP-normalised source
+ * already resized to H x W.  Replaces the per-image host float passes; the host then only PNG-encodes slices of one D2H copy.
+ */
+int rf_compose_outputs_u8(const float* result01, const float* target, const float* inpaint, const float* mask, const float* ref, int B, int H, int W,
+                          int with_grid, void* out_u8, int64_t record_bytes, void* stream);
 int rf_resize_u8_linear(const void* x_u8, int B, int H, int W, int C, int64_t image_stride, int Ho, int Wo, void* out_u8, void* stream);
 /* elementwise y = silu(x) on fp32 (emb path, openaimodel.py:219) */
 int rf_silu_f32(const float* x, float* y, int64_t n, void* stream);

@@ -208,6 +208,54 @@ __global__ void resize_u8_linear_kernel(const uint8_t* __restrict__ x, int B, in
     }
 }
 
+// The output files of the test-bench CLI as uint8 HWC panels, composed on the device (scripts/inference_test_bench.py:500-553 does it per
+// image on the host with torch-CPU / numpy float ops): per image ONE packed record
+//   [result | mask | GT | inpaint | ref]  5 x [H][W][3]      then      grid [H + 4][4 W + 10][3]  (make_grid: 4 panels, padding 2, pad value 0)
+// with every float -> uint8 conversion the reference's `(255. * x).astype(np.uint8)`: fp32 product, truncation toward zero, low byte
+// (out-of-range values of the un-clamped reference panel wrap modulo 256 exactly as numpy's cast does on x86-64).  Panels:
+//   result  255 * r                                  (r = clamp((x + 1) / 2, 0, 1) already, rf_to_image)
+//   GT / inpaint / mask   255 * ((v + 1) / 2)        (mask: the one channel replicated, cv2.COLOR_GRAY2RGB)
+//   ref     255 * (v * clip_std[c] + clip_mean[c])   (the CLIP-normalised reference resized to H x W beforehand)
+// The grid's pad bytes are never written (the buffer is zero-initialised once by the host).  One thread per pixel.
+__device__ __forceinline__ uint8_t u8_trunc(float v) { return (uint8_t)((int)v & 0xff); }
+__global__ void compose_outputs_u8_kernel(const float* __restrict__ res, const float* __restrict__ tgt, const float* __restrict__ inp,
+                                          const float* __restrict__ msk, const float* __restrict__ ref, int B, int H, int W, int with_grid,
+                                          uint8_t* __restrict__ out, long long rec_bytes) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long HW = (long long)H * W;
+    if (i >= B * HW) return;
+    const int b = (int)(i / HW);
+    const long long p = i - b * HW;
+    const int y = (int)(p / W), x = (int)(p - (long long)y * W);
+    const float stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f}, mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
+    uint8_t* rec = out + b * rec_bytes;
+    const long long panel = HW * 3;
+    const int GW = 4 * W + 10;
+    uint8_t* grid = rec + 5 * panel;
+    const float m = (msk[b * HW + p] + 1.0f) / 2.0f;
+    const uint8_t mu8 = u8_trunc(255.0f * m);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const long long src = ((long long)b * 3 + c) * HW + p;
+        const float r = res[src], g = (tgt[src] + 1.0f) / 2.0f, n = (inp[src] + 1.0f) / 2.0f;
+        const float rf = ref[src] * stdv[c] + mean[c];
+        const uint8_t r8 = u8_trunc(255.0f * r), g8 = u8_trunc(255.0f * g), n8 = u8_trunc(255.0f * n), f8 = u8_trunc(255.0f * rf);
+        const long long o = p * 3 + c;
+        rec[o] = r8;
+        rec[panel + o] = mu8;
+        rec[2 * panel + o] = g8;
+        rec[3 * panel + o] = n8;
+        rec[4 * panel + o] = f8;
+        if (with_grid) {          // make_grid([GT, inpaint, ref, result]): panel k at columns 2 + k (W + 2), rows 2 ..
+            uint8_t* gp = grid + ((long long)(y + 2) * GW + (x + 2)) * 3 + c;
+            gp[0] = g8;
+            gp[(long long)(W + 2) * 3] = n8;
+            gp[(long long)(W + 2) * 6] = f8;
+            gp[(long long)(W + 2) * 9] = r8;
+        }
+    }
+}
+
 }  // namespace rf
 
 using namespace rf;
@@ -336,5 +384,18 @@ extern "C" int rf_resize_u8_linear(const void* x, int B, int H, int W, int C, in
     hipLaunchKernelGGL(resize_u8_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)x, B, H, W, C,
                        (long long)image_stride, Ho, Wo, (uint8_t*)out);
     RF_LAUNCH_CHECK("rf_resize_u8_linear");
+    return 0;
+}
+
+extern "C" int rf_compose_outputs_u8(const float* result01, const float* target, const float* inpaint, const float* mask, const float* ref,
+                                     int B, int H, int W, int with_grid, void* out_u8, int64_t record_bytes, void* stream) {
+    using namespace rf;
+    const long long need = 5LL * H * W * 3 + (with_grid ? (long long)(H + 4) * (4 * W + 10) * 3 : 0);
+    RF_CHECK(result01 && target && inpaint && mask && ref && out_u8 && B > 0 && H > 0 && W > 0 && record_bytes >= need,
+             "rf_compose_outputs_u8: bad arguments (B=%d H=%d W=%d record %lld < %lld)", B, H, W, (long long)record_bytes, need);
+    const long long n = (long long)B * H * W;
+    hipLaunchKernelGGL(compose_outputs_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, result01, target, inpaint, mask, ref,
+                       B, H, W, with_grid, (uint8_t*)out_u8, (long long)record_bytes);
+    RF_LAUNCH_CHECK("rf_compose_outputs_u8");
     return 0;
 }

@@ -630,6 +630,18 @@ def u8_to_norm(x_u8, mean, std, out, name="u8_to_norm"):
     return Launch(lib.rf_u8_to_norm, (_p(x_u8), B, H * W_, _p(mean), _p(std), _p(out)), (x_u8, mean, std, out), name)
 
 
+def compose_outputs_u8(result01, target, inpaint, mask, ref, out_u8, *, with_grid=True, name="compose_outputs_u8"):
+    """The CLI's output panels (+ grid) of a batch as packed uint8 records out_u8 [B, record_bytes] (reface_amd/output.record_layout)."""
+    lib = _lib.load()
+    _require_gpu(result01, target, inpaint, mask, ref, out_u8)
+    B, _, H, W_ = result01.shape
+    for t in (result01, target, inpaint, mask, ref):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape[0] == B and tuple(t.shape[2:]) == (H, W_), tuple(t.shape)
+    assert out_u8.dtype == torch.uint8 and out_u8.is_contiguous() and out_u8.shape[0] == B
+    return Launch(lib.rf_compose_outputs_u8, (_p(result01), _p(target), _p(inpaint), _p(mask), _p(ref), B, H, W_, int(bool(with_grid)), _p(out_u8),
+                                              out_u8.stride(0)), (result01, target, inpaint, mask, ref, out_u8), name)
+
+
 def resize_u8_linear(x_u8, out, name="resize_u8_linear"):
     """x_u8 [B, H, W, C] uint8 (HWC, contiguous images) -> out [B, Ho, Wo, C] uint8: cv2.resize(..., INTER_LINEAR) bit for bit."""
     lib = _lib.load()

@@ -76,6 +76,31 @@ def compose(result01, target, inpaint_image, inpaint_mask, ref512, skip_grid=Fal
     return out
 
 
+PANELS = ("result", "mask", "GT", "inpaint", "ref")          # order of the 5 [H][W][3] panels in a packed record (rf_compose_outputs_u8)
+
+
+def record_layout(H, W, with_grid=True):
+    """(record bytes, {name: (offset, shape)}) of one image's packed uint8 record as rf_compose_outputs_u8 writes it."""
+    panel = H * W * 3
+    lay = {n: (k * panel, (H, W, 3)) for k, n in enumerate(PANELS)}
+    nbytes = 5 * panel
+    if with_grid:
+        lay["grid"] = (nbytes, (H + 4, 4 * W + 10, 3))
+        nbytes += (H + 4) * (4 * W + 10) * 3
+    return nbytes, lay
+
+
+def default_writer_threads(world=1):
+    """PNG-encode workers per process: the encodes of one batch must finish inside a batch time, but N processes x 8 workers x 4 loader
+    processes on one node is what the 8-process probe measured as contention (tools/host_scaling_probe.py) -- bound the workers by the
+    process's share of the host: cpus / (world * 6), between 2 and 8."""
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 8
+    return max(2, min(8, cpus // (max(1, world) * 6)))
+
+
 def paths(outdir, sid):
     s, r, g = (os.path.join(outdir, d) for d in ("samples", "results", "grid"))
     return {"result": os.path.join(r, sid + ".png"), "grid": os.path.join(g, "grid-" + sid + ".png"),
@@ -86,11 +111,14 @@ def paths(outdir, sid):
 class OutputWriter:
     """PNG encoding off the launch thread: ``submit`` takes host arrays of one batch and returns at once; ``close`` drains."""
 
-    def __init__(self, outdir, skip_grid=False, depth=4, threads=8):
+    def __init__(self, outdir, skip_grid=False, depth=4, threads=8, compress_level=None):
         # One job per IMAGE, `threads` workers: the six PNG encodes of an image are ~0.3 s of zlib on incompressible content (zlib runs
         # outside the GIL), so a single worker caps the CLI at ~3 images/s -- below one MI355X (tools/host_scaling_probe.py: 2.86 s per
         # batch of 8 with one worker against 0.9 s of device time)
         self.outdir, self.skip_grid = outdir, skip_grid
+        # zlib level of the PNG files: None = PIL's default (6), what the reference's Image.save writes; a lower level gives the same
+        # pixels in larger files for a third of the CPU time (RF_PNG_LEVEL / --png_level)
+        self.save_kw = {} if compress_level is None else {"compress_level": int(compress_level)}
         self.q = queue.Queue(maxsize=depth * 8)
         self.err = None
         self.n = 0
@@ -106,11 +134,15 @@ class OutputWriter:
             if job is None:
                 return
             try:
-                sid, res, tgt, inp, msk, ref = job
-                arrs = compose(res, tgt, inp, msk, ref, skip_grid=self.skip_grid)
+                if len(job) == 3:          # a packed uint8 record composed on the device: only slicing and PNG encoding are left
+                    sid, rec, lay = job
+                    arrs = {k: rec[o:o + int(np.prod(shp))].reshape(shp) for k, (o, shp) in lay.items()}
+                else:
+                    sid, res, tgt, inp, msk, ref = job
+                    arrs = compose(res, tgt, inp, msk, ref, skip_grid=self.skip_grid)
                 p = paths(self.outdir, sid)
                 for k, a in arrs.items():
-                    Image.fromarray(a).save(p[k])
+                    Image.fromarray(a).save(p[k], **self.save_kw)
                 with self.lock:
                     self.n += 1
             except Exception as e:          # surfaced on the next submit / close
@@ -121,6 +153,15 @@ class OutputWriter:
             raise self.err
         for i, sid in enumerate(ids):
             self.q.put((sid, result01[i], target[i], inpaint_image[i], inpaint_mask[i], ref512[i]))
+
+    def submit_u8(self, ids, records, H, W):
+        """records: uint8 [B, record_bytes] host array (one D2H copy of what rf_compose_outputs_u8 wrote); the rows are copied out of the
+        staging buffer here, so the caller may reuse it at once."""
+        if self.err is not None:
+            raise self.err
+        _, lay = record_layout(H, W, with_grid=not self.skip_grid)
+        for i, sid in enumerate(ids):
+            self.q.put((sid, np.array(records[i], copy=True), lay))
 
     def close(self):
         for _ in self.ts:

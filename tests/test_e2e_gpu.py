@@ -335,6 +335,30 @@ def test_device_prep_matches_host(tmp_path):
             assert (out["ref_imgs"][i].cpu() - hk["ref_imgs"]).abs().max().item() < 2e-6
 
 
+def test_compose_outputs_u8_matches_host_composition():
+    """rf_compose_outputs_u8 (the CLI's output panels + 4-panel grid as packed uint8 records, composed on the device) is bit-identical to
+    reface_amd/output.compose -- the host restatement of the reference's save block (inference_test_bench.py:500-552), itself pinned to the
+    reference's own output for the e2e fixture -- including the un-clamped reference panel, whose out-of-range values wrap in the cast."""
+    from reface_amd import ops
+    from reface_amd import output as O
+    rng = np.random.default_rng(5)
+    for (B, H, W, grid) in ((2, 64, 64, True), (3, 40, 56, True), (1, 512, 512, True), (2, 64, 64, False)):
+        res = rng.random((B, 3, H, W), dtype=np.float32)
+        tgt = np.tanh(rng.standard_normal((B, 3, H, W))).astype(np.float32)
+        msk = (rng.random((B, 1, H, W)) > 0.5).astype(np.float32)
+        ref = (rng.standard_normal((B, 3, H, W)) * 2.5).astype(np.float32)
+        nbytes, lay = O.record_layout(H, W, with_grid=grid)
+        rec = torch.zeros((B, nbytes), dtype=torch.uint8, device="cuda")
+        f = lambda a: torch.from_numpy(a).cuda()
+        ops.compose_outputs_u8(f(res), f(tgt), f(tgt * msk), f(msk), f(ref), rec, with_grid=grid)()
+        torch.cuda.synchronize()
+        got = rec.cpu().numpy()
+        for i in range(B):
+            o = O.compose(res[i], tgt[i], tgt[i] * msk[i], msk[i], ref[i], skip_grid=not grid)
+            for k, (off, shp) in lay.items():
+                assert np.array_equal(got[i, off:off + int(np.prod(shp))].reshape(shp), o[k]), (B, H, W, k)
+
+
 def test_resize_u8_linear_kernel_matches_host():
     """rf_resize_u8_linear (cv2 INTER_LINEAR arithmetic on the GPU, --gpu_prep) is bit-identical to the host restatement
     `reface_amd.data.resize_u8_linear` -- down- and upscales, non-square, the exact 2:1 fast-area case, a strided batch -- and the

@@ -274,6 +274,45 @@ def test_output_tree_composition():
     assert np.array_equal(o["GT"], (255.0 * ((tgt + 1.0) / 2.0).transpose(1, 2, 0)).astype(np.uint8))
 
 
+def test_output_writer_packed_records(tmp_path):
+    """The packed uint8 record of rf_compose_outputs_u8 (reface_amd/output.record_layout: 5 panels + grid) through OutputWriter.submit_u8 gives
+    the same PNG files as the host composition path (submit): same file set, identical decoded pixels; the writer's worker count is
+    bounded by the process's share of the host."""
+    from PIL import Image
+    from reface_amd import output as O
+    rng = np.random.default_rng(1)
+    H, B = 16, 3
+    res = rng.random((B, 3, H, H), dtype=np.float32)
+    tgt = np.tanh(rng.standard_normal((B, 3, H, H))).astype(np.float32)
+    msk = (rng.random((B, 1, H, H)) > 0.5).astype(np.float32)
+    ref = rng.standard_normal((B, 3, H, H)).astype(np.float32) * 2          # out of [0, 1] after un-normalisation: the uint8 cast wraps
+    nbytes, lay = O.record_layout(H, H)
+    assert nbytes == 5 * H * H * 3 + (H + 4) * (4 * H + 10) * 3 and lay["grid"][1] == (H + 4, 4 * H + 10, 3)
+    recs = np.zeros((B, nbytes), dtype=np.uint8)
+    for i in range(B):
+        o = O.compose(res[i], tgt[i], tgt[i] * msk[i], msk[i], ref[i])
+        for k, (off, shp) in lay.items():
+            recs[i, off:off + int(np.prod(shp))] = o[k].reshape(-1)
+    ids = [f"{i:012d}" for i in range(B)]
+    outs = []
+    for tag in ("a", "b"):
+        d = tmp_path / tag
+        for sub in ("samples", "results", "grid"):
+            (d / sub).mkdir(parents=True)
+        w = O.OutputWriter(str(d), threads=O.default_writer_threads(8), compress_level=1 if tag == "b" else None)
+        if tag == "a":
+            w.submit(ids, res, tgt, tgt * msk, msk, ref)
+        else:
+            w.submit_u8(ids, recs, H, H)
+        assert w.close() == B
+        outs.append(d)
+    files = sorted(str(p.relative_to(outs[0])) for p in outs[0].rglob("*.png"))
+    assert len(files) == 6 * B and files == sorted(str(p.relative_to(outs[1])) for p in outs[1].rglob("*.png"))
+    for f in files:
+        assert np.array_equal(np.asarray(Image.open(outs[0] / f)), np.asarray(Image.open(outs[1] / f))), f
+    assert 2 <= O.default_writer_threads(8) <= 8 and 2 <= O.default_writer_threads(1) <= 8
+
+
 def test_checkpoint_missing_engine_tensor_is_an_error():
     """A pruned checkpoint must not leave engine tensors at their zero initialisation: strict=False loading
     reports it through LatentDiffusion.check_engine_weights; keys the inference path never reads may be absent."""

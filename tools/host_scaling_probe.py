@@ -32,7 +32,7 @@ def make_tree(root, n):
         Image.fromarray(rng.integers(0, 19, (512, 512), dtype=np.uint8)).save(os.path.join(root, "CelebA-HQ-mask", "Overall_mask", f"{i}.png"))
 
 
-def worker(tree, outdir, batches, device_ms, B=8):
+def worker(tree, outdir, batches, device_ms, B=8, legacy=False, world=1, png_level=None):
     import numpy as np
     import torch
     from reface_amd import output as O
@@ -40,17 +40,25 @@ def worker(tree, outdir, batches, device_ms, B=8):
     torch.set_num_threads(1)
     ds = CelebAdataset(dataset_dir=tree, n_targets=batches * B)
     loader = torch.utils.data.DataLoader(ds, batch_size=B, num_workers=4, shuffle=False)
-    O.make_dirs(outdir) if hasattr(O, "make_dirs") else [os.makedirs(os.path.join(outdir, d), exist_ok=True) for d in ("results", "grid", "samples")]
-    writer = O.OutputWriter(outdir)
+    [os.makedirs(os.path.join(outdir, d), exist_ok=True) for d in ("results", "grid", "samples")]
+    # round 4: the panels / grid are composed on the GPU and arrive as ONE packed uint8 record per image; the writer's worker count is the
+    # process's share of the host.  --legacy: the round-3 host half (fp32 panels composed on the host, 8 workers per process)
+    writer = O.OutputWriter(outdir) if legacy else O.OutputWriter(outdir, threads=O.default_writer_threads(world), compress_level=png_level)
+    nbytes, _ = O.record_layout(512, 512)
+    rng = np.random.default_rng(0)
+    pool_u8 = rng.integers(0, 256, (B, nbytes), dtype=np.uint8)              # stand-in for the D2H'd records (noise: zlib's worst case)
+    pool_f = rng.random((2, B, 3, 512, 512), dtype=np.float32)
     t0 = time.perf_counter()
     host_ms = []
     n = 0
     for target, prior, kw, ids in loader:
         t_host = time.perf_counter()
         time.sleep(device_ms / 1e3)                      # the device's share of the batch (sampling + decode are queued, the host is free)
-        res = np.random.rand(target.shape[0], 3, 512, 512).astype(np.float32)
-        ref = np.random.rand(target.shape[0], 3, 512, 512).astype(np.float32)
-        writer.submit(list(ids), res, target.float().numpy(), kw["inpaint_image"].float().numpy(), kw["inpaint_mask"].float().numpy(), ref)
+        if legacy:
+            writer.submit(list(ids), pool_f[0][:target.shape[0]], target.float().numpy(), kw["inpaint_image"].float().numpy(),
+                          kw["inpaint_mask"].float().numpy(), pool_f[1][:target.shape[0]])
+        else:
+            writer.submit_u8(list(ids), pool_u8[:target.shape[0]], 512, 512)
         host_ms.append(1e3 * (time.perf_counter() - t_host) - device_ms)
         n += 1
         if n == 1:
@@ -68,21 +76,27 @@ def main():
     ap.add_argument("--batches", type=int, default=6)
     ap.add_argument("--device-ms", type=float, default=900.0)
     ap.add_argument("--worker", nargs=2, default=None)
+    ap.add_argument("--legacy", action="store_true", help="the round-3 host half: fp32 panels composed on the host, 8 PNG workers per process")
+    ap.add_argument("--world", type=int, default=1, help="(worker) processes sharing the host")
+    ap.add_argument("--png-level", type=int, default=None, help="zlib level of the PNG files (default: PIL's 6, the reference's files)")
     a = ap.parse_args()
     if a.worker:
-        worker(a.worker[0], a.worker[1], a.batches, a.device_ms)
+        worker(a.worker[0], a.worker[1], a.batches, a.device_ms, legacy=a.legacy, world=a.world, png_level=a.png_level)
         return
     with tempfile.TemporaryDirectory() as tmp:
         tree = os.path.join(tmp, "CelebAMask-HQ")
         make_tree(tree, a.batches * 8)
         out = {}
         for n in (1, a.procs):
+            extra = (["--legacy"] if a.legacy else []) + (["--png-level", str(a.png_level)] if a.png_level is not None else [])
             ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", tree, os.path.join(tmp, f"out_{n}_{r}"), "--batches", str(a.batches),
-                                    "--device-ms", str(a.device_ms)], stdout=subprocess.PIPE, text=True) for r in range(n)]
+                                    "--device-ms", str(a.device_ms), "--world", str(n)] + extra, stdout=subprocess.PIPE, text=True) for r in range(n)]
             rs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in ps]
             out[n] = {"ms_per_batch_max": max(r["ms_per_batch"] for r in rs), "ms_per_batch_mean": sum(r["ms_per_batch"] for r in rs) / n,
                       "host_ms_on_launch_thread_max": max(r["host_ms_on_launch_thread"] for r in rs)}
         out["cpus"] = len(os.sched_getaffinity(0))
+        out["host_half"] = "round 3 (fp32 panels composed on the host, 8 PNG workers)" if a.legacy else \
+            f"round 4 (packed uint8 records from the device, PNG workers = share of the host, zlib level {a.png_level if a.png_level is not None else 6})"
         out["device_ms_assumed"] = a.device_ms
         out["verdict"] = ("host half hides under the device time in all %d processes" % a.procs
                           if out[a.procs]["ms_per_batch_max"] < 1.05 * max(a.device_ms, out[1]["ms_per_batch_max"]) else
