@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 F_UNET = {64: 796.94e9, 96: 2137.52e9}   # algorithmic FLOP per sample per UNet evaluation by latent side (SURVEY.md 8d / BASELINE.md 2)
 F_VAE_DEC_512 = 2514.5e9      # fp32 VAE decode per 512x512 image
-PEAK = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0, "fp8w": 2500.0}     # dense MFMA TFLOP/s of the instruction the dominant family issues
+PEAK = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0, "fp8w": 2500.0, "fp8c": 5000.0}     # dense MFMA TFLOP/s of the instruction the dominant family issues
                                                          # (MI355X_MICROARCH.md): "fp8" = fp8 x fp8 on the MX-scaled fp8 MFMA (5 PF dense);
                                                          # "fp8w" dequantises fp8 weights to bf16 in the LDS read path -> bf16 MFMA rate
 # BASELINE.json configs[i] -> per-GPU workload (configs[2] = configs[1] on every one of the N GPUs)
@@ -279,7 +279,7 @@ def family_key(fam, dname):
     """The dominant GEMM family of a mode and the MFMA peak of the instruction THAT family issues (a run whose own family is absent
     falls back to the bf16 family and is then priced against the bf16 peak)."""
     key = {"bf16": "rf_conv_gemm[bf16]", "f32": "rf_conv_gemm[f32]", "fp8": "rf_conv_gemm[fp8]", "fp8w": "rf_conv_gemm[fp8w]",
-           "f32x3": "rf_conv_gemm[bf16x3]"}[dname]
+           "fp8c": "rf_conv_gemm[fp8]", "f32x3": "rf_conv_gemm[bf16x3]"}[dname]
     peak_of = {"rf_conv_gemm[bf16]": PEAK["bf16"], "rf_conv_gemm[f32]": PEAK["f32"], "rf_conv_gemm[fp8]": PEAK["fp8"],
                "rf_conv_gemm[fp8w]": PEAK["fp8w"], "rf_conv_gemm[bf16x3]": PEAK["bf16"] / 3.0}
     if key not in fam:
@@ -311,7 +311,7 @@ def other_config_line(oc, unet, vae, ldm, args, device, timed, steps=3, warmup=1
     from reface_amd.ddim import DDIMSampler
     conf = CONFIGS[oc]
     B, h, dname, S = conf["batch"], conf["latent"], conf["dtype"], args.ddim_steps
-    unet.set_compute_dtype({"bf16": torch.bfloat16, "f32": torch.float32, "fp8": "fp8", "fp8w": "fp8w"}[dname])
+    unet.set_compute_dtype({"bf16": torch.bfloat16, "f32": torch.float32, "fp8": "fp8", "fp8w": "fp8w", "fp8c": "fp8c"}[dname])
     torch.cuda.empty_cache()
     sampler = DDIMSampler(ldm)
     x_T, z_inp, mask, c, uc = synthetic_inputs(B, h, 42, device)
@@ -352,7 +352,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="image pairs per GPU per step (overrides the config)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--latent", type=int, default=None, help="latent side (64 = 512x512 images; overrides the config)")
-    ap.add_argument("--dtype", default=None, choices=["bf16", "f32", "fp8", "fp8w"], help="UNet compute mode (overrides the config)")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f32", "fp8", "fp8w", "fp8c"], help="UNet compute mode (overrides the config)")
     ap.add_argument("--scale", type=float, default=3.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -389,7 +389,7 @@ def main():
 
     from reface_amd import ops
     from reface_amd.ddim import DDIMSampler
-    dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "fp8": "fp8", "fp8w": "fp8w"}[dname]
+    dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "fp8": "fp8", "fp8w": "fp8w", "fp8c": "fp8c"}[dname]
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     unet, vae, ldm, cpu_sd = build_models(dtype, device, rank, world, want_cpu)
     sampler = DDIMSampler(ldm)
@@ -440,7 +440,9 @@ def main():
     wdesc = {"bf16": "bf16 UNet", "f32": "exact-fp32 UNet",
              "fp8": "fp8 (e4m3fn) UNet weights + fp8 activations (E8M0 block scales) into the ResBlock convs / proj_in / qkv / GEGLU on the fp8 MFMA, "
                     "bf16 residual stream, fp32 accumulate",
-             "fp8w": "fp8 (e4m3fn) UNet weights, bf16 activations, fp32 accumulate"}[dname]
+             "fp8w": "fp8 (e4m3fn) UNet weights, bf16 activations, fp32 accumulate",
+             "fp8c": "fp8 (e4m3fn) weights + fp8 activations (E8M0 block scales) on the fp8 MFMA for the 3x3 convolutions (85 % of the FLOPs), bf16 projections, "
+                     "fp32 accumulate"}[dname]
     workload = f"{cname}:{px}x{px}:S{S}:B{B}:{dname}"
     result = {
         "metric": f"{px}x{px} {S}-step DDIM images/sec", "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,

@@ -27,7 +27,22 @@
 #define RF_SPREAD_DMA 1
 #endif
 
+// Experiment (RF_STORE_SC1 = 1): the direct epilogue's output stores as write-through `sc1` stores -- the bytes leave the XCD's L2 while the
+// kernel runs instead of in the write-back burst at the kernel boundary (every dirty line must reach the memory side before the next kernel
+// starts: the 8 L2s are not coherent), at the price of dropping the line from this XCD's L2.
+#ifndef RF_STORE_SC1
+#define RF_STORE_SC1 0
+#endif
+
 namespace rf {
+
+__device__ __forceinline__ void st16_out(void* ptr, const u32x4_t& w) {
+#if RF_STORE_SC1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(w) : "memory");
+#else
+    *(u32x4_t*)ptr = w;
+#endif
+}
 
 struct GemmParams {
     int M, N, K;
@@ -1065,11 +1080,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                     u32x4_t w;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) w[e] = pack_bf2(v[8 * h + 2 * e], v[8 * h + 2 * e + 1]);
-                    ((u32x4_t*)dst)[h] = w;
+                    st16_out((u32x4_t*)dst + h, w);
                 }
             } else {
 #pragma unroll
-                for (int h = 0; h < 4; ++h) ((f32x4_t*)dst)[h] = f32x4_t{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+                for (int h = 0; h < 4; ++h) st16_out((u32x4_t*)dst + h, u32x4_t{as_u32(v[4 * h]), as_u32(v[4 * h + 1]), as_u32(v[4 * h + 2]), as_u32(v[4 * h + 3])});
             }
         };
         // column constants -> LDS (the main loop ended on a barrier: the operand stages are dead)
@@ -1185,7 +1200,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
                             for (int e = 0; e < E; ++e) v[e] = acc[i][j][h * E + e] * p.alpha + cb[(h * E + e) >> 2][(h * E + e) & 3] + (resp ? f[e] : 0.0f);
                             const u32x4_t w = pack16<TO>(v);
-                            if (!(RF_DBG(p, 8))) ((u32x4_t*)dst)[h] = w;
+                            if (!(RF_DBG(p, 8))) st16_out((u32x4_t*)dst + h, w);
                             if (gn_on) {
                                 float y[E];
                                 unpack16<TO>(w, y);              // the values as stored replace the (dead) accumulators: no extra registers

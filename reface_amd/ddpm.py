@@ -221,7 +221,7 @@ class LatentDiffusion(nn.Module, _DeviceMixin):
         conditioning vector and the inpaint latent then deviate ~1 % from fp32 -- throughput mode only; the VAE decode stays fp32)."""
         self.model.diffusion_model.set_compute_dtype(dtype)
         self._sync_decode_mode(dtype)
-        if dtype in ("fp8", "fp8w"):       # fp8 GEMM operands are a UNet mode; the towers / VAE encoder take the bf16 activations' dtype
+        if dtype in ("fp8", "fp8w", "fp8c"):       # fp8 GEMM operands are a UNet mode; the towers / VAE encoder take the bf16 activations' dtype
             dtype = torch.bfloat16
         elif dtype == "f32x3":             # split-bf16 UNet operands (fast parity mode): everything around it stays fp32
             dtype = torch.float32

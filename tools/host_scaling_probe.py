@@ -32,14 +32,17 @@ def make_tree(root, n):
         Image.fromarray(rng.integers(0, 19, (512, 512), dtype=np.uint8)).save(os.path.join(root, "CelebA-HQ-mask", "Overall_mask", f"{i}.png"))
 
 
-def worker(tree, outdir, batches, device_ms, B=8, legacy=False, world=1, png_level=None):
+def worker(tree, outdir, batches, device_ms, B=8, legacy=False, world=1, png_level=None, gpu_prep=False):
     import numpy as np
     import torch
     from reface_amd import output as O
     from reface_amd.data import CelebAdataset
     torch.set_num_threads(1)
-    ds = CelebAdataset(dataset_dir=tree, n_targets=batches * B)
-    loader = torch.utils.data.DataLoader(ds, batch_size=B, num_workers=4, shuffle=False)
+    # --gpu-prep: the readers only decode / resize and hand over uint8 arrays (raw="full": normalisation, masks, the 224x224 source resize and
+    # the products run on the GPU, reface_amd/prep.py) -- the host half the CLI has with --gpu_prep
+    from reface_amd.data import raw_collate
+    ds = CelebAdataset(dataset_dir=tree, n_targets=batches * B, raw="full" if gpu_prep else False)
+    loader = torch.utils.data.DataLoader(ds, batch_size=B, num_workers=4, shuffle=False, collate_fn=raw_collate if gpu_prep else None)
     [os.makedirs(os.path.join(outdir, d), exist_ok=True) for d in ("results", "grid", "samples")]
     # round 4: the panels / grid are composed on the GPU and arrive as ONE packed uint8 record per image; the writer's worker count is the
     # process's share of the host.  --legacy: the round-3 host half (fp32 panels composed on the host, 8 workers per process)
@@ -51,10 +54,15 @@ def worker(tree, outdir, batches, device_ms, B=8, legacy=False, world=1, png_lev
     t0 = time.perf_counter()
     host_ms = []
     n = 0
-    for target, prior, kw, ids in loader:
+    for item in loader:
+        if gpu_prep:
+            target, ids = item[0], item[4]
+            kw = None
+        else:
+            target, prior, kw, ids = item
         t_host = time.perf_counter()
         time.sleep(device_ms / 1e3)                      # the device's share of the batch (sampling + decode are queued, the host is free)
-        if legacy:
+        if legacy and not gpu_prep:
             writer.submit(list(ids), pool_f[0][:target.shape[0]], target.float().numpy(), kw["inpaint_image"].float().numpy(),
                           kw["inpaint_mask"].float().numpy(), pool_f[1][:target.shape[0]])
         else:
@@ -78,17 +86,18 @@ def main():
     ap.add_argument("--worker", nargs=2, default=None)
     ap.add_argument("--legacy", action="store_true", help="the round-3 host half: fp32 panels composed on the host, 8 PNG workers per process")
     ap.add_argument("--world", type=int, default=1, help="(worker) processes sharing the host")
+    ap.add_argument("--gpu-prep", action="store_true", help="readers hand over uint8 arrays only (the CLI's --gpu_prep)")
     ap.add_argument("--png-level", type=int, default=None, help="zlib level of the PNG files (default: PIL's 6, the reference's files)")
     a = ap.parse_args()
     if a.worker:
-        worker(a.worker[0], a.worker[1], a.batches, a.device_ms, legacy=a.legacy, world=a.world, png_level=a.png_level)
+        worker(a.worker[0], a.worker[1], a.batches, a.device_ms, legacy=a.legacy, world=a.world, png_level=a.png_level, gpu_prep=a.gpu_prep)
         return
     with tempfile.TemporaryDirectory() as tmp:
         tree = os.path.join(tmp, "CelebAMask-HQ")
         make_tree(tree, a.batches * 8)
         out = {}
         for n in (1, a.procs):
-            extra = (["--legacy"] if a.legacy else []) + (["--png-level", str(a.png_level)] if a.png_level is not None else [])
+            extra = (["--legacy"] if a.legacy else []) + (["--png-level", str(a.png_level)] if a.png_level is not None else []) + (["--gpu-prep"] if a.gpu_prep else [])
             ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", tree, os.path.join(tmp, f"out_{n}_{r}"), "--batches", str(a.batches),
                                     "--device-ms", str(a.device_ms), "--world", str(n)] + extra, stdout=subprocess.PIPE, text=True) for r in range(n)]
             rs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in ps]
@@ -96,7 +105,8 @@ def main():
                       "host_ms_on_launch_thread_max": max(r["host_ms_on_launch_thread"] for r in rs)}
         out["cpus"] = len(os.sched_getaffinity(0))
         out["host_half"] = "round 3 (fp32 panels composed on the host, 8 PNG workers)" if a.legacy else \
-            f"round 4 (packed uint8 records from the device, PNG workers = share of the host, zlib level {a.png_level if a.png_level is not None else 6})"
+            f"round 4 (packed uint8 records from the device, PNG workers = share of the host, zlib level {a.png_level if a.png_level is not None else 6}" + \
+            (", readers decode / resize only: --gpu_prep)" if a.gpu_prep else ")")
         out["device_ms_assumed"] = a.device_ms
         out["verdict"] = ("host half hides under the device time in all %d processes" % a.procs
                           if out[a.procs]["ms_per_batch_max"] < 1.05 * max(a.device_ms, out[1]["ms_per_batch_max"]) else
