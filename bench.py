@@ -352,7 +352,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="image pairs per GPU per step (overrides the config)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--latent", type=int, default=None, help="latent side (64 = 512x512 images; overrides the config)")
-    ap.add_argument("--dtype", default=None, choices=["bf16", "f32", "fp8", "fp8w", "fp8c"], help="UNet compute mode (overrides the config)")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f32", "f32x3", "fp8", "fp8w", "fp8c"], help="UNet compute mode (overrides the config)")
     ap.add_argument("--scale", type=float, default=3.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -389,7 +389,7 @@ def main():
 
     from reface_amd import ops
     from reface_amd.ddim import DDIMSampler
-    dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "fp8": "fp8", "fp8w": "fp8w", "fp8c": "fp8c"}[dname]
+    dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "f32x3": "f32x3", "fp8": "fp8", "fp8w": "fp8w", "fp8c": "fp8c"}[dname]
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     unet, vae, ldm, cpu_sd = build_models(dtype, device, rank, world, want_cpu)
     sampler = DDIMSampler(ldm)
@@ -438,6 +438,7 @@ def main():
 
     px = 8 * h
     wdesc = {"bf16": "bf16 UNet", "f32": "exact-fp32 UNet",
+             "f32x3": "fp32-storage UNet on split-bf16 operand pairs (three bf16 MFMA passes per product, GEMMs and attention; fp32 accumulate / softmax / norms)",
              "fp8": "fp8 (e4m3fn) UNet weights + fp8 activations (E8M0 block scales) into the ResBlock convs / proj_in / qkv / GEGLU on the fp8 MFMA, "
                     "bf16 residual stream, fp32 accumulate",
              "fp8w": "fp8 (e4m3fn) UNet weights, bf16 activations, fp32 accumulate",
@@ -515,7 +516,7 @@ def main():
             with open(args.profile_json, "w") as f:
                 json.dump({"families": fam, "vae_families": dfam, "step_launches": [row(l, ms) for l, ms in timed_l],
                            "vae_launches": [row(l, ms) for l, ms in dtimed]}, f, indent=1)
-    if rank == 0 and world == 1 and not args.no_parity and dname != "f32":
+    if rank == 0 and world == 1 and not args.no_parity and dname not in ("f32", "f32x3"):
         try:
             # (a) the reduced-precision mode's image error against the exact-fp32 mode, full width, full S
             result[f"parity_{dname}_vs_f32"] = image_parity(unet, vae, ldm, h, S, args.scale, device)

@@ -107,6 +107,19 @@ typedef struct rf_conv_gemm_desc {
     /* one E8M0 byte per (row, 32 output columns), row pitch os_ld -- the A operand of the following ff.net.2 GEMM (attention.py:60). */
     void* oscale;
     int32_t os_ld;
+    /* LayerNorm folded around two bf16 GEMMs (attention.py:231-233, 239-243: norm1 in front of to_q / to_k / to_v, norm3 in front of ff.net.0). */
+    /* PRODUCER of the tensor to be normalised (direct epilogue, no split-K): ln_stats_out [M][ln_out_parts][2] fp32 receives, per row and per */
+    /* column stripe of its wave tile (rf_conv_gemm_plan2's wave_cols; ln_out_parts = N / wave_cols), the (mean, M2 = sum of squared deviations) */
+    /* of the values as stored.  CONSUMER (A = that tensor, un-normalised): out = act(rstd[m] * (alpha * acc - mean[m] * ln_u[n]) + bias[n]) with */
+    /* mean / rstd of row m combined from ln_stats_in [M][ln_in_parts][2] (ln_in_cols columns per part, eps = ln_eps); the caller folds gamma */
+    /* into W's columns, passes ln_u[n] = sum_k W[n, k] (of the folded, rounded W) and W beta (+ the layer's bias) as `bias`. */
+    /* Replaces the nn.LayerNorm pass between the two GEMMs (one read + one write of [M, C] and a launch). */
+    void* ln_stats_out;
+    int32_t ln_out_parts;
+    const void* ln_stats_in;
+    int32_t ln_in_parts, ln_in_cols;
+    float ln_eps;
+    const float* ln_u;
 } rf_conv_gemm_desc;
 
 int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream);
@@ -117,6 +130,9 @@ int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream);
  * slot = gn_slot + (row tile within the sample) * ceil(N / bn) + column tile.  Replaces the separate statistics pass of
  * nn.GroupNorm (util.py:214-216) over a tensor this GEMM has just produced. */
 int rf_conv_gemm_plan(const rf_conv_gemm_desc* d, int32_t* bm, int32_t* bn, int32_t* splitk);
+/* The same query with the whole tile plan: info8 = {statistics rows, statistics cols, splitk, BM, BN, wave_cols (columns of one wave's tile),
+ * epilogue form (1 = direct register -> global, 0 = staged), split-K through fragment slabs (0 / 1)}. */
+int rf_conv_gemm_plan2(const rf_conv_gemm_desc* d, int32_t* info8);
 
 /* Fused transformer feed-forward at C = 320 (the 64x64 level):  out = (GEGLU(x W1^T + b1)) W2^T + b2 + residual, bf16 in / out, fp32
  * accumulate, GELU on the tanh form (the bf16 mode's).  The [M, 4C] hidden tensor stays in registers (tokens on lanes, see ffn.hip).

@@ -38,6 +38,8 @@ class ConvGemmDesc(C.Structure):
         ("w_dtype", C.c_int32), ("wscale", C.c_void_p),
         ("ascale", C.c_void_p), ("as_ld", C.c_int32),
         ("oscale", C.c_void_p), ("os_ld", C.c_int32),
+        ("ln_stats_out", C.c_void_p), ("ln_out_parts", C.c_int32),
+        ("ln_stats_in", C.c_void_p), ("ln_in_parts", C.c_int32), ("ln_in_cols", C.c_int32), ("ln_eps", C.c_float), ("ln_u", C.c_void_p),
     ]
 
 
@@ -46,6 +48,7 @@ _SIGS = {
     "rf_version": (C.c_int, []),
     "rf_conv_gemm": (C.c_int, [C.POINTER(ConvGemmDesc), C.c_void_p]),
     "rf_conv_gemm_plan": (C.c_int, [C.POINTER(ConvGemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "rf_conv_gemm_plan2": (C.c_int, [C.POINTER(ConvGemmDesc), C.POINTER(C.c_int32)]),
     "rf_ffn_geglu": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "rf_quantize_fp8_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -35,6 +35,7 @@
 #endif
 
 namespace rf {
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void st16_out(void* ptr, const u32x4_t& w) {
 #if RF_STORE_SC1
@@ -74,7 +75,7 @@ struct GemmParams {
     int gn_rows;
     double* gn_part[2];
     int gn_cpg[2], gn_coff[2], gn_slot[2], gn_nch[2];
-    int* plan;       // host only: {BM, BN, splitk} requested by rf_conv_gemm_plan (no launch)
+    int* plan;       // host only: rf_conv_gemm_plan / rf_conv_gemm_plan2 (no launch): {stat rows, stat cols, splitk, BM, BN, 32 TN, epilogue form, frag slabs}
     int epi2_ok;     // host only: operand alignment / feature set allow the direct (register -> global) epilogue
     int dbg;         // RF_GEMM_DBG (timing experiments only): bit 0 = skip the epilogue, bit 1 = skip the main loop
     const float* wscale;   // W8 kernels: per-output-channel power-of-two scale of the fp8 (e4m3fn) weights
@@ -83,6 +84,15 @@ struct GemmParams {
     const void* ascale;    // A8 kernels (fp8 activations): E8M0 scale bytes, one per (pixel, 32-channel block), pixel pitch as_ld bytes (a multiple of 4)
     int as_ld;
     unsigned as_bytes;
+    // LayerNorm folded around two GEMMs (rf_conv_gemm_desc.ln_*).  Producer: per row and per 32 TN-column stripe of the wave tile, (mean, M2)
+    // of the values as stored -> ln_out [M][ln_out_parts][2].  Consumer: out = rstd[m] (alpha acc - mean[m] ln_u[n]) + bias[n] with the row
+    // statistics combined from ln_in's parts (Chan's formula); gamma rides in W, beta W^T in the bias (host).
+    float* ln_out;
+    int ln_out_parts;
+    const float* ln_in;
+    int ln_in_parts, ln_in_cols;
+    float ln_eps;
+    const float* ln_u;
     int x3;          // split-bf16 operands (RF_BF16X3): K counts VIRTUAL tiles, three per real 64-element K tile -- (A hi, W hi), (A hi, W lo),
                      // (A lo, W hi); W rows hold them in that order, the A lo plane lies lo_off bytes behind the hi plane of the same pixel
     int lo_off;
@@ -185,8 +195,11 @@ __device__ __forceinline__ void halfwave_reduce_scatter32(float (&gx)[32], int l
 // geometry and therefore holds 128 K elements = the W operand of TWO consecutive A tiles: the W pieces are issued every other
 // tile (half the weight bytes through L2 / LDS), and a W fragment is an 8-byte LDS read turned into 8 bf16 by 4 conversions
 // (issued between the MFMAs of the previous fragment column).  The MFMA itself is the bf16 one: same matrix-core ceiling.
-template <typename T, typename TO, int WM, int WN, int TM, int TN, bool CONV, bool GLDS, int NST, int EPI = 0, bool W8 = false>
+// LNF: LayerNorm role of the launch (rf_conv_gemm_desc.ln_*), a compile-time variant of the direct epilogue so that ordinary launches carry none
+// of its registers: 0 none, 1 producer (row statistics of the stored output), 2 consumer (row affine; such launches have no residual)
+template <typename T, typename TO, int WM, int WN, int TM, int TN, bool CONV, bool GLDS, int NST, int EPI = 0, bool W8 = false, int LNF = 0>
 __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams p) {
+    static_assert(LNF == 0 || (EPI == 1 && !CONV && !W8 && sizeof(T) == 2 && sizeof(TO) == 2), "LayerNorm folding: bf16 linear layers on the direct epilogue");
     static_assert(EPI == 0 || GLDS, "the direct / packed epilogues are built on the direct-to-LDS main loop");
     static_assert(EPI != 2 || sizeof(TO) == 2, "the packed staged epilogue writes bf16");
     static_assert(!W8 || (GLDS && sizeof(T) == 2), "fp8 weights: bf16 activations on the direct-to-LDS main loop");
@@ -240,6 +253,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             if (p.bias) colc = p.bias[n0 + tid];
             if (p.rowvec) colc += p.rowvec[(long long)(m0 / p.rows_per_sample) * p.ldv + n0 + tid];
         }
+    }
+    float colu = 0.f;          // LayerNorm consumer: sum_k W[n, k] of this thread's column (the mean's coefficient)
+    if constexpr (LNF == 2) {
+        if (tid < BN && n0 + tid < p.N) colu = p.ln_u[n0 + tid];
     }
 #if RF_RES_TOUCH
     // experiment: pull the residual rows of this tile into L2 now (one dword per 128-byte line, data discarded), so that the epilogue's residual
@@ -1089,7 +1106,33 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         };
         // column constants -> LDS (the main loop ended on a barrier: the operand stages are dead)
         float* const colc_lds = (float*)smem;
-        if (tid < BN) colc_lds[tid] = colc;
+        float* const colu_lds = (float*)(smem + 12288);            // (behind the GroupNorm column sums at +2048 .. +12288)
+        constexpr bool ln_c = LNF == 2;                             // this launch consumes a LayerNorm-ed operand: row affine in the epilogue
+        if (tid < BN) {
+            colc_lds[tid] = colc;
+            if (ln_c) colu_lds[tid] = colu;
+        }
+        // row statistics of this lane's TM rows from the producer's per-stripe (mean, M2) records: equal counts per part, Chan's combination
+        float ln_rs[TM], ln_rm[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { ln_rs[i] = 1.f; ln_rm[i] = 0.f; }
+        if constexpr (ln_c) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = m0 + (wm * TM + i) * 32 + lrow;
+                if (row < p.M) {
+                    const f32x2_t* const sp = (const f32x2_t*)p.ln_in + (long long)row * p.ln_in_parts;
+                    float mean = 0.f;
+                    for (int q = 0; q < p.ln_in_parts; ++q) mean += sp[q][0];
+                    mean /= (float)p.ln_in_parts;
+                    float m2 = 0.f;
+                    for (int q = 0; q < p.ln_in_parts; ++q) { const float dq = sp[q][0] - mean; m2 += sp[q][1] + (float)p.ln_in_cols * dq * dq; }
+                    const float rs = 1.0f / sqrtf(m2 / (float)(p.ln_in_cols * p.ln_in_parts) + p.ln_eps);
+                    ln_rs[i] = rs;
+                    ln_rm[i] = rs * mean;
+                }
+            }
+        }
         lds_barrier();
         bool geglu = false;
         if constexpr (TN % 2 == 0) geglu = p.act == RF_ACT_GEGLU;
@@ -1100,24 +1143,38 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                     const int cv = n0 + (wn * TN + j) * 32 + lhalf * 16;           // value columns (packed order); gate = +32
                     const int ocol = (n0 >> 1) + ((wn * TN + j) >> 1) * 32 + lhalf * 16;
                     const bool cok = cv + 32 < p.N;
-                    float bv[16], bg[16];
+                    float bv[16], bg[16], uv[16], ug[16];          // (uv / ug: LayerNorm consumers only -- untouched and eliminated otherwise)
 #pragma unroll
                     for (int h = 0; h < 4; ++h) {
                         const f32x4_t a = ((const f32x4_t*)(colc_lds + (cv - n0)))[h], g = ((const f32x4_t*)(colc_lds + (cv - n0) + 32))[h];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { bv[4 * h + e] = a[e]; bg[4 * h + e] = g[e]; }
+                        if constexpr (ln_c) {
+                            const f32x4_t ua = ((const f32x4_t*)(colu_lds + (cv - n0)))[h], ugg = ((const f32x4_t*)(colu_lds + (cv - n0) + 32))[h];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { uv[4 * h + e] = ua[e]; ug[4 * h + e] = ugg[e]; }
+                        }
                     }
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         const int row = m0 + (wm * TM + i) * 32 + lrow;
                         if (row < p.M && cok) {
                             float v[16];
+                            if constexpr (ln_c) {          // LayerNorm folded in: rstd (alpha acc - mean u) + b'  (gamma is in W, W beta in the bias)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const float a_ = acc[i][j][r] * p.alpha + bv[r], g_ = acc[i][j + 1][r] * p.alpha + bg[r];
-                                v[r] = a_ * gelu_for<T>(g_);
+                                for (int r = 0; r < 16; ++r) {
+                                    const float a_ = __builtin_fmaf(acc[i][j][r] * p.alpha, ln_rs[i], __builtin_fmaf(-ln_rm[i], uv[r], bv[r]));
+                                    const float g_ = __builtin_fmaf(acc[i][j + 1][r] * p.alpha, ln_rs[i], __builtin_fmaf(-ln_rm[i], ug[r], bg[r]));
+                                    v[r] = a_ * gelu_for<T>(g_);
+                                }
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const float a_ = acc[i][j][r] * p.alpha + bv[r], g_ = acc[i][j + 1][r] * p.alpha + bg[r];
+                                    v[r] = a_ * gelu_for<T>(g_);
+                                }
                             }
-                            if (resp) {
+                            if (!ln_c && resp) {
                                 const u32x4_t* rp = (const u32x4_t*)(resp + (long long)row * p.ldr + ocol);
 #pragma unroll
                                 for (int h = 0; h < OV; ++h) {
@@ -1163,7 +1220,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 const int i = blk % TM, j = blk / TM;
                 const int col = n0 + (wn * TN + j) * 32 + lhalf * 16;
                 const int row = m0 + (wm * TM + i) * 32 + lrow;
-                if (resp && row < p.M && col < p.N) {
+                if (!ln_c && resp && row < p.M && col < p.N) {
                     const u32x4_t* rp = (const u32x4_t*)(resp + (long long)row * p.ldr + col);
 #pragma unroll
                     for (int h = 0; h < OV; ++h) r[h] = rp[h];
@@ -1176,6 +1233,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             // squares), the wave rows meet in LDS and 64 threads form the 32 group sums per consumer in fp64 -- same slots, same
             // consumers as the staged epilogue.
             const bool gn_on = p.gn_rows > 0;
+            constexpr bool ln_p = LNF == 1;                      // this launch also emits the LayerNorm row statistics of its output
+            const bool keep_on = gn_on || ln_p;                  // the values as stored replace the (dead) accumulators
             float* const gcs = (float*)(smem + 2048);            // [2][WM][BN] column sums / sums of squares per wave row
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -1184,6 +1243,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 f32x4_t cb[4];
 #pragma unroll
                 for (int h = 0; h < 4; ++h) cb[h] = ((const f32x4_t*)(colc_lds + (col - n0)))[h];
+                // (LayerNorm consumer: rstd (alpha acc - mean u) + b' -- the row factors differ per i, the two column vectors are combined per element)
+                f32x4_t cu[4];          // (LayerNorm consumers only)
+                if constexpr (ln_c) {
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) cu[h] = ((const f32x4_t*)(colu_lds + (col - n0)))[h];
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int blk = j * TM + i;
@@ -1197,18 +1262,25 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                             constexpr int E = 16 / OV;
                             float f[E], v[E];
                             if (resp) unpack16<TO>(myr[h], f);
+                            if constexpr (ln_c) {          // (no residual on a LayerNorm consumer: host)
 #pragma unroll
-                            for (int e = 0; e < E; ++e) v[e] = acc[i][j][h * E + e] * p.alpha + cb[(h * E + e) >> 2][(h * E + e) & 3] + (resp ? f[e] : 0.0f);
+                                for (int e = 0; e < E; ++e)
+                                    v[e] = __builtin_fmaf(acc[i][j][h * E + e] * p.alpha, ln_rs[i],
+                                                          __builtin_fmaf(-ln_rm[i], cu[(h * E + e) >> 2][(h * E + e) & 3], cb[(h * E + e) >> 2][(h * E + e) & 3]));
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < E; ++e) v[e] = acc[i][j][h * E + e] * p.alpha + cb[(h * E + e) >> 2][(h * E + e) & 3] + (resp ? f[e] : 0.0f);
+                            }
                             const u32x4_t w = pack16<TO>(v);
                             if (!(RF_DBG(p, 8))) st16_out((u32x4_t*)dst + h, w);
-                            if (gn_on) {
+                            if (keep_on) {
                                 float y[E];
                                 unpack16<TO>(w, y);              // the values as stored replace the (dead) accumulators: no extra registers
 #pragma unroll
                                 for (int e = 0; e < E; ++e) acc[i][j][h * E + e] = y[e];
                             }
                         }
-                    } else if (gn_on) {
+                    } else if (keep_on) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
                     }
@@ -1248,6 +1320,36 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                         o[0] = sa;
                         o[1] = sq;
                     }
+                }
+            }
+            if constexpr (ln_p) {
+                // LayerNorm statistics of the rows this wave wrote, over its 32 TN columns (values as stored): the lane pair (row, half 0 / 1)
+                // holds them all -- two-pass (mean, then squared deviations) in registers, the halves meet through v_permlane32_swap;
+                // record = (mean, M2) per row and column stripe, combined by the consumer GEMM's epilogue
+                const int part = (n0 + wn * TN * 32) / (TN * 32);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float sm = 0.f;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) sm += acc[i][j][e];
+                    {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(as_u32(sm), as_u32(sm), false, false);
+                        sm = as_f32(sw[0]) + as_f32(sw[1]);
+                    }
+                    const float mean = sm / (float)(TN * 32);
+                    float sq = 0.f;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) { const float dq = acc[i][j][e] - mean; sq += dq * dq; }
+                    {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(as_u32(sq), as_u32(sq), false, false);
+                        sq = as_f32(sw[0]) + as_f32(sw[1]);
+                    }
+                    const int row = m0 + (wm * TM + i) * 32 + lrow;
+                    if (lhalf == 0 && row < p.M) *(f32x2_t*)(p.ln_out + ((long long)row * p.ln_out_parts + part) * 2) = f32x2_t{mean, sq};
                 }
             }
         }
@@ -1777,7 +1879,29 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
         RF_CHECK(DOK && TN % 2 == 0 && p.glds && p.epi2_ok && p.splitk == 1,
                  "rf_conv_gemm: fp8 output needs the direct epilogue (even TN, aligned rows, no split-K) -- this launch got a %d x %d tile", BM, BN);
     }
-    if (p.plan) { p.plan[0] = st_rows; p.plan[1] = st_cols; p.plan[2] = p.splitk; return 0; }
+    // epilogue form (needed by the plan query too): see the selection notes below
+    static const int epi_env = tune_env("RF_EPI", -1);
+    constexpr bool PACKED_OK = sizeof(TO) == 2 && !A8;
+    constexpr bool DIRECT_OK = (WM * WN == 8) || (TM * TN == 5) || (TM * TN >= 16) || std::is_same<T, fp8_t>::value;      // (fp8 x fp8: every tile --
+                                                                                          // the GEGLU epilogue with fp8 output exists only in this form)
+    const bool ep_common = p.glds && p.epi2_ok && p.splitk == 1 && (!p.rowvec || p.rows_per_sample % BM == 0) &&
+                           (d->act == RF_ACT_NONE || (d->act == RF_ACT_GEGLU && TN % 2 == 0));
+    static const int gn_direct = tune_env("RF_EPI_GN", 1);      // 0: fused statistics keep EPI 0
+    const bool direct = DIRECT_OK && (epi_env < 0 || epi_env == 1) && ep_common && (p.gn_rows == 0 || (gn_direct && d->act == RF_ACT_NONE));
+    // LayerNorm folding lives in the direct epilogue only (bf16 linear layers: the LNF variants of the kernel)
+    constexpr bool LN_OK = DIRECT_OK && sizeof(T) == 2 && sizeof(TO) == 2 && !W8 && !A8;
+    RF_CHECK(!(p.ln_out || p.ln_in) || (LN_OK && !conv),
+             "rf_conv_gemm: LayerNorm folding needs a bf16 linear layer on a direct-epilogue tile (this launch: %d x %d, conv %d)", BM, BN, (int)conv);
+    RF_CHECK(!p.ln_in || !d->residual, "rf_conv_gemm: a LayerNorm consumer takes no residual");
+    RF_CHECK(!p.ln_out || (direct && d->act == RF_ACT_NONE && p.N % (32 * TN) == 0 && p.ln_out_parts == p.N / (32 * TN)),
+             "rf_conv_gemm: ln_stats_out needs the direct epilogue (no split-K, act NONE) and ln_out_parts = N / %d (got %d; direct %d)", 32 * TN, p.ln_out_parts, (int)direct);
+    RF_CHECK(!p.ln_in || (direct && p.ln_u && p.ln_in_parts >= 1 && p.ln_in_cols >= 1 && p.ln_eps > 0.f && BN <= 320),
+             "rf_conv_gemm: ln_stats_in needs the direct epilogue (no split-K), ln_u, ln_in_parts / ln_in_cols >= 1 and ln_eps > 0 (direct %d)", (int)direct);
+    if (p.plan) {
+        p.plan[0] = st_rows; p.plan[1] = st_cols; p.plan[2] = p.splitk; p.plan[3] = BM; p.plan[4] = BN; p.plan[5] = 32 * TN;
+        p.plan[6] = direct ? 1 : 0; p.plan[7] = frag ? 1 : 0;
+        return 0;
+    }
     if (p.gn_rows > 0) {
         RF_CHECK(p.gn_rows % st_rows == 0 && p.M % p.gn_rows == 0 && d->batch == 1 && d->act != RF_ACT_GEGLU,
                  "rf_conv_gemm: fused GroupNorm statistics need gn_rows %% %d == 0 (%d), batch 1, no GEGLU -- ask rf_conv_gemm_plan", st_rows, p.gn_rows);
@@ -1795,35 +1919,28 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     //   EPI 0, fp32 tile staged in row chunks: everything else (split-K partials, per-row timestep vectors, activations other than
     //          GEGLU, fp32 output with statistics, unaligned shapes).
     // RF_EPI=0 forces EPI 0, RF_EPI=1 / 2 allow only that fast form (A/B runs).
-    static const int epi_env = tune_env("RF_EPI", -1);
-    constexpr bool PACKED_OK = sizeof(TO) == 2 && !A8;
-    constexpr bool DIRECT_OK = (WM * WN == 8) || (TM * TN == 5) || (TM * TN >= 16) || std::is_same<T, fp8_t>::value;      // (fp8 x fp8: every tile --
-                                                                                          // the GEGLU epilogue with fp8 output exists only in this form)
-    const bool ep_common = p.glds && p.epi2_ok && p.splitk == 1 && (!p.rowvec || p.rows_per_sample % BM == 0) &&
-                           (d->act == RF_ACT_NONE || (d->act == RF_ACT_GEGLU && TN % 2 == 0));
-    static const int gn_direct = tune_env("RF_EPI_GN", 1);      // 0: fused statistics keep EPI 0
-    const bool direct = DIRECT_OK && (epi_env < 0 || epi_env == 1) && ep_common && (p.gn_rows == 0 || (gn_direct && d->act == RF_ACT_NONE));
     // (packed: measured neutral-to-negative in situ -- proj_out 4096x1280x1280 with fused statistics 37 -> 63 us, the rest within
     //  noise, r02f -- so it is opt-in: RF_EPI=2)
     const bool packed = !direct && PACKED_OK && epi_env == 2 && ep_common;
     RF_CHECK(!p.oscale || direct, "rf_conv_gemm: fp8 output needs the direct epilogue (8-wave tile, aligned rows, no split-K)");
     constexpr int smem_pk = BM * BN * 2;
     const int smem_l = (packed && smem_pk > smem) ? smem_pk : smem;
-#define RF_LAUNCH_VARIANT(CONV_, GLDS_, EPI_)                                                                                   \
+#define RF_LAUNCH_VARIANT_LN(CONV_, GLDS_, EPI_, LNF_)                                                                          \
     {                                                                                                                            \
         constexpr int E_ = (EPI_ == 2 && PACKED_OK) ? 2 : ((EPI_ == 1 && DIRECT_OK) ? 1 : 0);                                   \
         if (GLDS_ && deep) {                                                                                                     \
-            auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NSTD : 2), E_, (W8 && GLDS_)>;              \
+            auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NSTD : 2), E_, (W8 && GLDS_), LNF_>;        \
             static bool attr = false;                                                                                            \
             if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem_deep); attr = true; } \
             hipLaunchKernelGGL(k, grid, block, smem_deep, st, p);                                                                \
         } else {                                                                                                                 \
-            auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NST : 2), E_, (W8 && GLDS_)>;               \
+            auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NST : 2), E_, (W8 && GLDS_), LNF_>;         \
             static bool attr = false;                                                                                            \
             if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem_pk > smem ? smem_pk : smem); attr = true; } \
             hipLaunchKernelGGL(k, grid, block, smem_l, st, p);                                                                   \
         }                                                                                                                        \
     }
+#define RF_LAUNCH_VARIANT(CONV_, GLDS_, EPI_) RF_LAUNCH_VARIANT_LN(CONV_, GLDS_, EPI_, 0)
     const int esel = packed ? 2 : ((direct || frag) ? 1 : 0);
     // The ring of four stages for 128x160 launches of at most one block per CU (4096 x 1280 x K <= 6000: the projections, ff.net.2 and 1x1 skips
     // of the 16x16 level, 25 launches per step): nothing else covers the single tile of look-ahead there.  Alone (warm weights) it is neutral
@@ -1845,12 +1962,20 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
         RF_LAUNCH_VARIANT(true, false, 0)
     } else if (p.glds) {
         if (esel == 2) RF_LAUNCH_VARIANT(false, true, 2)
-        else if (esel == 1) RF_LAUNCH_VARIANT(false, true, 1)
+        else if (esel == 1) {
+            // (LayerNorm roles: compile-time variants of the direct epilogue, bf16 linear layers only)
+            if constexpr (LN_OK) {
+                if (p.ln_in) RF_LAUNCH_VARIANT_LN(false, true, 1, 2)
+                else if (p.ln_out) RF_LAUNCH_VARIANT_LN(false, true, 1, 1)
+                else RF_LAUNCH_VARIANT(false, true, 1)
+            } else RF_LAUNCH_VARIANT(false, true, 1)
+        }
         else RF_LAUNCH_VARIANT(false, true, 0)
     } else {
         RF_LAUNCH_VARIANT(false, false, 0)
     }
 #undef RF_LAUNCH_VARIANT
+#undef RF_LAUNCH_VARIANT_LN
     if (p.splitk > 1 && frag) {
         if constexpr (FRAG_OK)
             hipLaunchKernelGGL((splitk_reduce_frag_kernel<TO, WM, WN, TM, TN>), dim3(p.tiles_m * p.tiles_n, WM * WN * TM), dim3(64 * TN), 0, st, p);
@@ -2025,6 +2150,10 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
     p.gn_part[0] = d->gn_part0; p.gn_cpg[0] = d->gn_cpg0; p.gn_coff[0] = d->gn_coff0; p.gn_slot[0] = d->gn_slot0; p.gn_nch[0] = d->gn_nchunks0;
     p.gn_part[1] = d->gn_part1; p.gn_cpg[1] = d->gn_cpg1; p.gn_coff[1] = d->gn_coff1; p.gn_slot[1] = d->gn_slot1; p.gn_nch[1] = d->gn_nchunks1;
     p.plan = plan;
+    p.ln_out = (float*)d->ln_stats_out; p.ln_out_parts = d->ln_out_parts;
+    p.ln_in = (const float*)d->ln_stats_in; p.ln_in_parts = d->ln_in_parts; p.ln_in_cols = d->ln_in_cols; p.ln_eps = d->ln_eps; p.ln_u = d->ln_u;
+    RF_CHECK(!(p.ln_out || p.ln_in) || (d->out_dtype == RF_BF16 && d->dtype == RF_BF16 && d->batch == 1 && !(p.ln_out && p.ln_in)),
+             "rf_conv_gemm: LayerNorm folding is built for bf16 GEMMs (batch 1, one role per launch)");
     {
         static const int dbg = tune_env("RF_GEMM_DBG", 0);
         p.dbg = dbg;
@@ -2137,8 +2266,17 @@ extern "C" int rf_quantize_fp8_rows(const float* w, int N, int K, int ldq, void*
 extern "C" int rf_conv_gemm_plan(const rf_conv_gemm_desc* d, int32_t* bm, int32_t* bn, int32_t* splitk) {
     using namespace rf;
     RF_CHECK(bm && bn && splitk, "rf_conv_gemm_plan: null output");
-    int plan[3] = {0, 0, 0};
+    int plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int rc = conv_gemm_impl(d, nullptr, plan);
     *bm = plan[0]; *bn = plan[1]; *splitk = plan[2];
+    return rc;
+}
+
+extern "C" int rf_conv_gemm_plan2(const rf_conv_gemm_desc* d, int32_t* info8) {
+    using namespace rf;
+    RF_CHECK(info8, "rf_conv_gemm_plan2: null output");
+    int plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int rc = conv_gemm_impl(d, nullptr, plan);
+    for (int i = 0; i < 8; ++i) info8[i] = plan[i];
     return rc;
 }

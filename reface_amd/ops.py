@@ -359,7 +359,8 @@ def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, 
     return l
 
 
-def linear(x, W, out, bias=None, *, act=ACT_NONE, residual=None, rowvec=None, rows_per_sample=0, alpha=1.0, act_vec=None, x3=False, name="linear"):
+def linear(x, W, out, bias=None, *, act=ACT_NONE, residual=None, rowvec=None, rows_per_sample=0, alpha=1.0, act_vec=None, x3=False, ln_u=None,
+           name="linear"):
     """out[M, N] = act(x[M, K] @ W[N, K]^T + bias) (+ residual).  x / out may be row-strided 2-D views.  x3: x is the split-bf16 form
     [M, 2K] of an fp32 matrix and W comes from pack_x3 ([N, 3K])."""
     if x3:
@@ -377,10 +378,15 @@ def linear(x, W, out, bias=None, *, act=ACT_NONE, residual=None, rowvec=None, ro
     N = W.shape[0]
     ldo = out.q.stride(0) if isinstance(out, Fp8Act) else out.stride(0)
     assert W.shape[1] == K and (isinstance(out, Fp8Act) or out.stride(1) == 1), (tuple(W.shape), K)
-    return conv_gemm(x, W, out, M=M, N=N, K=K, C0=K, ld0=ld0, Hin=1, Win=M, Hout=1, Wout=M, bias=bias, act=act,
-                     residual=residual, ldr=(residual.stride(0) if residual is not None else 0), rowvec=rowvec,
-                     rows_per_sample=rows_per_sample, ldv=(rowvec.stride(0) if rowvec is not None else 0),
-                     ldo=ldo, alpha=alpha, act_vec=act_vec, name=name)
+    l = conv_gemm(x, W, out, M=M, N=N, K=K, C0=K, ld0=ld0, Hin=1, Win=M, Hout=1, Wout=M, bias=bias, act=act,
+                  residual=residual, ldr=(residual.stride(0) if residual is not None else 0), rowvec=rowvec,
+                  rows_per_sample=rows_per_sample, ldv=(rowvec.stride(0) if rowvec is not None else 0),
+                  ldo=ldo, alpha=alpha, act_vec=act_vec, name=name)
+    if ln_u is not None:          # consumer of a folded LayerNorm (fold_layernorm_linear + layernorm_fold): sum_k W'[n, k]
+        assert ln_u.dtype == torch.float32 and ln_u.is_contiguous() and ln_u.numel() == N
+        l.keep[0].ln_u = _p(ln_u)
+        l.keep = tuple(l.keep) + (ln_u,)
+    return l
 
 
 def conv2d(x, W, out, bias=None, *, ksize=3, stride=1, pad=(1, 1), ups=0, x2=None, residual=None, rowvec=None,
@@ -453,6 +459,68 @@ def gemm_plan(launch):
     bm, bn, sk = C.c_int32(0), C.c_int32(0), C.c_int32(0)
     _lib.check(lib.rf_conv_gemm_plan(C.byref(launch.keep[0]), C.byref(bm), C.byref(bn), C.byref(sk)), launch.name + ".plan")
     return bm.value, bn.value, sk.value
+
+
+def gemm_plan2(launch):
+    """The whole tile plan of a prepared rf_conv_gemm launch: dict(stat_rows, stat_cols, splitk, bm, bn, wave_cols, direct, frag); raises
+    RefaceHipError when the library rejects the descriptor (e.g. LayerNorm folding asked of a launch that cannot carry it)."""
+    lib = _lib.load()
+    info = (C.c_int32 * 8)()
+    _lib.check(lib.rf_conv_gemm_plan2(C.byref(launch.keep[0]), info), launch.name + ".plan2")
+    return dict(zip(("stat_rows", "stat_cols", "splitk", "bm", "bn", "wave_cols", "direct", "frag"), (int(v) for v in info)))
+
+
+def fold_layernorm_linear(w, gamma, beta, bias, dtype):
+    """LayerNorm folded into the Linear behind it, the consumer half of rf_conv_gemm's ln_* fields:
+        (xhat * gamma + beta) W^T + b  =  rstd (x W'^T - mean u) + b'      with  W' = W diag(gamma),  u[n] = sum_k W'[n, k],  b' = b + W beta.
+    w [N, C] fp32 (any row packing -- the fold is per column), gamma / beta [C], bias [N] or None -> (W' in `dtype`, u fp32 [N] summed over the
+    ROUNDED W' so that the mean's term cancels exactly what the matrix pipe accumulates, b' fp32 [N])."""
+    wf = w.float()
+    w2 = (wf * gamma.float()[None, :]).to(dtype).contiguous()
+    u = w2.float().sum(dim=1).contiguous()
+    b2 = wf @ beta.float()
+    if bias is not None:
+        b2 = b2 + bias.float()
+    return w2, u, b2.contiguous()
+
+
+def layernorm_fold(producers, consumer, *, eps, C_):
+    """Wire LayerNorm statistics from the producer GEMM(s) of a [M, C] tensor into the consumer GEMM that multiplies its normalised form.
+    producers: [(launch, row0, rows)] prepared rf_conv_gemm launches that write rows [row0, row0 + rows) (all C columns each); consumer: the
+    prepared launch whose A operand is that tensor (weights / bias / ln_u already folded: set_layernorm_consumer).  Returns the statistics
+    tensor [M, parts, 2], or None (producers untouched; the consumer, whose weights assume the fold, is then to be discarded) when some launch
+    cannot carry its half -- the caller keeps the rf_layernorm pass."""
+    cd = consumer.keep[0]
+    M = cd.M
+    plans = []
+    for l, row0, rows in producers:
+        d = l.keep[0]
+        if l.fn.__name__ != "rf_conv_gemm" or d.N != C_ or d.act != ACT_NONE or d.M != rows:
+            return None
+        pl = gemm_plan2(l)
+        if not pl["direct"] or pl["splitk"] != 1 or C_ % pl["wave_cols"]:
+            return None
+        plans.append(pl["wave_cols"])
+    if len(set(plans)) != 1 or sum(r for _, _, r in producers) != M:
+        return None
+    wc = plans[0]
+    parts = C_ // wc
+    stats = torch.zeros((M, parts, 2), dtype=torch.float32, device=consumer.keep[1].device)
+    try:
+        for l, row0, rows in producers:
+            d = l.keep[0]
+            d.ln_stats_out, d.ln_out_parts = stats[row0:].data_ptr(), parts
+            gemm_plan2(l)                       # the library checks the producer half
+        cd.ln_stats_in, cd.ln_in_parts, cd.ln_in_cols, cd.ln_eps = stats.data_ptr(), parts, wc, float(eps)
+        gemm_plan2(consumer)                    # ... and the consumer half
+    except _lib.RefaceHipError:
+        for l, _, _ in producers:               # producers back to plain launches; the (folded-weight) consumer is the caller's to discard
+            l.keep[0].ln_stats_out, l.keep[0].ln_out_parts = None, 0
+        return None
+    for l, _, _ in producers:
+        l.keep = tuple(l.keep) + (stats,)
+    consumer.keep = tuple(consumer.keep) + (stats,)
+    return stats
 
 
 def fuse_groupnorm_stats(x, producers):

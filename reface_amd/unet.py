@@ -107,6 +107,8 @@ class UNetEngine:
         self.ffn_fuse = os.environ.get("REFACE_FFN_FUSE", "1") == "1"
         # norm3 inside the fused feed-forward kernel (C = 320 blocks): REFACE_LN_FOLD=0 keeps the separate LayerNorm pass
         self.ln_fold = os.environ.get("REFACE_LN_FOLD", "1") == "1"
+        # norm1 / norm3 folded around their neighbour GEMMs (producer statistics + consumer epilogue affine; bf16 mode): REFACE_LN_FOLD_GEMM=0 off
+        self.ln_fold_gemm = os.environ.get("REFACE_LN_FOLD_GEMM", "1") == "1"
         self.n_ln_folded = 0
         self.n_cu = torch.cuda.get_device_properties(device).multi_processor_count if torch.cuda.is_available() else 256
         self.gn_fused = 0
@@ -353,17 +355,29 @@ class UNetEngine:
         g = self._gn(x, f"{p}.norm", 1e-6, False, fp8=a8)
         tok = self.pool.get((M, c), self.dt)
         w_pi = self.sd[f"{p}.proj_in.weight"].reshape(c, c)
-        self.main.append(ops.linear(g.view(M, c), self.gw8(w_pi, 1, c) if a8 else self.gw(w_pi), tok, self.f32(f"{p}.proj_in.bias"),
-                                    name=f"{p}.proj_in"))
+        l_pi = ops.linear(g.view(M, c), self.gw8(w_pi, 1, c) if a8 else self.gw(w_pi), tok, self.f32(f"{p}.proj_in.bias"), name=f"{p}.proj_in")
+        self.main.append(l_pi)
         (self.aput if a8 else self.pool.put)(g)
         ln = self.aget((M, c)) if a8 else self.pool.get((M, c), self.dt)
-        self.main.append(ops.layernorm(tok, self.f32(f"{t}.norm1.weight"), self.f32(f"{t}.norm1.bias"), ln, name=f"{t}.norm1"))
         qkv = self.pool.get((M, 3 * c), self.dt)
         # to_q carries d^-0.5 * log2(e): the scores reach the attention kernels in the exp2 domain (scale = ln 2 below) -- the product
         # is rounded to the storage type once, as a weight, instead of the kernel re-rounding q * scale
         wqkv = torch.cat([self.sd[f"{t}.attn1.to_q.weight"].float() * (d ** -0.5 * ops.LOG2E), self.sd[f"{t}.attn1.to_k.weight"].float(),
                           self.sd[f"{t}.attn1.to_v.weight"].float()], 0)
-        self.main.append(ops.linear(ln, self.gw8(wqkv, 1, c) if a8 else self.gw(wqkv), qkv, None, name=f"{t}.attn1.qkv"))
+        # norm1 folded around the two GEMMs (bf16 mode): proj_in's epilogue leaves per-row (mean, M2) records, the qkv GEMM reads the
+        # UN-normalised tokens and applies  rstd (acc - mean u) + W beta  in its epilogue; gamma rides in the weights' columns -- the
+        # rf_layernorm pass (one read + one write of [M, C]) and its launch are gone
+        l_qkv = None
+        if self.ln_fold_gemm and self.dt == torch.bfloat16 and not self.w8:
+            w2, u2, b2 = ops.fold_layernorm_linear(wqkv, self.sd[f"{t}.norm1.weight"], self.sd[f"{t}.norm1.bias"], None, self.dt)
+            cand = ops.linear(tok, w2, qkv, b2, ln_u=u2, name=f"{t}.attn1.qkv")
+            if ops.layernorm_fold([(l_pi, 0, M)], cand, eps=1e-5, C_=c) is not None:
+                l_qkv = cand
+                self.n_ln_folded += 1
+        if l_qkv is None:
+            self.main.append(ops.layernorm(tok, self.f32(f"{t}.norm1.weight"), self.f32(f"{t}.norm1.bias"), ln, name=f"{t}.norm1"))
+            l_qkv = ops.linear(ln, self.gw8(wqkv, 1, c) if a8 else self.gw(wqkv), qkv, None, name=f"{t}.attn1.qkv")
+        self.main.append(l_qkv)
         if a8:
             self.aput(ln)
             ln = self.pool.get((M, c), self.dt)
@@ -375,9 +389,11 @@ class UNetEngine:
         # attn1 out-projection + residual + the (token-independent) cross-attention output; with pair=True one launch per CFG
         # half: same A and residual, that half's context vectors
         w_out, b_out, cv = self.gw(self.sd[f"{t}.attn1.to_out.0.weight"]), self.f32(f"{t}.attn1.to_out.0.bias"), self.ctx_vec(p)
+        l_out = []
         for hf in range(nb):
-            self.main.append(ops.linear(att, w_out, x1[hf * M:(hf + 1) * M], b_out, residual=tok, rowvec=cv[hf * B:(hf + 1) * B],
-                                        rows_per_sample=H * W, name=f"{t}.attn1.to_out"))
+            l_out.append(ops.linear(att, w_out, x1[hf * M:(hf + 1) * M], b_out, residual=tok, rowvec=cv[hf * B:(hf + 1) * B],
+                                    rows_per_sample=H * W, name=f"{t}.attn1.to_out"))
+        self.main += l_out
         self.pool.put(qkv)
         self.pool.put(tok)
         if pair or a8:
@@ -396,10 +412,30 @@ class UNetEngine:
             self.pool.put(ln)
             w1s, b1s = ops.fold_layernorm_geglu(w1s, b1s, self.sd[f"{t}.norm3.weight"], self.sd[f"{t}.norm3.bias"])
             self.n_ln_folded += 1
-        else:
+        l_geglu_f = None
+        if not fold and self.ln_fold_gemm and self.dt == torch.bfloat16 and not self.w8:
+            # norm3 of the unfused feed-forward (C = 640 / 1280, and C = 320 where the fused kernel is not taken): the statistics come from the
+            # to_out launch(es) that wrote x1, the GEGLU GEMM reads x1 itself and normalises in its epilogue
+            wgp, bgp = ops.pack_geglu(w1s, b1s, F32)          # (the fold is per input column: it commutes with the row packing)
+            w2, u2, b2 = ops.fold_layernorm_linear(wgp, self.sd[f"{t}.norm3.weight"], self.sd[f"{t}.norm3.bias"], None, self.dt)
+            b2 = (b2 + bgp).contiguous()
+            ggc = self.pool.get((nb * M, 4 * c), self.dt)
+            cand = ops.linear(x1, w2, ggc, b2, act=ops.ACT_GEGLU, ln_u=u2, name=f"{t}.ff.net.0")
+            if ops.layernorm_fold([(l, hf * M, M) for hf, l in enumerate(l_out)], cand, eps=1e-5, C_=c) is not None:
+                l_geglu_f = (cand, ggc)
+                self.n_ln_folded += 1
+            else:
+                self.pool.put(ggc)
+        if not fold and l_geglu_f is None:
             self.main.append(ops.layernorm(x1, self.f32(f"{t}.norm3.weight"), self.f32(f"{t}.norm3.bias"), ln, name=f"{t}.norm3"))
         wg, bg = ops.pack_geglu(w1s, b1s, F32)
-        if fused_ffn:
+        if l_geglu_f is not None:
+            l_g, gg = l_geglu_f
+            self.main.append(l_g)
+            x2 = ln
+            self.main.append(ops.linear(gg, self.gw(self.sd[f"{t}.ff.net.2.weight"]), x2, self.f32(f"{t}.ff.net.2.bias"), residual=x1, name=f"{t}.ff.net.2"))
+            self.pool.put(gg)
+        elif fused_ffn:
             # one kernel: the [M, 4C] hidden tensor (168 MB at 64x64) stays in registers (csrc/ffn.hip)
             x2 = self.pool.get((nb * M, c), self.dt)
             self.main.append(ops.ffn_geglu(x1 if fold else ln, wg.to(self.dt).contiguous(), bg, ops.pack_ffn_w2(self.sd[f"{t}.ff.net.2.weight"], self.dt),

@@ -254,7 +254,7 @@ def test_unet_fp8_c4_engine_shape_matches_oracle_rows(full_unet, mode):
     else:
         n_a8 = sum(1 for l in eng.main if l.fn.__name__ == "rf_conv_gemm" and l.keep[0].dtype == 2)
         if mode == "fp8c":          # ("fp8c": the 3x3 convolutions only -- 44 ResBlock convs + 6 resampling convs; every projection is a bf16 launch)
-            assert n_a8 == 50 and eng.n_a8 == n_a8 and eng.n_ln_folded == 5, (n_a8, eng.n_a8, eng.n_ln_folded)
+            assert n_a8 == 50 and eng.n_a8 == n_a8 and eng.n_ln_folded >= 5, (n_a8, eng.n_a8, eng.n_ln_folded)
         else:
             assert n_a8 >= 85 and eng.n_a8 == n_a8, (n_a8, eng.n_a8)          # 44 ResBlock convs + 16 x (proj_in, qkv, GEGLU), stem shared
     del eng

@@ -615,6 +615,65 @@ def test_ffn_geglu_fused_with_layernorm(M):
     assert d <= 2.0 ** -5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,K0,Cc,N,geglu,res", [(4096, 320, 320, 960, False, False), (65536, 320, 320, 960, False, True), (16384, 640, 640, 5120, True, True),
+                                                  (4096, 1280, 1280, 3840, False, True), (1000, 320, 320, 640, True, False)])
+def test_layernorm_folded_around_gemms(M, K0, Cc, N, geglu, res):
+    """LayerNorm folded around two bf16 GEMMs (rf_conv_gemm_desc.ln_*; attention.py:231-243 norm1 -> to_q/k/v, norm3 -> ff.net.0): the producer's
+    direct epilogue writes per-row (mean, M2) records per wave-tile stripe, the consumer multiplies the UN-normalised tensor by W diag(gamma)
+    and applies rstd (acc - mean u) + (b + W beta) in its epilogue.  Against fp32 torch on the stored producer output, and against the
+    unfolded chain on the GPU (rf_layernorm pass + plain GEMM): a few bf16 ulps (the normalised operand is never rounded in the folded form)."""
+    dt = torch.bfloat16
+    x0, _ = q(rnd((M, K0), 190) * 0.8, dt)
+    wp = rnd((Cc, K0), 191) / math.sqrt(K0)
+    bp = rnd((Cc,), 192) * 0.5 + 0.3                        # rows with a mean
+    r0, _ = q(rnd((M, Cc), 193), dt)
+    gamma, beta = rnd((Cc,), 194) * 0.3 + 1.0, rnd((Cc,), 195) * 0.2
+    w = rnd((N, Cc), 196) / math.sqrt(Cc)
+    b = rnd((N,), 197) * 0.3
+    y = torch.empty((M, Cc), dtype=dt, device=DEV)
+    l_prod = ops.linear(x0, wp.to(dt).to(DEV), y, bp.to(DEV), residual=r0 if res else None, name="producer")
+    act = ops.ACT_GEGLU if geglu else ops.ACT_NONE
+    if geglu:
+        wpk, bpk = ops.pack_geglu(w, b, torch.float32)
+    else:
+        wpk, bpk = w, b
+    w2, u2, b2 = ops.fold_layernorm_linear(wpk, gamma, beta, bpk, dt)
+    out = torch.empty((M, N // 2 if geglu else N), dtype=dt, device=DEV)
+    cons = ops.linear(y, w2.to(DEV), out, b2.to(DEV), act=act, ln_u=u2.to(DEV), name="consumer")
+    stats = ops.layernorm_fold([(l_prod, 0, M)], cons, eps=1e-5, C_=Cc)
+    pl = ops.gemm_plan2(l_prod)
+    if stats is None:
+        assert not pl["direct"] or pl["splitk"] != 1 or Cc % pl["wave_cols"], pl
+        pytest.skip(f"this producer plan cannot carry the statistics: {pl}")
+    assert stats.shape == (M, Cc // pl["wave_cols"], 2)
+    l_prod()
+    cons()
+    # unfolded chain on the GPU: LayerNorm pass + plain GEMM on its bf16 output
+    ln = torch.empty_like(y)
+    ops.layernorm(y, gamma.to(DEV), beta.to(DEV), ln)()
+    out_u = torch.empty_like(out)
+    ops.linear(ln, wpk.to(dt).to(DEV), out_u, bpk.to(DEV), act=act)()
+    torch.cuda.synchronize()
+    yf = y.float().cpu()
+    # the records: mean / M2 of the stored row values per stripe
+    wc = pl["wave_cols"]
+    ys = yf.reshape(M, Cc // wc, wc)
+    assert (stats[..., 0].cpu() - ys.mean(-1)).abs().max().item() < 1e-4
+    m2 = ((ys - ys.mean(-1, keepdim=True)) ** 2).sum(-1)
+    assert ((stats[..., 1].cpu() - m2).abs() / (m2 + 1.0)).max().item() < 1e-4
+    h = F.linear(F.layer_norm(yf, (Cc,), gamma, beta, 1e-5), w, b)
+    if geglu:
+        a, g = h.chunk(2, -1)
+        ref = a * F.gelu(g, approximate="tanh")
+    else:
+        ref = h
+    check(out, ref, dt)
+    dmax = (out.float() - out_u.float()).abs().max().item()
+    print(f"LayerNorm fold M={M} C={Cc} N={N} geglu={geglu}: folded vs LayerNorm pass + GEMM max |d| = {dmax:.3e} (|out| max {ref.abs().max().item():.2f}), "
+          f"producer tile {pl['bm']}x{pl['bn']} stripe {wc}")
+    assert dmax <= 2.0 ** -5 * max(1.0, ref.abs().max().item())
+
+
 # ------------------------------------------------------------------------------------------------ split-bf16 (RF_BF16X3) operands
 def _split_ref(x):
     """(hi, lo) bf16 pair of an fp32 tensor, as rf_split_bf16 / rf_groupnorm_apply(out_dtype = RF_BF16X3) define it."""
