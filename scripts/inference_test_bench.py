@@ -61,7 +61,7 @@ def build_parser():
     p.add_argument("--ckpt", type=str, default="models/REFace/checkpoints/last.ckpt")
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--rank", type=int, default=0)
-    p.add_argument("--precision", type=str, choices=["full", "fullx3", "autocast", "bf16", "fp8"], default="full")
+    p.add_argument("--precision", type=str, choices=["full", "fullx3", "autocast", "bf16", "fp8", "fp8c"], default="full")
     # additions (not in the reference)
     p.add_argument("--n_items", type=int, default=8, help="number of synthetic pairs (--dataset synthetic)")
     p.add_argument("--dump_tensors", type=str, default=None, help="directory for per-batch .npz dumps of the tensors fed to / produced by the engines (tests)")
@@ -121,8 +121,8 @@ def main(argv=None):
     model = model.to(device)
     if opt.precision in ("autocast", "bf16"):
         model.set_compute_dtype(torch.bfloat16, encoders=True)
-    elif opt.precision == "fp8":                    # BASELINE configs[4]: fp8 (e4m3fn) UNet GEMM weights, bf16 activations
-        model.set_compute_dtype("fp8", encoders=True)
+    elif opt.precision in ("fp8", "fp8c"):          # BASELINE configs[4]: fp8 x fp8 UNet GEMMs ("fp8c": the 3x3 convolutions only, bf16 projections -- 8 dB closer to fp32)
+        model.set_compute_dtype(opt.precision, encoders=True)
     elif opt.precision == "fullx3":                 # the fast form of "full": fp32 storage, split-bf16 GEMM operands (3 bf16 MFMA passes)
         model.set_compute_dtype("f32x3")
     if world > 1:

@@ -249,7 +249,7 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     # configs: the metric label follows the workload
-    assert bench.CONFIGS["c3"]["latent"] == 96 and bench.CONFIGS["c3"]["batch"] == 4 and bench.CONFIGS["c4"]["dtype"] == "fp8"
+    assert bench.CONFIGS["c3"]["latent"] == 96 and bench.CONFIGS["c3"]["batch"] == 4 and bench.CONFIGS["c4"]["dtype"] in ("fp8", "fp8c")
 
 
 def test_output_tree_composition():

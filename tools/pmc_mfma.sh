@@ -6,7 +6,7 @@
 tag=$1
 cfg=${2:-c1}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-CMD="python3 bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-conditioning --no-parity"
+CMD="python3 bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-conditioning --no-parity --no-other-configs"
 REFACE_NO_GRAPH=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES --output-format csv -d gpurun_out/${tag}_pmc_mfma -- $CMD > gpurun_out/${tag}_pmc_mfma.log 2>&1
 REFACE_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_kt_mfma -- $CMD > gpurun_out/${tag}_kt_mfma.log 2>&1
 python3 - <<PY

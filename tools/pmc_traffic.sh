@@ -5,7 +5,7 @@ tag=$1
 cfg=${2:-c1}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  REFACE_NO_GRAPH=1 rocprofv3 --pmc $c --output-format csv -d gpurun_out/${tag}_pmc_$c -- python3 bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-conditioning --no-parity > gpurun_out/${tag}_pmc_$c.log 2>&1
+  REFACE_NO_GRAPH=1 rocprofv3 --pmc $c --output-format csv -d gpurun_out/${tag}_pmc_$c -- python3 bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-conditioning --no-parity --no-other-configs > gpurun_out/${tag}_pmc_$c.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, json, re

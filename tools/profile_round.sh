@@ -5,7 +5,7 @@
 tag=$1; cfg=${2:-c1}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_${cfg}_rocprof -- python3 bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-conditioning --no-parity > gpurun_out/${tag}_${cfg}_bench_under_rocprof.json 2> gpurun_out/${tag}_${cfg}_rocprof.log
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_${cfg}_rocprof -- python3 bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-conditioning --no-parity --no-other-configs > gpurun_out/${tag}_${cfg}_bench_under_rocprof.json 2> gpurun_out/${tag}_${cfg}_rocprof.log
 cp $(ls gpurun_out/${tag}_${cfg}_rocprof/*/*kernel_stats.csv | head -1) gpurun_out/${tag}_${cfg}_rocprofv3_kernel_stats.csv
 head -8 gpurun_out/${tag}_${cfg}_rocprofv3_kernel_stats.csv | cut -c1-150
 rm -rf gpurun_out/${tag}_${cfg}_rocprof
