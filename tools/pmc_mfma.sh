@@ -6,7 +6,7 @@
 tag=$1
 cfg=${2:-c1}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-CMD="python3 bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-conditioning --no-parity --no-other-configs"
+CMD="python3 bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-conditioning --no-parity --no-other-configs $EXTRA"
 REFACE_NO_GRAPH=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES --output-format csv -d gpurun_out/${tag}_pmc_mfma -- $CMD > gpurun_out/${tag}_pmc_mfma.log 2>&1
 REFACE_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_kt_mfma -- $CMD > gpurun_out/${tag}_kt_mfma.log 2>&1
 python3 - <<PY
@@ -41,7 +41,7 @@ import sys
 sys.path.insert(0, ".")
 import bench
 c = bench.CONFIGS["$cfg"]
-out["_meta"] = {"lib_digest": bench.lib_digest(), "workload": "$cfg:%dx%d:S50:B%d:%s" % (8 * c["latent"], 8 * c["latent"], c["batch"], c["dtype"]),
+out["_meta"] = {"lib_digest": bench.lib_digest(), "workload": "$cfg:%dx%d:S50:B%d:%s" % (8 * c["latent"], 8 * c["latent"], c["batch"], ("$EXTRA".split("--dtype ")[1].split()[0] if "--dtype " in "$EXTRA" else c["dtype"])),
                 "command": "tools/pmc_mfma.sh ${tag} $cfg (REFACE_NO_GRAPH=1, one batch of eager launches; counters and durations from two passes of the same command)",
                 "note": "a v_mfma_f32_32x32x16_bf16 keeps the pipe busy for 32 cycles; busy_frac = busy cycles / (duration x 2.4 GHz x 1024 SIMDs); fp32 families are the VAE decode"}
 json.dump(out, open("gpurun_out/${tag}_mfma_busy.json", "w"), indent=1)

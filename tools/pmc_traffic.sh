@@ -5,7 +5,7 @@ tag=$1
 cfg=${2:-c1}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  REFACE_NO_GRAPH=1 rocprofv3 --pmc $c --output-format csv -d gpurun_out/${tag}_pmc_$c -- python3 bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-conditioning --no-parity --no-other-configs > gpurun_out/${tag}_pmc_$c.log 2>&1
+  REFACE_NO_GRAPH=1 rocprofv3 --pmc $c --output-format csv -d gpurun_out/${tag}_pmc_$c -- python3 bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-conditioning --no-parity --no-other-configs $EXTRA > gpurun_out/${tag}_pmc_$c.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, json, re
@@ -36,7 +36,7 @@ sys.path.insert(0, ".")
 import bench
 c = bench.CONFIGS["$cfg"]
 import time
-out["_meta"] = {"collected_unix": time.time(), "lib_digest": bench.lib_digest(), "workload": "$cfg:%dx%d:S50:B%d:%s" % (8 * c["latent"], 8 * c["latent"], c["batch"], c["dtype"]),
+out["_meta"] = {"collected_unix": time.time(), "lib_digest": bench.lib_digest(), "workload": "$cfg:%dx%d:S50:B%d:%s" % (8 * c["latent"], 8 * c["latent"], c["batch"], ("$EXTRA".split("--dtype ")[1].split()[0] if "--dtype " in "$EXTRA" else c["dtype"])),
                 "command": "tools/pmc_traffic.sh ${tag} $cfg (REFACE_NO_GRAPH=1, --steps 1 --warmup 0: one batch of eager launches per PMC pass)"}
 json.dump(out, open("gpurun_out/${tag}_traffic.json", "w"), indent=1)
 for k, v in sorted(((k, v) for k, v in out.items() if k != "_meta"), key=lambda kv: -kv[1].get("FETCH_SIZE_KB_raw_total", 0)):
