@@ -16,7 +16,7 @@ def fam(n):
     m = re.search(r"conv_gemm_kernel<(unsigned short|float), (unsigned short|float)", n)
     if m:
         if m.group(1) == "unsigned short" and m.group(2) == "float": return "rf_conv_gemm[bf16x3]"      # bf16 operands, fp32 out: the split-bf16 VAE convs (+ the UNet's 4-channel out conv)
-        if re.search(r", true>\(", n): return "rf_conv_gemm[fp8w]"
+        if re.search(r", true, \d+>\(", n): return "rf_conv_gemm[fp8w]"          # template arguments end with ..., W8, LNF
         return "rf_conv_gemm[%s]" % ("bf16" if m.group(1) == "unsigned short" else "f32")
     m = re.search(r"rf::(\w+?)_kernel", n)
     return "rf_" + m.group(1) if m else "other"
