@@ -539,9 +539,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
                 if (q >= q0 && q < q1) {
-                    if (q < AV)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(a + q * (RPP * 128)), 16, offs[q], soA, 0, 0);
-                    else
+                    if (q < AV) {
+                        // (RF_GEMM_DBG bit 8, timing only: the A pieces of two K tiles out of three are not issued -- the fill a row-extended A
+                        //  tile shared by the three horizontal taps of a 3x3 window would need; stale operands, wrong results)
+                        if (!(RF_DBG(p, 256) && CONV && p.KW == 3 && p.stride == 1 && !p.ups && (it % 3) != 0))
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(a + q * (RPP * 128)), 16, offs[q], soA, 0, 0);
+                    } else
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(b + (q - AV) * (RPP * 128)), 16, offs[q], soB, 0, 0);
                 }
             }

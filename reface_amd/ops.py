@@ -516,6 +516,7 @@ def layernorm_fold(producers, consumer, *, eps, C_):
     except _lib.RefaceHipError:
         for l, _, _ in producers:               # producers back to plain launches; the (folded-weight) consumer is the caller's to discard
             l.keep[0].ln_stats_out, l.keep[0].ln_out_parts = None, 0
+        cd.ln_stats_in, cd.ln_in_parts, cd.ln_in_cols, cd.ln_eps = None, 0, 0, 0.0
         return None
     for l, _, _ in producers:
         l.keep = tuple(l.keep) + (stats,)

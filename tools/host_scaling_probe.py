@@ -21,18 +21,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def make_tree(root, n):
+def photo_like(rng, h, w):
+    """A smooth image with photographic statistics for the codecs (low-frequency structure + a little sensor noise): what JPEG / PNG see on
+    face photographs, against uniform noise, their worst case."""
+    import numpy as np
+    from PIL import Image
+    base = Image.fromarray(rng.integers(0, 256, (h // 32, w // 32, 3), dtype=np.uint8)).resize((w, h), Image.BICUBIC)
+    a = np.asarray(base, dtype=np.int16) + rng.integers(-3, 4, (h, w, 3), dtype=np.int16)
+    return np.clip(a, 0, 255).astype(np.uint8)
+
+
+def make_tree(root, n, natural=False):
     import numpy as np
     from PIL import Image
     os.makedirs(os.path.join(root, "CelebA-HQ-img"), exist_ok=True)
     os.makedirs(os.path.join(root, "CelebA-HQ-mask", "Overall_mask"), exist_ok=True)
     rng = np.random.default_rng(0)
     for i in list(range(28000, 28000 + n)) + list(range(29000, 29000 + n)):
-        Image.fromarray(rng.integers(0, 256, (1024, 1024, 3), dtype=np.uint8)).save(os.path.join(root, "CelebA-HQ-img", f"{i}.jpg"), quality=90)
-        Image.fromarray(rng.integers(0, 19, (512, 512), dtype=np.uint8)).save(os.path.join(root, "CelebA-HQ-mask", "Overall_mask", f"{i}.png"))
+        img = photo_like(rng, 1024, 1024) if natural else rng.integers(0, 256, (1024, 1024, 3), dtype=np.uint8)
+        Image.fromarray(img).save(os.path.join(root, "CelebA-HQ-img", f"{i}.jpg"), quality=90)
+        lab = np.repeat(np.repeat(rng.integers(0, 19, (16, 16), dtype=np.uint8), 32, 0), 32, 1) if natural else rng.integers(0, 19, (512, 512), dtype=np.uint8)
+        Image.fromarray(lab).save(os.path.join(root, "CelebA-HQ-mask", "Overall_mask", f"{i}.png"))
 
 
-def worker(tree, outdir, batches, device_ms, B=8, legacy=False, world=1, png_level=None, gpu_prep=False):
+def worker(tree, outdir, batches, device_ms, B=8, legacy=False, world=1, png_level=None, gpu_prep=False, natural=False):
     import numpy as np
     import torch
     from reface_amd import output as O
@@ -50,6 +62,11 @@ def worker(tree, outdir, batches, device_ms, B=8, legacy=False, world=1, png_lev
     nbytes, _ = O.record_layout(512, 512)
     rng = np.random.default_rng(0)
     pool_u8 = rng.integers(0, 256, (B, nbytes), dtype=np.uint8)              # stand-in for the D2H'd records (noise: zlib's worst case)
+    if natural:                                                              # ... or photo-like panels and grid
+        _, lay = O.record_layout(512, 512)
+        for i in range(B):
+            for k, (off, shp) in lay.items():
+                pool_u8[i, off:off + int(np.prod(shp))] = photo_like(rng, (shp[0] + 31) // 32 * 32, (shp[1] + 31) // 32 * 32)[:shp[0], :shp[1]].reshape(-1)
     pool_f = rng.random((2, B, 3, 512, 512), dtype=np.float32)
     t0 = time.perf_counter()
     host_ms = []
@@ -86,18 +103,19 @@ def main():
     ap.add_argument("--worker", nargs=2, default=None)
     ap.add_argument("--legacy", action="store_true", help="the round-3 host half: fp32 panels composed on the host, 8 PNG workers per process")
     ap.add_argument("--world", type=int, default=1, help="(worker) processes sharing the host")
+    ap.add_argument("--natural", action="store_true", help="photo-like images in and out (smooth content + sensor noise) instead of uniform noise, the codecs' worst case")
     ap.add_argument("--gpu-prep", action="store_true", help="readers hand over uint8 arrays only (the CLI's --gpu_prep)")
     ap.add_argument("--png-level", type=int, default=None, help="zlib level of the PNG files (default: PIL's 6, the reference's files)")
     a = ap.parse_args()
     if a.worker:
-        worker(a.worker[0], a.worker[1], a.batches, a.device_ms, legacy=a.legacy, world=a.world, png_level=a.png_level, gpu_prep=a.gpu_prep)
+        worker(a.worker[0], a.worker[1], a.batches, a.device_ms, legacy=a.legacy, world=a.world, png_level=a.png_level, gpu_prep=a.gpu_prep, natural=a.natural)
         return
     with tempfile.TemporaryDirectory() as tmp:
         tree = os.path.join(tmp, "CelebAMask-HQ")
-        make_tree(tree, a.batches * 8)
+        make_tree(tree, a.batches * 8, natural=a.natural)
         out = {}
         for n in (1, a.procs):
-            extra = (["--legacy"] if a.legacy else []) + (["--png-level", str(a.png_level)] if a.png_level is not None else []) + (["--gpu-prep"] if a.gpu_prep else [])
+            extra = (["--legacy"] if a.legacy else []) + (["--png-level", str(a.png_level)] if a.png_level is not None else []) + (["--gpu-prep"] if a.gpu_prep else []) + (["--natural"] if a.natural else [])
             ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", tree, os.path.join(tmp, f"out_{n}_{r}"), "--batches", str(a.batches),
                                     "--device-ms", str(a.device_ms), "--world", str(n)] + extra, stdout=subprocess.PIPE, text=True) for r in range(n)]
             rs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in ps]
@@ -107,6 +125,7 @@ def main():
         out["host_half"] = "round 3 (fp32 panels composed on the host, 8 PNG workers)" if a.legacy else \
             f"round 4 (packed uint8 records from the device, PNG workers = share of the host, zlib level {a.png_level if a.png_level is not None else 6}" + \
             (", readers decode / resize only: --gpu_prep)" if a.gpu_prep else ")")
+        out["content"] = "photo-like (smooth + sensor noise)" if a.natural else "uniform noise (worst case of JPEG decode and zlib)"
         out["device_ms_assumed"] = a.device_ms
         out["verdict"] = ("host half hides under the device time in all %d processes" % a.procs
                           if out[a.procs]["ms_per_batch_max"] < 1.05 * max(a.device_ms, out[1]["ms_per_batch_max"]) else
