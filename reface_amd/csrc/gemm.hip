@@ -197,9 +197,15 @@ __device__ __forceinline__ void halfwave_reduce_scatter32(float (&gx)[32], int l
 // (issued between the MFMAs of the previous fragment column).  The MFMA itself is the bf16 one: same matrix-core ceiling.
 // LNF: LayerNorm role of the launch (rf_conv_gemm_desc.ln_*), a compile-time variant of the direct epilogue so that ordinary launches carry none
 // of its registers: 0 none, 1 producer (row statistics of the stored output), 2 consumer (row affine; such launches have no residual)
-template <typename T, typename TO, int WM, int WN, int TM, int TN, bool CONV, bool GLDS, int NST, int EPI = 0, bool W8 = false, int LNF = 0>
+// HX (round 4): 3x3 stride-1 convolutions with the K order (filter row dy, channel chunk, filter column dx) -- rf_conv_gemm_desc.korder = 2.  The three
+// horizontal taps of one (dy, chunk) read the SAME image rows shifted by one pixel, so ONE row-extended A tile -- every image row of the output tile
+// with one halo pixel on each side, (BM / Wout) * (Wout + 2) rows of 128 bytes -- is staged per group of three K tiles instead of one BM-row tile per
+// K tile: a third of the A-operand fill (the per-CU operand fill is what caps these kernels).  Fragment reads address row  erow(pixel) + dx  of that
+// tile (the XOR swizzle follows the row), the W side and everything behind the main loop are unchanged.
+template <typename T, typename TO, int WM, int WN, int TM, int TN, bool CONV, bool GLDS, int NST, int EPI = 0, bool W8 = false, int LNF = 0, bool HX = false>
 __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams p) {
     static_assert(LNF == 0 || (EPI == 1 && !CONV && !W8 && sizeof(T) == 2 && sizeof(TO) == 2), "LayerNorm folding: bf16 linear layers on the direct epilogue");
+    static_assert(!HX || (CONV && GLDS && NST == 2 && sizeof(T) == 2 && !W8 && EPI != 2), "row-extended A tiles: bf16 3x3 convolutions on the two-stage direct-to-LDS loop");
     static_assert(EPI == 0 || GLDS, "the direct / packed epilogues are built on the direct-to-LDS main loop");
     static_assert(EPI != 2 || sizeof(TO) == 2, "the packed staged epilogue writes bf16");
     static_assert(!W8 || (GLDS && sizeof(T) == 2), "fp8 weights: bf16 activations on the direct-to-LDS main loop");
@@ -213,14 +219,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
     constexpr int VEC = elem<T>::VEC;
     constexpr int BK = 8 * VEC;          // elements of K per tile (128 bytes)
     constexpr int RPP = NT / 8;          // rows covered per staging pass
-    constexpr int AV = BM / RPP;         // A vectors per thread
+    constexpr int AXR = HX ? ((BM * 5 / 4 + RPP - 1) / RPP) * RPP : BM;      // rows of an A stage (HX: up to BM + 2 BM / Wout rows, Wout >= 8)
+    constexpr int AV = AXR / RPP;        // A vectors per thread
     constexpr int BV = BN / RPP;         // B vectors per thread
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/threads mismatch");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const ldsA = smem;                       // [2][BM][128]
-    char* const ldsB = smem + NST * BM * 128;      // [NST][BN][128]
-    char* const ldsS = smem + NST * (BM + BN) * 128;      // A8: [2][8 waves][64 rows] scale dwords (4 E8M0 bytes = the 4 blocks of a K tile)
+    char* const ldsA = smem;                       // [2][AXR][128]
+    char* const ldsB = smem + NST * AXR * 128;     // [NST][BN][128]
+    char* const ldsS = smem + NST * (AXR + BN) * 128;     // A8: [2][8 waves][64 rows] scale dwords (4 E8M0 bytes = the 4 blocks of a K tile)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
     int kb0_tiles = 0;       // first K tile of this block (split-K)
     if (p.splitk > 1) {          // this block's K-tile range [kb0, kb0 + nk)
         int per = (nk + p.splitk - 1) / p.splitk;
-        if (p.x3) per = (per + 2) / 3 * 3;
+        if (p.x3 || HX) per = (per + 2) / 3 * 3;          // whole groups of three tiles (split-bf16 passes / the three dx taps of an HX group)
         const int kb0 = blockIdx.z * per;
         nk = max(0, min(nk, kb0 + per) - kb0);
         kb0_tiles = kb0;
@@ -464,7 +471,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
             const int m = m0 + r0 + i * RPP;
-            if (CONV) {
+            if constexpr (HX) {
+                // row j of the row-extended tile = image row (m0 / Wout + j / (Wout + 2)) over all samples, column code xc = j % (Wout + 2)
+                // (input column xc - 1: the halo pixels are xc = 0 and xc = Wout + 1)
+                const int j = r0 + i * RPP, we = p.Wout + 2;
+                const int ir = j / we, xc = j - ir * we;
+                const int R = m0 / p.Wout + ir;                       // (host: BM % Wout == 0, so m0 is the first pixel of an image row)
+                const int b = R / p.Hout, oy = R - b * p.Hout;
+                rowd[i] = (ir < BM / p.Wout && R * p.Wout < p.M) ? ((unsigned)b << 20 | (unsigned)oy << 10 | (unsigned)xc) : ~0u;
+            } else if (CONV) {
                 const int hw = p.Hout * p.Wout;
                 const int b = m / hw, rem = m - b * hw;
                 const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
@@ -473,6 +488,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 offs[i] = m < p.M ? m * p.ld0 * (int)sizeof(T) + lane_k : OOB;
             }
         }
+        // HX: A-piece offsets of filter row dy (3x3, stride 1, pad 1: input row oy + dy - 1, input column xc - 1), once per dy
+        auto set_grp = [&](int dy) {
+#pragma unroll
+            for (int i = 0; i < AV; ++i) {
+                const unsigned d = rowd[i];
+                const int iy = (int)((d >> 10) & 1023u) + dy - 1, ix = (int)(d & 1023u) - 1;
+                const bool ok = d != ~0u && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                offs[i] = ok ? (((int)(d >> 20) * p.Hin + iy) * p.Win + ix) * p.ld0 * (int)sizeof(T) + lane_k : OOB;
+            }
+        };
         // A-piece offsets of filter tap (ty, tx): padding / upsampling / stride live here, once per tap
         auto set_tap = [&](int ty, int tx) {
 #pragma unroll
@@ -503,6 +528,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         const bool x3 = X3OK && p.x3;
         int it = kb0_tiles, ity = 0, itx = 0, ic = 0, ph = 0;
         int ia = x3 ? kb0_tiles / 3 : kb0_tiles;          // (split-K ranges of the split mode start on a multiple of 3)
+        int hx_dx = 0, hx_ist = 0;                         // HX issue state: filter column of tile `it`, A stage of its group
+        if constexpr (HX) {
+            const int grp = kb0_tiles / 3;                 // K order (dy, chunk, dx): group = dy * tpt + chunk
+            ity = grp / tpt;
+            ic = grp - ity * tpt;
+            set_grp(ity);
+        } else
         if (CONV) {
             const int ntap = p.KH * p.KW;
             const int tap = p.korder ? ia % ntap : ia / tpt;
@@ -513,6 +545,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         }
         auto next_tile = [&]() {     // advance the issue state by one K tile
             ++it;
+            if constexpr (HX) {
+                if (++hx_dx == 3) {
+                    hx_dx = 0;
+                    hx_ist ^= 1;
+                    if (++ic == tpt) { ic = 0; ++ity; set_grp(ity); }
+                }
+                return;
+            }
             if (X3OK && x3) {
                 if (++ph != 3) return;
                 ph = 0;
@@ -531,7 +571,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         };
         // issue pieces [q0, q1) of the issue-state tile into LDS stage `buf`
         auto issue_pieces = [&](int buf, int q0, int q1) {
-            char* a = ldsA + buf * BM * 128 + wave_u * 1024;
+            char* a = ldsA + (HX ? hx_ist : buf) * AXR * 128 + wave_u * 1024;          // (HX: the A stage belongs to the group of three tiles)
             char* b = ldsB + w_stage<W8>(it, buf) * BN * 128 + wave_u * 1024;
             const int soA = __builtin_amdgcn_readfirstlane((CONV ? ic : ia) * 128 + ((X3OK && ph == 2) ? p.lo_off : 0));
             const int soB = __builtin_amdgcn_readfirstlane(w_soff<W8>(it));
@@ -542,7 +582,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                     if (q < AV) {
                         // (RF_GEMM_DBG bit 8, timing only: the A pieces of two K tiles out of three are not issued -- the fill a row-extended A
                         //  tile shared by the three horizontal taps of a 3x3 window would need; stale operands, wrong results)
-                        if (!(RF_DBG(p, 256) && CONV && p.KW == 3 && p.stride == 1 && !p.ups && (it % 3) != 0))
+                        if (!(RF_DBG(p, 256) && CONV && p.KW == 3 && p.stride == 1 && !p.ups && (it % 3) != 0) && !(HX && hx_dx != 0))
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(a + q * (RPP * 128)), 16, offs[q], soA, 0, 0);
                     } else
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(b + (q - AV) * (RPP * 128)), 16, offs[q], soB, 0, 0);
@@ -699,6 +739,30 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         // The loop body is ONE straight-line block (no per-tile variants): branches around MFMAs make the register allocator
         // keep two copies of the accumulators.
         const char* curA = ldsA + (wm * TM) * 4096 + lrow * 128;
+        // HX: this lane's row of block i in the row-extended tile for filter column 0 (erow), the A row pointer / swizzle term of the tile being
+        // multiplied (hcb / hcs) and of the next one (hnb / hns), the filter column and A stage of the tile being multiplied
+        int erow[TM];
+        const char* hcb[TM];
+        const char* hnb[TM];
+        int hcs[TM], hns[TM], m_dx = 0, m_st = 0;
+        const int ks_[4] = {(0 + lhalf) << 4, (2 + lhalf) << 4, (4 + lhalf) << 4, (6 + lhalf) << 4};          // k-step kk -> 16-byte slot 2 kk + half
+        auto hx_set = [&](const char** hb, int* hs, int st, int dx) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int e = erow[i] + dx;
+                hb[i] = ldsA + st * (AXR * 128) + e * 128;
+                hs[i] = ((e >> 1) & 7) << 4;
+            }
+        };
+        if constexpr (HX) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int pm = (wm * TM + i) * 32 + lrow, ir = pm / p.Wout;
+                erow[i] = ir * (p.Wout + 2) + (pm - ir * p.Wout);
+            }
+            hx_set(hcb, hcs, 0, 0);
+            hx_set(hnb, hns, 0, 1);
+        }
         const char* const wbase = ldsB + (wn * TN) * 4096 + brow * 128;
         const char* curB = wbase + w_stage<W8>(kb0_tiles, 0) * BN * 128;
         const char* othA = curA + BM * 128;
@@ -747,7 +811,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 __builtin_amdgcn_s_barrier();
             }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[nx][i] = *(const u32x4_t*)(nA + i * 4096);
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (HX) fa[nx][i] = *(const u32x4_t*)((kk < 3 ? hcb[i] : hnb[i]) + (ks_[nkk] ^ (kk < 3 ? hcs[i] : hns[i])));
+                else fa[nx][i] = *(const u32x4_t*)(nA + i * 4096);
+            }
 #pragma unroll
             for (int j = 0; j < (ROT ? JS : TN); ++j) load_b(fbn, j, nB + j * 4096);
 #if !RF_SPREAD_DMA
@@ -828,13 +895,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 if constexpr (W8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile 1 may have had no W pieces: no fixed count
                 else if (RF_DBG(p, 128)) {}          // timing decomposition: the first tile is not waited for (upper bound of what a tile loop that
                                                       // issues the next tile's first pieces ahead of the epilogue could hide)
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HX ? BV : NP) : "memory");          // (HX: tile 1 -- filter column 1 -- has W pieces only)
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[0][i] = *(const u32x4_t*)(curA + i * 4096 + fk[0]);
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (HX) fa[0][i] = *(const u32x4_t*)(hcb[i] + (ks_[0] ^ hcs[i]));
+                else fa[0][i] = *(const u32x4_t*)(curA + i * 4096 + fk[0]);
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) load_b(0, j, curB + j * 4096 + (fkb[0] ^ curPar));
         }
@@ -888,6 +958,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             if (kt + 3 < nk) next_tile();
 #endif
             const char* t = curA; curA = othA; othA = t;
+            if constexpr (HX) {          // the tile multiplied next becomes current; its successor: next filter column, or column 0 of the next group's stage
+                if (++m_dx == 3) { m_dx = 0; m_st ^= 1; }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) { hcb[i] = hnb[i]; hcs[i] = hns[i]; }
+                hx_set(hnb, hns, m_dx == 2 ? (m_st ^ 1) : m_st, m_dx == 2 ? 0 : m_dx + 1);
+            }
             if constexpr (W8) {
                 ++t_abs;
                 curB = othB; curPar = othPar;
@@ -1850,6 +1926,11 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     constexpr bool A8 = std::is_same<T, fp8_t>::value;
     constexpr int smem_ml = NST * (BM + BN) * 128 + (A8 ? 4096 : 0), smem_ep = (BM / NCH) * BN * 4;
     constexpr int smem = smem_ml > smem_ep ? smem_ml : smem_ep;
+    // HX (row-extended A tiles for 3x3 stride-1 convolutions, korder 2): bf16 -> bf16 only; the stage of BM + BM / 4 rows must fit the 160 KB of LDS
+    constexpr int RPP_ = WM * WN * 8, AXR_ = ((BM * 5 / 4 + RPP_ - 1) / RPP_) * RPP_;
+    constexpr int smem_hx_ml = NST * (AXR_ + BN) * 128, smem_hx = smem_hx_ml > smem_ep ? smem_hx_ml : smem_ep;
+    constexpr bool HX_OK = std::is_same<T, bf16_t>::value && std::is_same<TO, bf16_t>::value && !W8 && !A8 && smem_hx <= 160 * 1024;
+    const bool hx = p.korder == 2;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     {
@@ -1891,6 +1972,9 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
                            (d->act == RF_ACT_NONE || (d->act == RF_ACT_GEGLU && TN % 2 == 0));
     static const int gn_direct = tune_env("RF_EPI_GN", 1);      // 0: fused statistics keep EPI 0
     const bool direct = DIRECT_OK && (epi_env < 0 || epi_env == 1) && ep_common && (p.gn_rows == 0 || (gn_direct && d->act == RF_ACT_NONE));
+    RF_CHECK(!hx || (HX_OK && conv && p.glds && p.KH == 3 && p.KW == 3 && p.stride == 1 && !p.ups && p.pad_t == 1 && p.pad_l == 1 && p.Hin == p.Hout &&
+                     p.Win == p.Wout && p.Wout >= 8 && BM % p.Wout == 0 && (BM / p.Wout) * (p.Wout + 2) <= AXR_ && epi_env != 2),
+             "rf_conv_gemm: korder 2 (row-extended A tiles) needs a bf16 3x3 stride-1 pad-1 convolution whose %d-row tile holds whole image rows (Wout = %d)", BM, p.Wout);
     // LayerNorm folding lives in the direct epilogue only (bf16 linear layers: the LNF variants of the kernel)
     constexpr bool LN_OK = DIRECT_OK && sizeof(T) == 2 && sizeof(TO) == 2 && !W8 && !A8;
     RF_CHECK(!(p.ln_out || p.ln_in) || (LN_OK && !conv),
@@ -1928,21 +2012,23 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     RF_CHECK(!p.oscale || direct, "rf_conv_gemm: fp8 output needs the direct epilogue (8-wave tile, aligned rows, no split-K)");
     constexpr int smem_pk = BM * BN * 2;
     const int smem_l = (packed && smem_pk > smem) ? smem_pk : smem;
-#define RF_LAUNCH_VARIANT_LN(CONV_, GLDS_, EPI_, LNF_)                                                                          \
+#define RF_LAUNCH_VARIANT_X(CONV_, GLDS_, EPI_, LNF_, HX_)                                                                      \
     {                                                                                                                            \
         constexpr int E_ = (EPI_ == 2 && PACKED_OK) ? 2 : ((EPI_ == 1 && DIRECT_OK) ? 1 : 0);                                   \
         if (GLDS_ && deep) {                                                                                                     \
-            auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NSTD : 2), E_, (W8 && GLDS_), LNF_>;        \
+            auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NSTD : 2), E_, (W8 && GLDS_), LNF_, false>; \
             static bool attr = false;                                                                                            \
             if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem_deep); attr = true; } \
             hipLaunchKernelGGL(k, grid, block, smem_deep, st, p);                                                                \
         } else {                                                                                                                 \
-            auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NST : 2), E_, (W8 && GLDS_), LNF_>;         \
+            auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NST : 2), E_, (W8 && GLDS_), LNF_, HX_>;    \
+            constexpr int SM_ = HX_ ? smem_hx : (smem_pk > smem ? smem_pk : smem);                                               \
             static bool attr = false;                                                                                            \
-            if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem_pk > smem ? smem_pk : smem); attr = true; } \
-            hipLaunchKernelGGL(k, grid, block, smem_l, st, p);                                                                   \
+            if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SM_); attr = true; } \
+            hipLaunchKernelGGL(k, grid, block, HX_ ? smem_hx : smem_l, st, p);                                                   \
         }                                                                                                                        \
     }
+#define RF_LAUNCH_VARIANT_LN(CONV_, GLDS_, EPI_, LNF_) RF_LAUNCH_VARIANT_X(CONV_, GLDS_, EPI_, LNF_, false)
 #define RF_LAUNCH_VARIANT(CONV_, GLDS_, EPI_) RF_LAUNCH_VARIANT_LN(CONV_, GLDS_, EPI_, 0)
     const int esel = packed ? 2 : ((direct || frag) ? 1 : 0);
     // The ring of four stages for 128x160 launches of at most one block per CU (4096 x 1280 x K <= 6000: the projections, ff.net.2 and 1x1 skips
@@ -1952,13 +2038,19 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     // 3x3 convs, +0.9 % for its small projections.
     static const int deep_env = tune_env("RF_GEMM_DEEP", 256);        // largest grid (blocks) that takes the ring
     constexpr int smem_deep = NSTD * (BM + BN) * 128 > smem ? NSTD * (BM + BN) * 128 : smem;
-    const bool deep = DEEP_OK && p.glds && !packed && !p.x3 && (long long)grid.x * grid.y * grid.z <= deep_env;
+    const bool deep = DEEP_OK && p.glds && !packed && !p.x3 && !hx && (long long)grid.x * grid.y * grid.z <= deep_env;
     if constexpr (A8) {            // fp8 activations: direct-to-LDS kernels only, staged or direct epilogue
         if (conv) { if (esel == 1) RF_LAUNCH_VARIANT(true, true, 1) else RF_LAUNCH_VARIANT(true, true, 0) }
         else { if (esel == 1) RF_LAUNCH_VARIANT(false, true, 1) else RF_LAUNCH_VARIANT(false, true, 0) }
     } else
     if (conv && p.glds) {
-        if (esel == 2) RF_LAUNCH_VARIANT(true, true, 2)
+        if (hx) {
+            if constexpr (HX_OK) {          // (checked above: korder 2 only reaches tiles that can take it)
+                if (esel == 1) RF_LAUNCH_VARIANT_X(true, true, 1, 0, true)
+                else RF_LAUNCH_VARIANT_X(true, true, 0, 0, true)
+            }
+        }
+        else if (esel == 2) RF_LAUNCH_VARIANT(true, true, 2)
         else if (esel == 1) RF_LAUNCH_VARIANT(true, true, 1)
         else RF_LAUNCH_VARIANT(true, true, 0)
     } else if (conv) {
@@ -1979,6 +2071,7 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     }
 #undef RF_LAUNCH_VARIANT
 #undef RF_LAUNCH_VARIANT_LN
+#undef RF_LAUNCH_VARIANT_X
     if (p.splitk > 1 && frag) {
         if constexpr (FRAG_OK)
             hipLaunchKernelGGL((splitk_reduce_frag_kernel<TO, WM, WN, TM, TN>), dim3(p.tiles_m * p.tiles_n, WM * WN * TM), dim3(64 * TN), 0, st, p);
@@ -2133,8 +2226,10 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
     RF_CHECK(((uintptr_t)d->src0 | (uintptr_t)d->src1 | (uintptr_t)d->W) % 16 == 0, "rf_conv_gemm: operands must be 16-byte aligned");
     RF_CHECK(d->act != RF_ACT_GEGLU || (d->N % 64 == 0 && !d->rowvec), "rf_conv_gemm: GEGLU needs N %% 64 == 0 and no rowvec");
     RF_CHECK(!d->rowvec || d->rows_per_sample > 0, "rf_conv_gemm: rowvec needs rows_per_sample");
-    RF_CHECK(d->korder == 0 || (d->korder == 1 && ctot % (8 * vec) == 0 && d->K == d->KH * d->KW * ctot),
-             "rf_conv_gemm: korder=1 needs (C0+C1) to be a multiple of %d", 8 * vec);
+    RF_CHECK(d->korder == 0 || ((d->korder == 1 || d->korder == 2) && ctot % (8 * vec) == 0 && d->K == d->KH * d->KW * ctot),
+             "rf_conv_gemm: korder=%d needs (C0+C1) to be a multiple of %d", d->korder, 8 * vec);
+    RF_CHECK(d->korder != 2 || (d->dtype == RF_BF16 && d->out_dtype == RF_BF16 && d->w_dtype == 0 && d->C1 == 0 && d->batch == 1),
+             "rf_conv_gemm: korder=2 (row-extended A tiles) is built for bf16 -> bf16 convolutions of one source");
     RF_CHECK(d->act != RF_ACT_PRELU || d->act_vec, "rf_conv_gemm: PReLU needs act_vec (per-column slopes)");
     const bool conv = !(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->ups == 0 &&
                         d->C1 == 0 && d->Hin == d->Hout && d->Win == d->Wout);

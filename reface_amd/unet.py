@@ -109,6 +109,9 @@ class UNetEngine:
         self.ln_fold = os.environ.get("REFACE_LN_FOLD", "1") == "1"
         # norm1 / norm3 folded around their neighbour GEMMs (producer statistics + consumer epilogue affine; bf16 mode): REFACE_LN_FOLD_GEMM=0 off
         self.ln_fold_gemm = os.environ.get("REFACE_LN_FOLD_GEMM", "1") == "1"
+        # row-extended A tiles for the 3x3 stride-1 convolutions (korder 2): REFACE_HX=0 keeps the tap-major K order
+        self.hx_on = os.environ.get("REFACE_HX", "1") == "1"
+        self.n_hx = 0
         self.n_ln_folded = 0
         self.n_cu = torch.cuda.get_device_properties(device).multi_processor_count if torch.cuda.is_available() else 256
         self.gn_fused = 0
@@ -277,6 +280,18 @@ class UNetEngine:
             self.n_x3 += 1
             return ops.conv2d(x, ops.pack_x3(ops.pack_conv_weight(self.sd[wkey], F32)), out, self.f32(bkey), x3=True, name=name, **kw)
         ko = ops.conv_korder(cin, self.dt) if self.korder_on else 0
+        if (self.hx_on and self.dt == torch.bfloat16 and not self.w8 and not ko and cin % 64 == 0 and kw.get("stride", 1) == 1 and not kw.get("ups", 0)
+                and x.shape[1:3] == out.shape[1:3]):
+            # 3x3 stride-1 convolution: K order (filter row, channel chunk, filter column) -- one row-extended A tile serves the three horizontal
+            # taps (a third of the A-operand fill, gemm.hip HX).  Whether the launch's tile can take it (whole image rows per tile) is the
+            # library's answer: ask for the plan, fall back to the tap-major order otherwise.
+            cand = ops.conv2d(x, ops.pack_conv_weight(self.sd[wkey], self.dt, korder=2), out, self.f32(bkey), korder=2, name=name, **kw)
+            try:
+                ops.gemm_plan2(cand)
+                self.n_hx += 1
+                return cand
+            except Exception:
+                pass
         wp = ops.pack_conv_weight(self.sd[wkey], F32, korder=ko)
         return ops.conv2d(x, wp.to(self.dt) if ko else self.gw(wp, cin), out, self.f32(bkey), korder=ko, name=name, **kw)
 

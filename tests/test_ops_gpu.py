@@ -392,6 +392,47 @@ def test_conv_channel_chunk_major_k(dt, stride, ups, Ci):
     check(out, ref, dt)
 
 
+@pytest.mark.parametrize("B,hw,Ci,Co", [(2, 32, 128, 320), (16, 8, 1280, 1280), (4, 16, 640, 1280), (2, 64, 320, 320), (16, 64, 320, 320), (3, 8, 128, 320),
+                                        (16, 32, 640, 640), (1, 16, 64, 64), (5, 16, 1280, 640)])
+def test_conv_row_extended_a_tiles(B, hw, Ci, Co):
+    """rf_conv_gemm korder 2 (gemm.hip HX, round 4): 3x3 stride-1 convolutions with the K order (filter row, channel chunk, filter column) -- the
+    three horizontal taps of a (row, chunk) share ONE row-extended A tile (every image row of the output tile + a halo pixel on each side).
+    Image borders (zero halo, top / bottom rows), tiles spanning several samples (8x8: 128-row tile = 2 samples), ragged M, split-K, and the
+    epilogue's bias / per-sample vector / residual / fused GroupNorm statistics -- against F.conv2d on the bf16-rounded operands, and bit-equal
+    to the tap-major launch of the same layer where the summation order per accumulator is the same K-tile sequence permuted (checked to 2 ulps)."""
+    dt = torch.bfloat16
+    x, xr = q(rnd((B, hw, hw, Ci), 160) * 0.5, dt)
+    w = rnd((Co, Ci, 3, 3), 161) / math.sqrt(Ci * 9)
+    b = rnd((Co,), 162)
+    rv = rnd((B, Co), 163)
+    res, rr = q(rnd((B, hw, hw, Co), 164), dt)
+    out = torch.empty((B, hw, hw, Co), dtype=dt, device=DEV)
+    l = ops.conv2d(x, ops.pack_conv_weight(w, dt, korder=2).to(DEV), out, b.to(DEV), rowvec=rv.to(DEV), residual=res, korder=2)
+    try:
+        pl = ops.gemm_plan2(l)
+    except Exception as e:
+        pytest.skip(f"this launch's tile cannot take korder 2: {e}")
+    assert pl["bm"] % hw == 0, pl
+    fused = ops.fuse_groupnorm_stats(out, [(l, 0, B * hw * hw, 0, Co)])
+    l()
+    out0 = torch.empty_like(out)
+    ops.conv2d(x, ops.pack_conv_weight(w, dt).to(DEV), out0, b.to(DEV), rowvec=rv.to(DEV), residual=res)()
+    torch.cuda.synchronize()
+    ref = (F.conv2d(xr.to(DEV).permute(0, 3, 1, 2), w.to(dt).float().to(DEV), b.to(DEV), padding=1).permute(0, 2, 3, 1).cpu() + rv[:, None, None, :] + rr)
+    check(out, ref, dt)
+    d01 = (out.float() - out0.float()).abs().max().item()
+    print(f"korder 2 vs tap-major (B={B}, {hw}x{hw}, {Ci}->{Co}): tile {pl['bm']}x{pl['bn']} splitk {pl['splitk']}, max |d| = {d01:.3e} at |out| max {ref.abs().max().item():.2f}")
+    assert d01 <= 2.0 ** -6 * max(1.0, ref.abs().max().item())
+    if fused is not None:
+        ops.run(fused[2])
+        g, be = rnd((Co,), 165) * 0.2 + 1, rnd((Co,), 166) * 0.2
+        y = torch.empty_like(out)
+        ops.groupnorm_apply(out, g.to(DEV), be.to(DEV), y, fused[0], fused[1], eps=1e-5, silu=True)()
+        torch.cuda.synchronize()
+        refn = F.silu(F.group_norm(out.float().cpu().permute(0, 3, 1, 2), 32, g, be, 1e-5)).permute(0, 2, 3, 1)
+        check(y, refn, dt)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_conv_split_k(dt):
     """Small-M / long-K conv (8x8 level of the UNet): takes the split-K path (partials in the workspace + reduce pass)."""
