@@ -184,8 +184,12 @@ def main(argv=None):
         from reface_amd.output import OutputWriter
         from reface_amd.output import default_writer_threads
         lvl = os.environ.get("RF_PNG_LEVEL")
-        # PNG encodes run on worker threads, bounded by this process's share of the host (8 processes per node share it)
-        writer = OutputWriter(outpath, skip_grid=opt.skip_grid, threads=default_writer_threads(world), compress_level=int(lvl) if lvl else None)
+        # PNG encodes run on worker threads, bounded by this process's share of the host (8 processes per node share it).  zlib level: PIL's
+        # default (6, the reference's files) for a single process; 1 when several processes share the host -- the same pixels in larger files:
+        # photo-like panels at level 6 cost 2.4 s per batch of 8 with 8 processes at once, 1.03 s at level 1 (tools/host_scaling_probe.py
+        # --natural, profiles/r04d_host_probe_natural*.json).  RF_PNG_LEVEL overrides.
+        level = int(lvl) if lvl else (1 if world > 1 else None)
+        writer = OutputWriter(outpath, skip_grid=opt.skip_grid, threads=default_writer_threads(world), compress_level=level)
     host_compose = os.environ.get("RF_HOST_COMPOSE") == "1"          # debug: the reference's per-image float passes on the host (round-3 form)
     def with_landmark_prefetch(batches):
         """Yield (batch, landmarks136 or None): the dlib landmarks of batch i+1 are detected on a worker thread while the GPU works
