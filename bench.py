@@ -469,7 +469,8 @@ def main():
         plan = list(sampler._plans.values())[0]
         log(f"[bench] UNet launches per DDIM step: {len(plan['step'])} (GroupNorm statistics fused into GEMM epilogues: {plan['eng'].gn_fused} of 61; "
             f"LayerNorm passes folded into neighbouring kernels: {plan['eng'].n_ln_folded} of 32)")
-        result["fusion"] = {"launches_per_ddim_step": len(plan["step"]), "groupnorm_statistics_fused": plan["eng"].gn_fused, "layernorm_passes_folded": plan["eng"].n_ln_folded}
+        result["fusion"] = {"launches_per_ddim_step": len(plan["step"]), "groupnorm_statistics_fused": plan["eng"].gn_fused, "layernorm_passes_folded": plan["eng"].n_ln_folded,
+                            "convs_on_row_extended_a_tiles": plan["eng"].n_hx}
         timed_l = profiler.time_launches(plan["step"], reps=5)
         fam = profiler.summarize(timed_l)
         step_ms = sum(ms for _, ms in timed_l)

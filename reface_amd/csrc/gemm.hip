@@ -472,13 +472,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         for (int i = 0; i < AV; ++i) {
             const int m = m0 + r0 + i * RPP;
             if constexpr (HX) {
-                // row j of the row-extended tile = image row (m0 / Wout + j / (Wout + 2)) over all samples, column code xc = j % (Wout + 2)
-                // (input column xc - 1: the halo pixels are xc = 0 and xc = Wout + 1)
-                const int j = r0 + i * RPP, we = p.Wout + 2;
-                const int ir = j / we, xc = j - ir * we;
-                const int R = m0 / p.Wout + ir;                       // (host: BM % Wout == 0, so m0 is the first pixel of an image row)
-                const int b = R / p.Hout, oy = R - b * p.Hout;
-                rowd[i] = (ir < BM / p.Wout && R * p.Wout < p.M) ? ((unsigned)b << 20 | (unsigned)oy << 10 | (unsigned)xc) : ~0u;
+                // (the row descriptors are recomputed by set_grp, three times per block: nothing is kept in registers across the main loop)
             } else if (CONV) {
                 const int hw = p.Hout * p.Wout;
                 const int b = m / hw, rem = m - b * hw;
@@ -490,12 +484,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         }
         // HX: A-piece offsets of filter row dy (3x3, stride 1, pad 1: input row oy + dy - 1, input column xc - 1), once per dy
         auto set_grp = [&](int dy) {
+            // row j of the row-extended tile = image row (m0 / Wout + j / (Wout + 2)) over all samples, column code xc = j % (Wout + 2)
+            // (input column xc - 1: the halo pixels are xc = 0 and xc = Wout + 1)
+            const int we = p.Wout + 2, R0 = m0 / p.Wout;                  // (host: BM % Wout == 0, so m0 is the first pixel of an image row)
 #pragma unroll
             for (int i = 0; i < AV; ++i) {
-                const unsigned d = rowd[i];
-                const int iy = (int)((d >> 10) & 1023u) + dy - 1, ix = (int)(d & 1023u) - 1;
-                const bool ok = d != ~0u && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-                offs[i] = ok ? (((int)(d >> 20) * p.Hin + iy) * p.Win + ix) * p.ld0 * (int)sizeof(T) + lane_k : OOB;
+                const int j = r0 + i * RPP;
+                const int ir = j / we, xc = j - ir * we;
+                const int R = R0 + ir;
+                const int b = R / p.Hout, oy = R - b * p.Hout;
+                const int iy = oy + dy - 1, ix = xc - 1;
+                const bool ok = ir < BM / p.Wout && R * p.Wout < p.M && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                offs[i] = ok ? ((b * p.Hin + iy) * p.Win + ix) * p.ld0 * (int)sizeof(T) + lane_k : OOB;
             }
         };
         // A-piece offsets of filter tap (ty, tx): padding / upsampling / stride live here, once per tap
@@ -741,27 +741,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         const char* curA = ldsA + (wm * TM) * 4096 + lrow * 128;
         // HX: this lane's row of block i in the row-extended tile for filter column 0 (erow), the A row pointer / swizzle term of the tile being
         // multiplied (hcb / hcs) and of the next one (hnb / hns), the filter column and A stage of the tile being multiplied
-        int erow[TM];
-        const char* hcb[TM];
-        const char* hnb[TM];
-        int hcs[TM], hns[TM], m_dx = 0, m_st = 0;
-        const int ks_[4] = {(0 + lhalf) << 4, (2 + lhalf) << 4, (4 + lhalf) << 4, (6 + lhalf) << 4};          // k-step kk -> 16-byte slot 2 kk + half
-        auto hx_set = [&](const char** hb, int* hs, int st, int dx) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int e = erow[i] + dx;
-                hb[i] = ldsA + st * (AXR * 128) + e * 128;
-                hs[i] = ((e >> 1) & 7) << 4;
-            }
+        int erow[TM], hcb[TM], hcs[TM];          // (hcb: byte offset of the row in LDS, hcs: its swizzle term with the lane half folded in)
+        int m_dx = 0, m_st = 0;                  // wave-uniform
+        // slot 2 kk + half of row e sits at 16-byte position (2 kk + half) ^ ((e >> 1) & 7) = (2 kk) ^ (half ^ ((e >> 1) & 7)): one XOR with kk << 5
+        auto hx_row = [&](int i, int st, int dx, int& hb, int& hs) {
+            const int e = erow[i] + dx;
+            hb = st * (AXR * 128) + e * 128;
+            hs = (((e >> 1) & 7) ^ lhalf) << 4;
         };
         if constexpr (HX) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int pm = (wm * TM + i) * 32 + lrow, ir = pm / p.Wout;
                 erow[i] = ir * (p.Wout + 2) + (pm - ir * p.Wout);
+                hx_row(i, 0, 0, hcb[i], hcs[i]);
             }
-            hx_set(hcb, hcs, 0, 0);
-            hx_set(hnb, hns, 0, 1);
         }
         const char* const wbase = ldsB + (wn * TN) * 4096 + brow * 128;
         const char* curB = wbase + w_stage<W8>(kb0_tiles, 0) * BN * 128;
@@ -812,8 +806,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                if constexpr (HX) fa[nx][i] = *(const u32x4_t*)((kk < 3 ? hcb[i] : hnb[i]) + (ks_[nkk] ^ (kk < 3 ? hcs[i] : hns[i])));
-                else fa[nx][i] = *(const u32x4_t*)(nA + i * 4096);
+                if constexpr (HX) {
+                    if (kk < 3) {
+                        fa[nx][i] = *(const u32x4_t*)(ldsA + hcb[i] + ((nkk << 5) ^ hcs[i]));
+                    } else {          // first fragments of the next tile: next filter column, or column 0 of the next group's stage
+                        int nb, ns;
+                        hx_row(i, m_dx == 2 ? (m_st ^ 1) : m_st, m_dx == 2 ? 0 : m_dx + 1, nb, ns);
+                        fa[nx][i] = *(const u32x4_t*)(ldsA + nb + ns);
+                    }
+                } else fa[nx][i] = *(const u32x4_t*)(nA + i * 4096);
             }
 #pragma unroll
             for (int j = 0; j < (ROT ? JS : TN); ++j) load_b(fbn, j, nB + j * 4096);
@@ -902,7 +903,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             __builtin_amdgcn_s_barrier();
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                if constexpr (HX) fa[0][i] = *(const u32x4_t*)(hcb[i] + (ks_[0] ^ hcs[i]));
+                if constexpr (HX) fa[0][i] = *(const u32x4_t*)(ldsA + hcb[i] + hcs[i]);
                 else fa[0][i] = *(const u32x4_t*)(curA + i * 4096 + fk[0]);
             }
 #pragma unroll
@@ -958,11 +959,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             if (kt + 3 < nk) next_tile();
 #endif
             const char* t = curA; curA = othA; othA = t;
-            if constexpr (HX) {          // the tile multiplied next becomes current; its successor: next filter column, or column 0 of the next group's stage
+            if constexpr (HX) {          // the tile multiplied next: the next filter column, or column 0 of the next group's stage
                 if (++m_dx == 3) { m_dx = 0; m_st ^= 1; }
 #pragma unroll
-                for (int i = 0; i < TM; ++i) { hcb[i] = hnb[i]; hcs[i] = hns[i]; }
-                hx_set(hnb, hns, m_dx == 2 ? (m_st ^ 1) : m_st, m_dx == 2 ? 0 : m_dx + 1);
+                for (int i = 0; i < TM; ++i) hx_row(i, m_st, m_dx, hcb[i], hcs[i]);
             }
             if constexpr (W8) {
                 ++t_abs;
