@@ -582,7 +582,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                     if (q < AV) {
                         // (RF_GEMM_DBG bit 8, timing only: the A pieces of two K tiles out of three are not issued -- the fill a row-extended A
                         //  tile shared by the three horizontal taps of a 3x3 window would need; stale operands, wrong results)
-                        if (!(RF_DBG(p, 256) && CONV && p.KW == 3 && p.stride == 1 && !p.ups && (it % 3) != 0) && !(HX && hx_dx != 0))
+                        if (!(RF_DBG(p, 256) && CONV && p.KW == 3 && p.stride == 1 && !p.ups && (it % 3) != 0) && !(HX && hx_dx != 0) &&
+                            !(RF_DBG(p, 512) && HX))          // (bit 9, timing only: an HX kernel that stages no A tile at all)
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(a + q * (RPP * 128)), 16, offs[q], soA, 0, 0);
                     } else
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(b + (q - AV) * (RPP * 128)), 16, offs[q], soB, 0, 0);
@@ -1973,8 +1974,9 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     static const int gn_direct = tune_env("RF_EPI_GN", 1);      // 0: fused statistics keep EPI 0
     const bool direct = DIRECT_OK && (epi_env < 0 || epi_env == 1) && ep_common && (p.gn_rows == 0 || (gn_direct && d->act == RF_ACT_NONE));
     RF_CHECK(!hx || (HX_OK && conv && p.glds && p.KH == 3 && p.KW == 3 && p.stride == 1 && !p.ups && p.pad_t == 1 && p.pad_l == 1 && p.Hin == p.Hout &&
-                     p.Win == p.Wout && p.Wout >= 8 && BM % p.Wout == 0 && (BM / p.Wout) * (p.Wout + 2) <= AXR_ && epi_env != 2),
-             "rf_conv_gemm: korder 2 (row-extended A tiles) needs a bf16 3x3 stride-1 pad-1 convolution whose %d-row tile holds whole image rows (Wout = %d)", BM, p.Wout);
+                     p.Win == p.Wout && p.Wout >= 16 && BM % p.Wout == 0 && (BM / p.Wout) * (p.Wout + 2) <= AXR_ && epi_env != 2 &&
+                     !(DEEP_OK && (long long)p.tiles_m * p.tiles_n * p.splitk <= 256)),
+             "rf_conv_gemm: korder 2 (row-extended A tiles) needs a bf16 3x3 stride-1 pad-1 convolution, Wout >= 16, whose %d-row tile holds whole image rows (Wout = %d) and that does not take the 4-stage ring", BM, p.Wout);
     // LayerNorm folding lives in the direct epilogue only (bf16 linear layers: the LNF variants of the kernel)
     constexpr bool LN_OK = DIRECT_OK && sizeof(T) == 2 && sizeof(TO) == 2 && !W8 && !A8;
     RF_CHECK(!(p.ln_out || p.ln_in) || (LN_OK && !conv),
