@@ -1930,7 +1930,7 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     // HX (row-extended A tiles for 3x3 stride-1 convolutions, korder 2): bf16 -> bf16 only; the stage of BM + BM / 4 rows must fit the 160 KB of LDS
     constexpr int RPP_ = WM * WN * 8, AXR_ = ((BM * 5 / 4 + RPP_ - 1) / RPP_) * RPP_;
     constexpr int smem_hx_ml = NST * (AXR_ + BN) * 128, smem_hx = smem_hx_ml > smem_ep ? smem_hx_ml : smem_ep;
-    constexpr bool HX_OK = std::is_same<T, bf16_t>::value && std::is_same<TO, bf16_t>::value && !W8 && !A8 && smem_hx <= 160 * 1024;
+    constexpr bool HX_OK = std::is_same<T, bf16_t>::value && std::is_same<TO, bf16_t>::value && !W8 && !A8 && smem_hx <= 160 * 1024 && AXR_ / RPP_ <= 8;
     const bool hx = p.korder == 2;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
