@@ -197,7 +197,7 @@ __device__ __forceinline__ void halfwave_reduce_scatter32(float (&gx)[32], int l
 // (issued between the MFMAs of the previous fragment column).  The MFMA itself is the bf16 one: same matrix-core ceiling.
 // LNF: LayerNorm role of the launch (rf_conv_gemm_desc.ln_*), a compile-time variant of the direct epilogue so that ordinary launches carry none
 // of its registers: 0 none, 1 producer (row statistics of the stored output), 2 consumer (row affine; such launches have no residual)
-// HX (round 4): 3x3 stride-1 convolutions with the K order (filter row dy, channel chunk, filter column dx) -- rf_conv_gemm_desc.korder = 2.  The three
+// HX (round 4): 3x3 stride-1 convolutions with the K order (channel chunk, filter row dy, filter column dx) -- rf_conv_gemm_desc.korder = 2.  The three
 // horizontal taps of one (dy, chunk) read the SAME image rows shifted by one pixel, so ONE row-extended A tile -- every image row of the output tile
 // with one halo pixel on each side, (BM / Wout) * (Wout + 2) rows of 128 bytes -- is staged per group of three K tiles instead of one BM-row tile per
 // K tile: a third of the A-operand fill (the per-CU operand fill is what caps these kernels).  Fragment reads address row  erow(pixel) + dx  of that
@@ -483,39 +483,33 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             }
         }
         // HX: A-piece offsets of filter row dy (3x3, stride 1, pad 1: input row oy + dy - 1, input column xc - 1), once per dy
-        auto set_grp = [&](int dy) {
-            // row j of the row-extended tile = image row (m0 / Wout + j / (Wout + 2)) over all samples, column code xc = j % (Wout + 2)
-            // (input column xc - 1: the halo pixels are xc = 0 and xc = Wout + 1)
+        // HX: per A piece the byte offset of its pixel for filter row 1 (iy = oy), OOB when the row / column does not exist, and whether the image
+        // rows above (filter row 0) and below (filter row 2) exist; the offsets of filter row dy follow at issue time: base + (dy - 1) * row bytes
+        int hx_base[8];          // (fixed size: a conditional array size makes hipcc's host pass drop kernel stubs; AV <= 8)
+        unsigned hx_up = 0u, hx_dn = 0u;          // bit i: piece i's pixel has an image row above / below
+        int hx_rowb = 0;
+        if constexpr (HX) {
             const int we = p.Wout + 2, R0 = m0 / p.Wout;                  // (host: BM % Wout == 0, so m0 is the first pixel of an image row)
+            hx_rowb = p.Win * p.ld0 * (int)sizeof(T);
 #pragma unroll
             for (int i = 0; i < AV; ++i) {
+                // row j of the row-extended tile = image row (R0 + j / (Wout + 2)) over all samples, column code xc = j % (Wout + 2)
+                // (input column xc - 1: the halo pixels are xc = 0 and xc = Wout + 1)
                 const int j = r0 + i * RPP;
                 const int ir = j / we, xc = j - ir * we;
                 const int R = R0 + ir;
-                const int b = R / p.Hout, oy = R - b * p.Hout;
-                const int iy = oy + dy - 1, ix = xc - 1;
-                const bool ok = ir < BM / p.Wout && R * p.Wout < p.M && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-                offs[i] = ok ? ((b * p.Hin + iy) * p.Win + ix) * p.ld0 * (int)sizeof(T) + lane_k : OOB;
+                const int b = R / p.Hout, oy = R - b * p.Hout, ix = xc - 1;
+                const bool ok = ir < BM / p.Wout && R * p.Wout < p.M && (unsigned)ix < (unsigned)p.Win;
+                hx_base[i] = ok ? ((b * p.Hin + oy) * p.Win + ix) * p.ld0 * (int)sizeof(T) + lane_k : OOB;
+                if (ok && oy > 0) hx_up |= 1u << i;
+                if (ok && oy + 1 < p.Hin) hx_dn |= 1u << i;
             }
-        };
-        // A-piece offsets of filter tap (ty, tx): padding / upsampling / stride live here, once per tap
-        auto set_tap = [&](int ty, int tx) {
+        }
+        auto set_grp = [&](int dy) {
 #pragma unroll
             for (int i = 0; i < AV; ++i) {
-                const unsigned d = rowd[i];
-                int iy = (int)((d >> 10) & 1023u) * p.stride - p.pad_t + ty;
-                int ix = (int)(d & 1023u) * p.stride - p.pad_l + tx;
-                const bool ok = d != ~0u && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-                if (p.ups) { iy >>= 1; ix >>= 1; }
-                offs[i] = ok ? (((int)(d >> 20) * p.Hin + iy) * p.Win + ix) * p.ld0 * (int)sizeof(T) + lane_k : OOB;
-            }
-            if constexpr (A8) {
-                const unsigned d = srowd;
-                int iy = (int)((d >> 10) & 1023u) * p.stride - p.pad_t + ty;
-                int ix = (int)(d & 1023u) * p.stride - p.pad_l + tx;
-                const bool ok = d != ~0u && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-                if (p.ups) { iy >>= 1; ix >>= 1; }
-                soffs = ok ? (((int)(d >> 20) * p.Hin + iy) * p.Win + ix) * p.as_ld : OOB;
+                const bool ok = hx_base[i] != OOB && (dy == 1 || ((dy == 0 ? hx_up : hx_dn) >> i & 1u));
+                offs[i] = ok ? hx_base[i] + (dy - 1) * hx_rowb : OOB;
             }
         };
         // uniform K state of the NEXT tile to issue: absolute tile index, and for convs (tap, channel chunk inside the tap)
@@ -530,9 +524,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         int ia = x3 ? kb0_tiles / 3 : kb0_tiles;          // (split-K ranges of the split mode start on a multiple of 3)
         int hx_dx = 0, hx_ist = 0;                         // HX issue state: filter column of tile `it`, A stage of its group
         if constexpr (HX) {
-            const int grp = kb0_tiles / 3;                 // K order (dy, chunk, dx): group = dy * tpt + chunk
-            ity = grp / tpt;
-            ic = grp - ity * tpt;
+            const int grp = kb0_tiles / 3;                 // K order (chunk, dy, dx): group = chunk * 3 + dy -- the three filter rows of a channel
+            ic = grp / 3;                                  // chunk re-read two thirds of each other's image rows back to back (L2 hits)
+            ity = grp - ic * 3;
             set_grp(ity);
         } else
         if (CONV) {
@@ -549,7 +543,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 if (++hx_dx == 3) {
                     hx_dx = 0;
                     hx_ist ^= 1;
-                    if (++ic == tpt) { ic = 0; ++ity; set_grp(ity); }
+                    if (++ity == 3) { ity = 0; ++ic; }
+                    set_grp(ity);
                 }
                 return;
             }
