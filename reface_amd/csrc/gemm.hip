@@ -197,7 +197,7 @@ __device__ __forceinline__ void halfwave_reduce_scatter32(float (&gx)[32], int l
 // (issued between the MFMAs of the previous fragment column).  The MFMA itself is the bf16 one: same matrix-core ceiling.
 // LNF: LayerNorm role of the launch (rf_conv_gemm_desc.ln_*), a compile-time variant of the direct epilogue so that ordinary launches carry none
 // of its registers: 0 none, 1 producer (row statistics of the stored output), 2 consumer (row affine; such launches have no residual)
-// HX (round 4): 3x3 stride-1 convolutions with the K order (channel chunk, filter row dy, filter column dx) -- rf_conv_gemm_desc.korder = 2.  The three
+// HX (round 4): 3x3 stride-1 convolutions with the K order (filter row dy, channel chunk, filter column dx) -- rf_conv_gemm_desc.korder = 2.  The three
 // horizontal taps of one (dy, chunk) read the SAME image rows shifted by one pixel, so ONE row-extended A tile -- every image row of the output tile
 // with one halo pixel on each side, (BM / Wout) * (Wout + 2) rows of 128 bytes -- is staged per group of three K tiles instead of one BM-row tile per
 // K tile: a third of the A-operand fill (the per-CU operand fill is what caps these kernels).  Fragment reads address row  erow(pixel) + dx  of that
@@ -472,7 +472,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         for (int i = 0; i < AV; ++i) {
             const int m = m0 + r0 + i * RPP;
             if constexpr (HX) {
-                // (the row descriptors are recomputed by set_grp, three times per block: nothing is kept in registers across the main loop)
+                // row j of the row-extended tile = image row (m0 / Wout + j / (Wout + 2)) over all samples, column code xc = j % (Wout + 2)
+                // (input column xc - 1: the halo pixels are xc = 0 and xc = Wout + 1)
+                const int j = r0 + i * RPP, we = p.Wout + 2;
+                const int ir = j / we, xc = j - ir * we;
+                const int R = m0 / p.Wout + ir;                       // (host: BM % Wout == 0, so m0 is the first pixel of an image row)
+                const int b = R / p.Hout, oy = R - b * p.Hout;
+                rowd[i] = (ir < BM / p.Wout && R * p.Wout < p.M) ? ((unsigned)b << 20 | (unsigned)oy << 10 | (unsigned)xc) : ~0u;
             } else if (CONV) {
                 const int hw = p.Hout * p.Wout;
                 const int b = m / hw, rem = m - b * hw;
@@ -483,33 +489,33 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             }
         }
         // HX: A-piece offsets of filter row dy (3x3, stride 1, pad 1: input row oy + dy - 1, input column xc - 1), once per dy
-        // HX: per A piece the byte offset of its pixel for filter row 1 (iy = oy), OOB when the row / column does not exist, and whether the image
-        // rows above (filter row 0) and below (filter row 2) exist; the offsets of filter row dy follow at issue time: base + (dy - 1) * row bytes
-        int hx_base[8];          // (fixed size: a conditional array size makes hipcc's host pass drop kernel stubs; AV <= 8)
-        unsigned hx_up = 0u, hx_dn = 0u;          // bit i: piece i's pixel has an image row above / below
-        int hx_rowb = 0;
-        if constexpr (HX) {
-            const int we = p.Wout + 2, R0 = m0 / p.Wout;                  // (host: BM % Wout == 0, so m0 is the first pixel of an image row)
-            hx_rowb = p.Win * p.ld0 * (int)sizeof(T);
-#pragma unroll
-            for (int i = 0; i < AV; ++i) {
-                // row j of the row-extended tile = image row (R0 + j / (Wout + 2)) over all samples, column code xc = j % (Wout + 2)
-                // (input column xc - 1: the halo pixels are xc = 0 and xc = Wout + 1)
-                const int j = r0 + i * RPP;
-                const int ir = j / we, xc = j - ir * we;
-                const int R = R0 + ir;
-                const int b = R / p.Hout, oy = R - b * p.Hout, ix = xc - 1;
-                const bool ok = ir < BM / p.Wout && R * p.Wout < p.M && (unsigned)ix < (unsigned)p.Win;
-                hx_base[i] = ok ? ((b * p.Hin + oy) * p.Win + ix) * p.ld0 * (int)sizeof(T) + lane_k : OOB;
-                if (ok && oy > 0) hx_up |= 1u << i;
-                if (ok && oy + 1 < p.Hin) hx_dn |= 1u << i;
-            }
-        }
         auto set_grp = [&](int dy) {
 #pragma unroll
             for (int i = 0; i < AV; ++i) {
-                const bool ok = hx_base[i] != OOB && (dy == 1 || ((dy == 0 ? hx_up : hx_dn) >> i & 1u));
-                offs[i] = ok ? hx_base[i] + (dy - 1) * hx_rowb : OOB;
+                const unsigned d = rowd[i];
+                const int iy = (int)((d >> 10) & 1023u) + dy - 1, ix = (int)(d & 1023u) - 1;
+                const bool ok = d != ~0u && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                offs[i] = ok ? (((int)(d >> 20) * p.Hin + iy) * p.Win + ix) * p.ld0 * (int)sizeof(T) + lane_k : OOB;
+            }
+        };
+        // A-piece offsets of filter tap (ty, tx): padding / upsampling / stride live here, once per tap
+        auto set_tap = [&](int ty, int tx) {
+#pragma unroll
+            for (int i = 0; i < AV; ++i) {
+                const unsigned d = rowd[i];
+                int iy = (int)((d >> 10) & 1023u) * p.stride - p.pad_t + ty;
+                int ix = (int)(d & 1023u) * p.stride - p.pad_l + tx;
+                const bool ok = d != ~0u && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+                if (p.ups) { iy >>= 1; ix >>= 1; }
+                offs[i] = ok ? (((int)(d >> 20) * p.Hin + iy) * p.Win + ix) * p.ld0 * (int)sizeof(T) + lane_k : OOB;
+            }
+            if constexpr (A8) {
+                const unsigned d = srowd;
+                int iy = (int)((d >> 10) & 1023u) * p.stride - p.pad_t + ty;
+                int ix = (int)(d & 1023u) * p.stride - p.pad_l + tx;
+                const bool ok = d != ~0u && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+                if (p.ups) { iy >>= 1; ix >>= 1; }
+                soffs = ok ? (((int)(d >> 20) * p.Hin + iy) * p.Win + ix) * p.as_ld : OOB;
             }
         };
         // uniform K state of the NEXT tile to issue: absolute tile index, and for convs (tap, channel chunk inside the tap)
@@ -524,9 +530,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         int ia = x3 ? kb0_tiles / 3 : kb0_tiles;          // (split-K ranges of the split mode start on a multiple of 3)
         int hx_dx = 0, hx_ist = 0;                         // HX issue state: filter column of tile `it`, A stage of its group
         if constexpr (HX) {
-            const int grp = kb0_tiles / 3;                 // K order (chunk, dy, dx): group = chunk * 3 + dy -- the three filter rows of a channel
-            ic = grp / 3;                                  // chunk re-read two thirds of each other's image rows back to back (L2 hits)
-            ity = grp - ic * 3;
+            const int grp = kb0_tiles / 3;                 // K order (dy, chunk, dx): group = dy * tpt + chunk
+            ity = grp / tpt;
+            ic = grp - ity * tpt;
             set_grp(ity);
         } else
         if (CONV) {
@@ -543,8 +549,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 if (++hx_dx == 3) {
                     hx_dx = 0;
                     hx_ist ^= 1;
-                    if (++ity == 3) { ity = 0; ++ic; }
-                    set_grp(ity);
+                    if (++ic == tpt) { ic = 0; ++ity; set_grp(ity); }
                 }
                 return;
             }
@@ -577,8 +582,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                     if (q < AV) {
                         // (RF_GEMM_DBG bit 8, timing only: the A pieces of two K tiles out of three are not issued -- the fill a row-extended A
                         //  tile shared by the three horizontal taps of a 3x3 window would need; stale operands, wrong results)
-                        if (!(RF_DBG(p, 256) && CONV && p.KW == 3 && p.stride == 1 && !p.ups && (it % 3) != 0) && !(HX && hx_dx != 0) &&
-                            !(RF_DBG(p, 512) && HX))          // (bit 9, timing only: an HX kernel that stages no A tile at all)
+                        if (!(RF_DBG(p, 256) && CONV && p.KW == 3 && p.stride == 1 && !p.ups && (it % 3) != 0) && !(HX && hx_dx != 0))
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(a + q * (RPP * 128)), 16, offs[q], soA, 0, 0);
                     } else
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(b + (q - AV) * (RPP * 128)), 16, offs[q], soB, 0, 0);
@@ -737,21 +741,27 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         const char* curA = ldsA + (wm * TM) * 4096 + lrow * 128;
         // HX: this lane's row of block i in the row-extended tile for filter column 0 (erow), the A row pointer / swizzle term of the tile being
         // multiplied (hcb / hcs) and of the next one (hnb / hns), the filter column and A stage of the tile being multiplied
-        int erow[TM], hcb[TM], hcs[TM];          // (hcb: byte offset of the row in LDS, hcs: its swizzle term with the lane half folded in)
-        int m_dx = 0, m_st = 0;                  // wave-uniform
-        // slot 2 kk + half of row e sits at 16-byte position (2 kk + half) ^ ((e >> 1) & 7) = (2 kk) ^ (half ^ ((e >> 1) & 7)): one XOR with kk << 5
-        auto hx_row = [&](int i, int st, int dx, int& hb, int& hs) {
-            const int e = erow[i] + dx;
-            hb = st * (AXR * 128) + e * 128;
-            hs = (((e >> 1) & 7) ^ lhalf) << 4;
+        int erow[TM];
+        const char* hcb[TM];
+        const char* hnb[TM];
+        int hcs[TM], hns[TM], m_dx = 0, m_st = 0;
+        const int ks_[4] = {(0 + lhalf) << 4, (2 + lhalf) << 4, (4 + lhalf) << 4, (6 + lhalf) << 4};          // k-step kk -> 16-byte slot 2 kk + half
+        auto hx_set = [&](const char** hb, int* hs, int st, int dx) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int e = erow[i] + dx;
+                hb[i] = ldsA + st * (AXR * 128) + e * 128;
+                hs[i] = ((e >> 1) & 7) << 4;
+            }
         };
         if constexpr (HX) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int pm = (wm * TM + i) * 32 + lrow, ir = pm / p.Wout;
                 erow[i] = ir * (p.Wout + 2) + (pm - ir * p.Wout);
-                hx_row(i, 0, 0, hcb[i], hcs[i]);
             }
+            hx_set(hcb, hcs, 0, 0);
+            hx_set(hnb, hns, 0, 1);
         }
         const char* const wbase = ldsB + (wn * TN) * 4096 + brow * 128;
         const char* curB = wbase + w_stage<W8>(kb0_tiles, 0) * BN * 128;
@@ -802,15 +812,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                if constexpr (HX) {
-                    if (kk < 3) {
-                        fa[nx][i] = *(const u32x4_t*)(ldsA + hcb[i] + ((nkk << 5) ^ hcs[i]));
-                    } else {          // first fragments of the next tile: next filter column, or column 0 of the next group's stage
-                        int nb, ns;
-                        hx_row(i, m_dx == 2 ? (m_st ^ 1) : m_st, m_dx == 2 ? 0 : m_dx + 1, nb, ns);
-                        fa[nx][i] = *(const u32x4_t*)(ldsA + nb + ns);
-                    }
-                } else fa[nx][i] = *(const u32x4_t*)(nA + i * 4096);
+                if constexpr (HX) fa[nx][i] = *(const u32x4_t*)((kk < 3 ? hcb[i] : hnb[i]) + (ks_[nkk] ^ (kk < 3 ? hcs[i] : hns[i])));
+                else fa[nx][i] = *(const u32x4_t*)(nA + i * 4096);
             }
 #pragma unroll
             for (int j = 0; j < (ROT ? JS : TN); ++j) load_b(fbn, j, nB + j * 4096);
@@ -899,7 +902,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             __builtin_amdgcn_s_barrier();
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                if constexpr (HX) fa[0][i] = *(const u32x4_t*)(ldsA + hcb[i] + hcs[i]);
+                if constexpr (HX) fa[0][i] = *(const u32x4_t*)(hcb[i] + (ks_[0] ^ hcs[i]));
                 else fa[0][i] = *(const u32x4_t*)(curA + i * 4096 + fk[0]);
             }
 #pragma unroll
@@ -955,10 +958,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
             if (kt + 3 < nk) next_tile();
 #endif
             const char* t = curA; curA = othA; othA = t;
-            if constexpr (HX) {          // the tile multiplied next: the next filter column, or column 0 of the next group's stage
+            if constexpr (HX) {          // the tile multiplied next becomes current; its successor: next filter column, or column 0 of the next group's stage
                 if (++m_dx == 3) { m_dx = 0; m_st ^= 1; }
 #pragma unroll
-                for (int i = 0; i < TM; ++i) hx_row(i, m_st, m_dx, hcb[i], hcs[i]);
+                for (int i = 0; i < TM; ++i) { hcb[i] = hnb[i]; hcs[i] = hns[i]; }
+                hx_set(hnb, hns, m_dx == 2 ? (m_st ^ 1) : m_st, m_dx == 2 ? 0 : m_dx + 1);
             }
             if constexpr (W8) {
                 ++t_abs;
@@ -1971,7 +1975,8 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     RF_CHECK(!hx || (HX_OK && conv && p.glds && p.KH == 3 && p.KW == 3 && p.stride == 1 && !p.ups && p.pad_t == 1 && p.pad_l == 1 && p.Hin == p.Hout &&
                      p.Win == p.Wout && p.Wout >= 16 && BM % p.Wout == 0 && (BM / p.Wout) * (p.Wout + 2) <= AXR_ && epi_env != 2 &&
                      !(DEEP_OK && (long long)p.tiles_m * p.tiles_n * p.splitk <= 256)),
-             "rf_conv_gemm: korder 2 (row-extended A tiles) needs a bf16 3x3 stride-1 pad-1 convolution, Wout >= 16, whose %d-row tile holds whole image rows (Wout = %d) and that does not take the 4-stage ring", BM, p.Wout);
+             "rf_conv_gemm: korder 2 (row-extended A tiles) needs a bf16 3x3 stride-1 pad-1 convolution, Wout >= 16, whose %d-row tile holds whole image rows (Wout = %d) "
+             "and that does not take the 4-stage ring", BM, p.Wout);
     // LayerNorm folding lives in the direct epilogue only (bf16 linear layers: the LNF variants of the kernel)
     constexpr bool LN_OK = DIRECT_OK && sizeof(T) == 2 && sizeof(TO) == 2 && !W8 && !A8;
     RF_CHECK(!(p.ln_out || p.ln_in) || (LN_OK && !conv),

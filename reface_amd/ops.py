@@ -56,13 +56,17 @@ def conv_korder(cin, dtype, ksize=3):
 def pack_conv_weight(w, dtype, cin_pad=None, korder=0):
     """[Cout, Cin, KH, KW] -> [Cout, KH*KW*Cin_pad].
     korder 0: k = (ky*KW + kx)*Cin_pad + c.   korder 1: k = ((c // BK)*KH*KW + tap)*BK + c % BK (BK = K-tile elements).
-    korder 2: the layout of korder 1 (channel chunk, filter row, filter column) -- selects rf_conv_gemm's row-extended A tiles (3x3, stride 1): the three
-    horizontal taps of a (chunk, row) are consecutive K tiles and share ONE A tile, the three rows of a chunk follow each other (L2 hits)."""
+    korder 2: k = ((ky*(Cin_pad // BK) + c // BK)*KW + kx)*BK + c % BK -- filter row, channel chunk, filter column: the three horizontal taps of a
+    (row, chunk) are consecutive K tiles and share one row-extended A tile in rf_conv_gemm (3x3, stride 1)."""
     co, ci, kh, kw = w.shape
     cp = ci if cin_pad is None else cin_pad
     wp = torch.zeros((co, kh, kw, cp), dtype=torch.float32, device=w.device)
     wp[..., :ci] = w.float().permute(0, 2, 3, 1)
-    if korder:
+    if korder == 2:
+        bk = 8 * vec(dtype)
+        assert cp % bk == 0
+        wp = wp.reshape(co, kh, kw, cp // bk, bk).permute(0, 1, 3, 2, 4)
+    elif korder:
         bk = 8 * vec(dtype)
         assert cp % bk == 0
         wp = wp.reshape(co, kh * kw, cp // bk, bk).permute(0, 2, 1, 3)

@@ -19,3 +19,6 @@ export EXTRA=""
 # the default line the driver will run (other_configs included)
 python3 bench.py --steps 5 --warmup 2 --profile-json gpurun_out/${T}_c1_prof.json > gpurun_out/${T}_default_bench.json 2> gpurun_out/${T}_default_bench.log
 tail -4 gpurun_out/${T}_default_bench.log
+# shader clock actually held inside the DDIM loop (tools/clock_probe.*): evidence for the power-management reading of the stale-operand experiments
+timeout 300 python3 tools/clock_probe.py > gpurun_out/${T}_clock_probe.txt 2>&1
+tail -2 gpurun_out/${T}_clock_probe.txt
