@@ -23,8 +23,12 @@ ap.add_argument("--sustain", type=float, default=0.0, help="also report the rate
 ap.add_argument("--korder", type=int, default=0)
 ap.add_argument("--cold", type=int, default=0, help="time every launch alone behind a pass over a 1 GB buffer (operands come from HBM, as inside the step)")
 ap.add_argument("--gn", type=int, default=0, help="conv cases also emit the fused GroupNorm statistics of their output")
+ap.add_argument("--vendor", type=int, default=0, help="also time the SAME operation through PyTorch-ROCm's vendor libraries (hipBLASLt linear, MIOpen "
+                "channels-last conv2d, the SDPA flash kernel, native group_norm) on the same tensors: what the reference's own modules would launch on this GPU")
 args = ap.parse_args()
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+if args.vendor >= 2:
+    torch.backends.cudnn.benchmark = True          # MIOpen searches its solvers per shape (the reference's scripts leave this off)
 dev = "cuda"
 Bc = args.bc
 KORDER = args.korder
@@ -35,6 +39,8 @@ def r(*shape, scale=1.0, dtype=None):
 
 
 cases = []
+vendor = {}
+F = torch.nn.functional
 
 
 def conv(name, cin, cout, hw, *, c1=0, stride=1, ups=0):
@@ -50,6 +56,15 @@ def conv(name, cin, cout, hw, *, c1=0, stride=1, ups=0):
     if args.gn:
         assert ops.fuse_groupnorm_stats(out, [(l, 0, Bc * ho * ho, 0, cout)]) is not None, name
     cases.append((name, l, 2.0 * Bc * ho * ho * cout * 9 * (cin + c1)))
+    if args.vendor:
+        xv = x.permute(0, 3, 1, 2)                                                     # NCHW view of the NHWC buffer = channels_last
+        wv = w.view(cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+        bv, rv = b.to(dt), res.permute(0, 3, 1, 2)
+
+        def run(xv=xv, wv=wv, bv=bv, rv=rv, stride=stride, ups=ups):
+            xi = F.interpolate(xv, scale_factor=2.0, mode="nearest") if ups else xv
+            return F.conv2d(xi, wv, bv, stride=stride, padding=1) + rv
+        vendor[name] = run
 
 
 def lin(name, M, N, K, act=ops.ACT_NONE, res=False):
@@ -57,7 +72,18 @@ def lin(name, M, N, K, act=ops.ACT_NONE, res=False):
     w = r(N, K, scale=1 / math.sqrt(K))
     b = r(N, dtype=torch.float32)
     out = torch.empty(M, N // 2 if act == ops.ACT_GEGLU else N, device=dev, dtype=dt)
-    cases.append((name, ops.linear(x, w, out, b, act=act, residual=r(M, N) if res else None, name=name), 2.0 * M * N * K))
+    rs = r(M, N) if res else None
+    cases.append((name, ops.linear(x, w, out, b, act=act, residual=rs, name=name), 2.0 * M * N * K))
+    if args.vendor:
+        bv = b.to(dt)
+
+        def run(x=x, w=w, bv=bv, rs=rs, act=act):
+            y = F.linear(x, w, bv)
+            if act == ops.ACT_GEGLU:
+                a, g = y.chunk(2, dim=-1)
+                return a * F.gelu(g)
+            return y + rs if rs is not None else y
+        vendor[name] = run
 
 
 def attn(name, heads, d, N):
@@ -66,6 +92,9 @@ def attn(name, heads, d, N):
     out = torch.empty(Bc, N, c, device=dev, dtype=dt)
     cases.append((name, ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], out, heads=heads, scale=d ** -0.5, name=name),
                   4.0 * Bc * heads * N * N * d))
+    if args.vendor:
+        q, k, v = (qkv[..., i * c:(i + 1) * c].reshape(Bc, N, heads, d).transpose(1, 2) for i in range(3))
+        vendor[name] = lambda q=q, k=k, v=v: F.scaled_dot_product_attention(q, k, v)
 
 
 def gn(name, c, hw):
@@ -77,6 +106,9 @@ def gn(name, c, hw):
     nbytes = x.numel() * x.element_size()
     cases.append((name + ".stats", a, -float(nbytes)))
     cases.append((name + ".apply", bb, -2.0 * nbytes))
+    if args.vendor:
+        xv, gv, bv = x.permute(0, 3, 1, 2), g.to(dt), b.to(dt)
+        vendor[name + ".apply"] = lambda xv=xv, gv=gv, bv=bv: F.silu(F.group_norm(xv, 32, gv, bv, 1e-5))        # (statistics + apply + SiLU together)
 
 
 def ln(name, M, c):
@@ -188,7 +220,24 @@ for name, l, work in cases:
         torch.cuda.synchronize()
         us2 = s.elapsed_time(e) / (n // 2) * 1e3
         sus = f"   sustained {us2:10.1f} us  {abs(work) / us2 / (1e6 if work > 0 else 1e3):9.1f}"
+    ven = ""
+    if name in vendor:
+        fn = vendor[name]
+        try:
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            s.record(stream)
+            for _ in range(args.reps):
+                fn()
+            e.record(stream)
+            torch.cuda.synchronize()
+            vus = s.elapsed_time(e) / args.reps * 1e3
+            ven = f"   | vendor {vus:10.1f} us  {abs(work) / vus / (1e6 if work > 0 else 1e3):9.1f}  (ours / vendor time {us / vus:5.2f})"
+            results.append(dict(name=name + " [vendor]", us=vus, rate=abs(work) / vus / (1e6 if work > 0 else 1e3), unit=unit))
+        except Exception as ex:          # a shape the vendor kernel does not take
+            ven = f"   | vendor: {type(ex).__name__}: {str(ex)[:80]}"
     results.append(dict(name=name, us=us, rate=rate, unit=unit))
-    print(f"{name:32s} {us:10.1f} us  {rate:9.1f} {unit}{sus}", flush=True)
+    print(f"{name:32s} {us:10.1f} us  {rate:9.1f} {unit}{sus}{ven}", flush=True)
 if args.json:
     json.dump(results, open(args.json, "w"), indent=1)
