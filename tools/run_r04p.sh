@@ -1,4 +1,5 @@
 #!/bin/bash
+# (recreate the round-3 tree first:  git worktree add -f _r03 a43a2ba && (cd _r03 && python -c "import __graft_entry__ as g; g.build()") )
 # r04p: the round-3 final tree (git worktree of a43a2ba under _r03/, its own library built from its own sources) against this tree, SAME box, alternating
 mkdir -p gpurun_out/r04p
 F="--steps 4 --warmup 1 --no-cpu-baseline --no-roofline --no-conditioning --no-parity"
