@@ -119,7 +119,7 @@ def cpu_baseline(cpu_sd, cores):
     torch.set_num_threads(cores)
     usd, vsd = cpu_sd
     ucfg, vcfg = P.UNetConfig(), P.VAEConfig()
-    plan = P.unet_plan(ucfg)
+    plan = ounet.plan_of(usd, ucfg.num_heads)          # the oracle reads the block structure off the checkpoint layout itself (oracle.unet.plan_from_shapes)
     x = P.seeded_randn((2, 9, 64, 64), 1)
     t = torch.full((2,), 981, dtype=torch.long)
     c = P.seeded_randn((2, 1, 768), 2)

@@ -108,8 +108,54 @@ def _run_block(sd, prefix, layers, h, emb, context):
     return h
 
 
+def plan_from_shapes(shapes, num_heads=8):
+    """The block structure, read off the CHECKPOINT itself: ``shapes`` = {state-dict key: shape} in the reference's key layout (what
+    ``UNetModel.state_dict()`` of openaimodel.py:666-830 produces; tests/golden/unet_full_keys.json holds the reference's own list).
+    Child j of ``input_blocks.i`` / ``output_blocks.i`` / ``middle_block`` is a ResBlock when it owns ``in_layers.2.weight`` (cin, cout from
+    its shape), a SpatialTransformer when it owns ``proj_in.weight``, a Downsample when it owns ``op.weight``, an Upsample when it owns
+    ``conv.weight``, the stem conv when the weight hangs on the child directly.  Independent of reface_amd.params.unet_plan (product
+    code), which tests/test_oracle_golden.py compares it with.  Same tuple vocabulary as unet_forward's ``plan``."""
+    def children(prefix):
+        out = {}
+        for k in shapes:
+            if k.startswith(prefix + "."):
+                out.setdefault(int(k[len(prefix) + 1:].split(".")[0]), []).append(k)
+        return [out[j] for j in sorted(out)]
+
+    def layers_of(prefix):
+        ls = []
+        for j, keys in enumerate(children(prefix)):
+            q = f"{prefix}.{j}"
+            if f"{q}.in_layers.2.weight" in shapes:
+                co, ci = shapes[f"{q}.in_layers.2.weight"][:2]
+                ls.append(("res", int(ci), int(co)))
+            elif f"{q}.proj_in.weight" in shapes:
+                ch = int(shapes[f"{q}.proj_in.weight"][0])
+                ls.append(("st", ch, num_heads, ch // num_heads))
+            elif f"{q}.op.weight" in shapes:
+                ls.append(("down", int(shapes[f"{q}.op.weight"][0])))
+            elif f"{q}.conv.weight" in shapes:
+                ls.append(("up", int(shapes[f"{q}.conv.weight"][0])))
+            elif f"{q}.weight" in shapes:
+                co, ci = shapes[f"{q}.weight"][:2]
+                ls.append(("conv", int(ci), int(co)))
+            else:
+                raise KeyError(f"unrecognised block {q}: {keys[:3]}")
+        return ls
+
+    n_in = 1 + max(int(k.split(".")[1]) for k in shapes if k.startswith("input_blocks."))
+    n_out = 1 + max(int(k.split(".")[1]) for k in shapes if k.startswith("output_blocks."))
+    return ([layers_of(f"input_blocks.{i}") for i in range(n_in)], layers_of("middle_block"), [layers_of(f"output_blocks.{i}") for i in range(n_out)])
+
+
+def plan_of(sd, num_heads=8):
+    """plan_from_shapes of a state dict (tensors)."""
+    return plan_from_shapes({k: tuple(v.shape) for k, v in sd.items()}, num_heads)
+
+
 def unet_forward(sd, plan, x, timesteps, context, model_channels=320):
-    """openaimodel.py:860-907.  ``plan`` = reface_amd.params.unet_plan(cfg) (pure structure)."""
+    """openaimodel.py:860-907.  ``plan`` = the block structure: plan_from_shapes of the state dict (the oracle's own reading of the checkpoint),
+    or reface_amd.params.unet_plan(cfg) -- tests/test_oracle_golden.py holds the two equal on the reference's key list."""
     ib, mid, ob = plan
     emb = time_embed(sd, timestep_embedding(timesteps, model_channels))
     hs = []

@@ -170,7 +170,7 @@ def _oracle_chain_check(dump_npz, png_path, S, scale, rows=(0,)):
         m64 = oenc.mask64(inp_mask)
         assert maxerr(m64, d["mask64"][r]) == 0
         uc = heads["learnable_vector"].repeat(B, 1, 1)
-        plan = P.unet_plan(ucfg)
+        plan = ounet.plan_of(usd, ucfg.num_heads)
         samples, _ = oddim.sample(lambda x, t, cc: ounet.unet_forward(usd, plan, x, t, cc, ucfg.model_channels), S, x_T, c, uc, z_inp, m64, scale)
         assert maxerr(samples, d["samples"][r]) < 5e-4, maxerr(samples, d["samples"][r])
         x_dec = ovae.decode_first_stage(vsd, vcfg, samples)

@@ -62,6 +62,12 @@ def _pair_inputs(hw):
     return torch.cat([x1, x1]), torch.full((2,), 481, dtype=torch.long), rnd((2, 1, 768), 401)
 
 
+def _oracle_plan(sd, cfg):
+    """The oracle's own reading of the block structure, off the checkpoint layout (oracle.unet.plan_from_shapes) -- not the product's unet_plan."""
+    from oracle import unet as ounet
+    return ounet.plan_of(sd, cfg.num_heads)
+
+
 def _oracle_pair(sd, plan, hw, key="orig"):
     """oracle.unet.unet_forward on one CFG pair (same x and t, two contexts) at latent hw x hw; computed once per (weights, size)."""
     from oracle import unet as ounet
@@ -101,7 +107,7 @@ def _gemm_tile_set(eng, M, N):
 def test_unet_full_width_full_size_vs_oracle(full_unet, hw):
     """One CFG pair (batch 2: same x and t, different context) of the full-width UNet at the configured latent size."""
     m, sd = full_unet
-    plan = P.unet_plan(m.cfg)
+    plan = _oracle_plan(sd, m.cfg)
     x, t, ctx = _pair_inputs(hw)
     ref = _oracle_pair(sd, plan, hw)
     scale = ref.abs().max().item()
@@ -148,7 +154,7 @@ def test_unet_bf16_batch16_cfg_matches_oracle_rows(full_unet):
     Sample 0 / sample 8 (one CFG pair) must match the oracle's result for that pair; the other pairs use different x."""
     from oracle import unet as ounet
     m, sd = full_unet
-    plan = P.unet_plan(m.cfg)
+    plan = _oracle_plan(sd, m.cfg)
     hw, B = 64, 8
     xs = rnd((B, 9, hw, hw), 410)
     x = torch.cat([xs, xs])
@@ -188,7 +194,7 @@ def test_unet_bf16_c3_engine_shape_matches_oracle_rows(full_unet):
     be two rounds on 256 CUs with the second 12 % full, so the dispatcher takes the quarter-size 128x160 tile at two blocks per CU
     (gemm.hip, wave-quantisation branch) -- the instantiation only this M reaches.  Rows 0 / 4 (one CFG pair) vs the oracle's pair."""
     m, sd = full_unet
-    plan = P.unet_plan(m.cfg)
+    plan = _oracle_plan(sd, m.cfg)
     hw, B = 96, 4
     x2, t, ctx2 = _pair_inputs(hw)
     ref = _oracle_pair(sd, plan, hw)
@@ -238,7 +244,7 @@ def test_unet_fp8_c4_engine_shape_matches_oracle_rows(full_unet, mode):
     tolerance); for "fp8" the distance also contains the 3-mantissa-bit activation rounding (stated bound; the per-GEMM exactness on
     dequantised operands is pinned in test_ops_gpu.py::test_linear_fp8_act / test_conv_fp8_act and below at M = 131072)."""
     m, sd = full_unet
-    plan = P.unet_plan(m.cfg)
+    plan = _oracle_plan(sd, m.cfg)
     hw, B = 64, 16
     x2, t, ctx2 = _pair_inputs(hw)
     xs = rnd((B, 9, hw, hw), 414)
@@ -669,7 +675,7 @@ def test_full_width_ddim5_decode_vs_oracle(full_unet, full_vae, mode):
                                     test_model_kwargs={"inpaint_image": z_inp.to(DEV), "inpaint_mask": mask.to(DEV)})
     img = vae.decode(got, inv_scale=1.0 / 0.18215)
     torch.cuda.synchronize()
-    plan = P.unet_plan(m.cfg)
+    plan = _oracle_plan(usd, m.cfg)
     if not _DDIM5_REF:
         _oracle_threads()
         with torch.no_grad():
@@ -759,7 +765,7 @@ def test_unet_fp8_weights_vs_oracle_on_dequantised_weights(full_unet):
     from oracle import unet as ounet
     from reface_amd.unet import UNetModel
     m, sd = full_unet
-    plan = P.unet_plan(m.cfg)
+    plan = _oracle_plan(sd, m.cfg)
     hw = 32
     x1 = rnd((1, 9, hw, hw), 470)
     x = torch.cat([x1, x1])

@@ -82,10 +82,28 @@ def test_spatial_transformer(golden_dir, tag, c, hw):
     close(y, g[f"st_{tag}_y"], 2e-5, 1e-5)
 
 
+def test_unet_block_structure_from_the_reference_key_layout(golden_dir):
+    """oracle.unet.plan_from_shapes reads the block structure off a checkpoint's keys / shapes.  On the REFERENCE's own key list
+    (tests/golden/unet_keys.json: state_dict of the reference's UNetModel, openaimodel.py:666-830, for the REFace configuration and a small
+    one; tools/gen_golden.py unet_keys) it must give what the product derives from the constructor arguments (params.unet_plan), and the
+    product's parameter specs must BE that key list -- so a structural slip in either derivation shows up here, on the CPU."""
+    import json
+    ref = json.load(open(os.path.join(golden_dir, "unet_keys.json")))
+    for tag in ("full", "small"):
+        cfg = P.UNetConfig(**ref[tag]["config"])
+        shapes = {k: tuple(v) for k, v in ref[tag]["shapes"].items()}
+        assert unet.plan_from_shapes(shapes, cfg.num_heads) == tuple(P.unet_plan(cfg)), tag
+        specs = {k: tuple(v) for k, v in P.unet_param_specs(cfg).items()}
+        assert specs == shapes, (tag, sorted(set(specs) ^ set(shapes))[:6])
+    n_res = sum(1 for blk in unet.plan_from_shapes({k: tuple(v) for k, v in ref["full"]["shapes"].items()})[0] + unet.plan_from_shapes(
+        {k: tuple(v) for k, v in ref["full"]["shapes"].items()})[2] for l in blk if l[0] == "res")
+    assert n_res == 20          # 8 + 12 ResBlocks around the middle block's two (openaimodel.py: 2 per level down, 3 per level up)
+
+
 def _small_unet():
     cfg = P.UNetConfig(**SMALL_UNET)
     sd = P.seeded_state_dict(P.unet_param_specs(cfg), 7)
-    return cfg, sd, P.unet_plan(cfg)
+    return cfg, sd, unet.plan_of(sd, cfg.num_heads)          # the oracle reads the block structure off the checkpoint layout itself (oracle.unet.plan_from_shapes)
 
 
 def test_unet_small(golden_dir):
@@ -102,7 +120,7 @@ def test_unet_full_width(golden_dir):
     cfg = P.UNetConfig()
     sd = P.seeded_state_dict(P.unet_param_specs(cfg), 1234)
     assert sum(v.numel() for v in sd.values()) == 859_535_364      # 859.54 M
-    plan = P.unet_plan(cfg)
+    plan = unet.plan_of(sd, cfg.num_heads)
     g = G(golden_dir, "unet_full_8")
     y = unet.unet_forward(sd, plan, rnd((2, 9, 8, 8), 20), torch.from_numpy(g["t"]), rnd((2, 1, 768), 21))
     close(y, g["y"], 5e-5, 1e-5)
@@ -253,7 +271,7 @@ def test_e2e_small(golden_dir):
     alt = 0.25 * (inpaint_mask[..., 3::8, 3::8] + inpaint_mask[..., 3::8, 4::8]
                   + inpaint_mask[..., 4::8, 3::8] + inpaint_mask[..., 4::8, 4::8])
     close(alt, g["mask64"], 0)
-    plan = P.unet_plan(ucfg)
+    plan = unet.plan_of(usd, ucfg.num_heads)
     eps_fn = lambda x, t, cc: unet.unet_forward(usd, plan, x, t, cc, ucfg.model_channels)
     samples, _ = ddim.sample(eps_fn, 5, x_T, c, uc, z_inp, m64, 3.5)
     close(samples, g["samples"], 2e-4)

@@ -188,7 +188,7 @@ def test_ddim_no_cfg_matches_oracle():
     unet = make_unet(SMALL_UNET, 7)
     cfg = P.UNetConfig(**SMALL_UNET)
     sd = P.seeded_state_dict(P.unet_param_specs(cfg), 7)
-    plan = P.unet_plan(cfg)
+    plan = ounet.plan_of(sd, cfg.num_heads)
     x_T, z_inp, mask, c, uc = _ddim_inputs()
     ref, _ = oddim.sample(lambda x, t, cc: ounet.unet_forward(sd, plan, x, t, cc, 64), 5, x_T, c, None, z_inp, mask, 1.0)
     sampler = DDIMSampler(_LDMStub(unet))

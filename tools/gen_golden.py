@@ -146,6 +146,26 @@ def gen_unet_full():
     save("unet_full_16", t=t, y=m(x, t, context=ctx), seed=1234)
 
 
+def gen_unet_keys():
+    """{state-dict key: shape} of the REFERENCE's full-width UNetModel (openaimodel.py:666-830, the REFace configuration) and of a small
+    configuration with a different channel_mult / attention pattern: what oracle.unet.plan_from_shapes reads the block structure from."""
+    import json
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    out = {}
+    for tag, cfg in (("full", P.UNetConfig()),
+                     ("small", P.UNetConfig(model_channels=32, channel_mult=(1, 2, 4), attention_resolutions=(2, 1), num_res_blocks=1, num_heads=4, context_dim=32))):
+        with torch.device("meta"):
+            m = UNetModel(image_size=32, in_channels=cfg.in_channels, out_channels=cfg.out_channels, model_channels=cfg.model_channels,
+                          attention_resolutions=list(cfg.attention_resolutions), num_res_blocks=cfg.num_res_blocks, channel_mult=list(cfg.channel_mult),
+                          num_heads=cfg.num_heads, use_spatial_transformer=True, transformer_depth=1, context_dim=cfg.context_dim, use_checkpoint=True,
+                          legacy=False, add_conv_in_front_of_unet=False)
+        out[tag] = {"config": {k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.__dict__.items()},
+                    "shapes": {k: list(v.shape) for k, v in m.state_dict().items()}}
+    path = os.path.join(OUT, "unet_keys.json")
+    json.dump(out, open(path, "w"), separators=(",", ":"), sort_keys=True)
+    print(f"  wrote {path}  ({os.path.getsize(path)/1024:.1f} KiB, {len(out['full']['shapes'])} + {len(out['small']['shapes'])} keys)")
+
+
 class _StubLDM:
     """What DDIMSampler reads from the model (ddim.py:100,113-119,207,345)."""
 
@@ -486,7 +506,7 @@ def gen_e2e():
     save("e2e_png", grid=g0, mask=written["a_mask.png"])
 
 
-GROUPS = dict(ddim_full=gen_ddim_full, plms=gen_plms, schedule=gen_schedule, unet_ops=gen_unet_ops, unet_small=gen_unet_small, unet_full=gen_unet_full,
+GROUPS = dict(ddim_full=gen_ddim_full, unet_keys=gen_unet_keys, plms=gen_plms, schedule=gen_schedule, unet_ops=gen_unet_ops, unet_small=gen_unet_small, unet_full=gen_unet_full,
               ddim=gen_ddim, vae=gen_vae, arcface=gen_arcface, clip=gen_clip, e2e=gen_e2e)
 
 if __name__ == "__main__":
