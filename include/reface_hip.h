@@ -120,6 +120,10 @@ typedef struct rf_conv_gemm_desc {
     int32_t ln_in_parts, ln_in_cols;
     float ln_eps;
     const float* ln_u;
+    /* Per-sample weights (plain GEMM, dtype RF_BF16 / RF_F32, no w_dtype): rows [s * rows_per_sample, (s + 1) * rows_per_sample) multiply */
+    /* W + s * w_sample_stride (elements); 0 = one W for all rows.  rows_per_sample must be a multiple of the tile rows (rf_conv_gemm_plan2's BM). */
+    /* What rf_groupnorm_fold_linear writes: a GroupNorm folded into the weights of the Linear / 1x1 conv behind it. */
+    int64_t w_sample_stride;
 } rf_conv_gemm_desc;
 
 int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream);
@@ -165,6 +169,14 @@ int rf_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, int ldx, 
 int rf_groupnorm_finalize(const double* partial_in, int B, int nchunks, double* partial_out, void* stream);
 int rf_groupnorm_apply(int dtype, const void* x, int B, int HW, int C, int ldx, int nchunks, const double* partial,
                        const float* gamma, const float* beta, float eps, int silu, int out_dtype, void* out, int ldo, void* stream);
+/* GroupNorm(32) folded into the Linear / 1x1 conv that follows it (SpatialTransformer: `norm` then `proj_in`, attention.py:262-266 / 276-279):
+ *   Linear(GN(x))[m, n] = sum_k W'_s[n, k] x[m, k] + r_s[n]        for the rows m of sample s, with
+ *   W'_s[n, k] = W[n, k] rstd[s, g(k)] gamma[k]    (rounded to out_dtype)        r_s[n] = bias[n] + sum_k W[n, k] beta[k] - sum_k W'_s[n, k] mean[s, g(k)]
+ * (mean / rstd from the same `partial` records rf_groupnorm_apply reads; the mean's term uses the ROUNDED W' so that it cancels exactly what
+ * the matrix pipe accumulates).  W fp32 [N][C]; w_out [B][N][C] (rf_conv_gemm_desc.w_sample_stride = N * C), rowvec_out fp32 [B][N] (the GEMM's
+ * per-sample vector, no bias).  Replaces the rf_groupnorm_apply pass over [B, HW, C] in front of that Linear: a read + a write of the tensor. */
+int rf_groupnorm_fold_linear(const float* W, int N, int C, int B, int HW, int nchunks, const double* partial, const float* gamma, const float* beta,
+                             const float* bias, float eps, int out_dtype, void* w_out, float* rowvec_out, void* stream);
 
 /* LayerNorm over the last dim of [M, C] (eps, affine).  Replaces nn.LayerNorm (attention.py:231-233,
  * xf.py:22-28, HF CLIP layer norms). */

@@ -40,6 +40,7 @@ class ConvGemmDesc(C.Structure):
         ("oscale", C.c_void_p), ("os_ld", C.c_int32),
         ("ln_stats_out", C.c_void_p), ("ln_out_parts", C.c_int32),
         ("ln_stats_in", C.c_void_p), ("ln_in_parts", C.c_int32), ("ln_in_cols", C.c_int32), ("ln_eps", C.c_float), ("ln_u", C.c_void_p),
+        ("w_sample_stride", C.c_int64),
     ]
 
 
@@ -56,6 +57,8 @@ _SIGS = {
     "rf_groupnorm_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "rf_groupnorm_apply": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "rf_groupnorm_fold_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rf_quantize_fp8_act": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "rf_groupnorm_apply_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                          C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

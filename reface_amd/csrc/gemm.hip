@@ -96,6 +96,7 @@ struct GemmParams {
     int x3;          // split-bf16 operands (RF_BF16X3): K counts VIRTUAL tiles, three per real 64-element K tile -- (A hi, W hi), (A hi, W lo),
                      // (A lo, W hi); W rows hold them in that order, the A lo plane lies lo_off bytes behind the hi plane of the same pixel
     int lo_off;
+    long long w_ps;  // per-sample weights (rf_conv_gemm_desc.w_sample_stride, elements): the rows of sample s multiply W + s * w_ps; 0 = one W
 };
 
 // 8 fp8 (e4m3fn) weights -> 8 bf16, times the row's power-of-two scale: v_cvt_scalef32_pk_bf16_fp8, one instruction per pair (exact:
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
     const T* src0 = (const T*)p.src0 + zb * p.sA;
     const T* src1 = (const T*)p.src1;
     const T* Wp = W8 ? (const T*)((const char*)p.W + zb * p.sW) : (const T*)p.W + zb * p.sW;
+    if (!W8 && p.w_ps) Wp += (long long)(m0 / p.rows_per_sample) * p.w_ps;          // (a tile lies inside one sample: host)
 
     // EPI 1: the per-column constants of this tile (bias + the tile's timestep / context vector) are fetched NOW, one column per
     // thread, and parked in LDS after the main loop: fetched in the epilogue they cost one exposed L2 / HBM round trip per
@@ -1933,6 +1935,8 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     const bool hx = p.korder == 2;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
+    RF_CHECK(!p.w_ps || (p.rows_per_sample > 0 && p.rows_per_sample % BM == 0 && p.M % p.rows_per_sample == 0),
+             "rf_conv_gemm: per-sample weights need rows_per_sample (%d) to be a multiple of the %d-row tile", p.rows_per_sample, BM);
     {
         // Tile order inside each XCD's contiguous run of tiles (8 XCDs, one L2 each): the run touches m_x A panels and n_x W panels.
         // N-fastest keeps an A panel in one L2 (large images); M-fastest keeps a W panel there -- at the 8x8 / 16x16 levels W is the big
@@ -2296,6 +2300,10 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
         p.as_bytes = (unsigned)(a8 ? rows_a * d->as_ld : 0);
         p.x3 = x3 ? 1 : 0;
         p.lo_off = x3 ? d->C0 * 2 : 0;
+        p.w_ps = d->w_sample_stride;
+        RF_CHECK(d->w_sample_stride == 0 || (!conv && !w8 && !a8 && !x3 && d->batch == 1 && d->rows_per_sample > 0 && p.glds &&
+                                             d->w_sample_stride >= (long long)(d->N - 1) * p.ldw + d->K),
+                 "rf_conv_gemm: w_sample_stride needs a plain bf16 / fp32 GEMM on the direct-to-LDS loop, batch 1, rows_per_sample > 0 and a stride of at least one W");
         if (x3) {
             RF_CHECK(p.glds && (conv || d->C0 == d->K), "rf_conv_gemm: split-bf16 operands need the direct-to-LDS main loop (K and channel count multiples of 64) and C0 == K for plain GEMMs");
             p.K = 3 * d->K;          // virtual K: three passes per real K tile

@@ -141,6 +141,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
     {   // reduce the per-chunk partials of sample b: thread -> (group, part)
         const int g = threadIdx.x & 31, part = threadIdx.x >> 5;
         double a = 0.0, q = 0.0;
+#pragma unroll 4
         for (int c = part; c < nchunks; c += GN_THREADS / 32) {
             const double* pp = partial + (((long long)b * nchunks + c) * 32 + g) * 2;
             a += pp[0];
@@ -429,6 +430,125 @@ extern "C" int rf_groupnorm_apply(int dtype, const void* x, int B, int HW, int C
 #undef GN_APPLY
 #undef GN_APPLY_
     RF_LAUNCH_CHECK("rf_groupnorm_apply");
+    return 0;
+}
+
+// ---- GroupNorm folded into the weights of the Linear / 1x1 conv behind it (SpatialTransformer `norm` -> `proj_in`, attention.py:262-266, 276-279).
+// Block (x, s): the statistics of sample s (the preamble of gn_apply_kernel) and GN_FOLD_RPW rows n of W per wave: lane pairs
+// of columns k, W'[s][n][k] = W[n][k] rstd[g(k)] gamma[k] rounded to the GEMM's operand type, and the row's per-sample constant
+// r[s][n] = bias[n] + sum_k W[n][k] beta[k] - sum_k W'[s][n][k] mean[g(k)]   (with the ROUNDED W': what the matrix pipe will accumulate against x).
+constexpr int GN_FOLD_RPW = 2;            // rows per wave: 8 rows per block -- the launch is latency-bound (a W row is 1.3-2.5 KB), so many small blocks
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// NIT = iterations of 8 columns per lane (C <= 512 NIT): 16-byte stores of W'.  Everything that does not depend on the statistics -- the rows of W,
+// gamma, beta -- is in flight before the statistics are reduced (one global-memory latency for the block, not three in a row).
+template <typename TO, int NIT>
+__global__ __launch_bounds__(GN_THREADS) void gn_fold_linear_kernel(const float* __restrict__ W, int N, int C, int HW, int nchunks,
+                                                                    const double* __restrict__ partial, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, const float* __restrict__ bias, float eps,
+                                                                    TO* __restrict__ wout, float* __restrict__ rvout) {
+    const int b = blockIdx.y, cpg = C / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = (blockIdx.x * (GN_THREADS / 64) + wave) * GN_FOLD_RPW;
+    f32x4_t w8[GN_FOLD_RPW][NIT][2], g8[NIT][2], b8[NIT][2];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int k = 8 * lane + 512 * it;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            g8[it][h] = b8[it][h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (k < C) { g8[it][h] = *(const f32x4_t*)(gamma + k + 4 * h); b8[it][h] = *(const f32x4_t*)(beta + k + 4 * h); }
+#pragma unroll
+            for (int r = 0; r < GN_FOLD_RPW; ++r) {
+                w8[r][it][h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (k < C && n0 + r < N) w8[r][it][h] = *(const f32x4_t*)(W + (long long)(n0 + r) * C + k + 4 * h);
+            }
+        }
+    }
+    __shared__ float mean_s[32], rstd_s[32];
+    __shared__ double red[GN_THREADS][2];
+    {
+        const int g = threadIdx.x & 31, part = threadIdx.x >> 5;
+        double a = 0.0, q = 0.0;
+#pragma unroll 4
+        for (int c = part; c < nchunks; c += GN_THREADS / 32) {
+            const double* pp = partial + (((long long)b * nchunks + c) * 32 + g) * 2;
+            a += pp[0];
+            q += pp[1];
+        }
+        red[threadIdx.x][0] = a;
+        red[threadIdx.x][1] = q;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            double sa = 0.0, sq = 0.0;
+            for (int k = 0; k < GN_THREADS / 32; ++k) { sa += red[threadIdx.x + 32 * k][0]; sq += red[threadIdx.x + 32 * k][1]; }
+            const double n = (double)HW * cpg;
+            const double mean = sa / n;
+            double var = sq / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            mean_s[threadIdx.x] = (float)mean;
+            rstd_s[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+        __syncthreads();
+    }
+    float t[GN_FOLD_RPW];
+#pragma unroll
+    for (int r = 0; r < GN_FOLD_RPW; ++r) t[r] = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int k = 8 * lane + 512 * it;
+        if (k < C) {
+            float a[8], m[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int g = (k + e) / cpg;
+                a[e] = rstd_s[g] * g8[it][e >> 2][e & 3];
+                m[e] = mean_s[g];
+            }
+#pragma unroll
+            for (int r = 0; r < GN_FOLD_RPW; ++r) {
+                if (n0 + r < N) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = w8[r][it][e >> 2][e & 3] * a[e];
+                    TO* const wo = wout + ((long long)b * N + n0 + r) * C + k;
+                    if constexpr (sizeof(TO) == 2) {
+                        const u32x4_t pk = pack16<TO>(v);
+                        *(u32x4_t*)wo = pk;
+                        unpack16<TO>(pk, v);          // the values as rounded: what the matrix pipe will multiply x with
+                    } else {
+                        *(f32x4_t*)wo = f32x4_t{v[0], v[1], v[2], v[3]};
+                        *(f32x4_t*)(wo + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[r] += w8[r][it][e >> 2][e & 3] * b8[it][e >> 2][e & 3] - v[e] * m[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < GN_FOLD_RPW; ++r) {
+        float v = t[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0 && n0 + r < N) rvout[(long long)b * N + n0 + r] = v + (bias ? bias[n0 + r] : 0.f);
+    }
+}
+
+extern "C" int rf_groupnorm_fold_linear(const float* W, int N, int C, int B, int HW, int nchunks, const double* partial, const float* gamma,
+                                        const float* beta, const float* bias, float eps, int out_dtype, void* w_out, float* rowvec_out, void* stream) {
+    RF_CHECK(W && partial && gamma && beta && w_out && rowvec_out && N > 0 && B > 0 && HW > 0 && nchunks >= 1, "rf_groupnorm_fold_linear: bad arguments");
+    RF_CHECK(C > 0 && C % 32 == 0 && C <= 1536, "rf_groupnorm_fold_linear: C=%d must be a multiple of 32, at most 1536", C);
+    RF_CHECK(out_dtype == RF_BF16 || out_dtype == RF_F32, "rf_groupnorm_fold_linear: bad out_dtype %d", out_dtype);
+    RF_CHECK((((uintptr_t)W | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)w_out) & 15) == 0, "rf_groupnorm_fold_linear: W / gamma / beta / w_out must be 16-byte aligned");
+    constexpr int RPB = (GN_THREADS / 64) * GN_FOLD_RPW;
+    dim3 grid((N + RPB - 1) / RPB, B);
+    hipStream_t st = (hipStream_t)stream;
+#define GN_FOLD_(TO, NIT) hipLaunchKernelGGL((gn_fold_linear_kernel<TO, NIT>), grid, dim3(GN_THREADS), 0, st, W, N, C, HW, nchunks, partial, gamma, beta, bias, eps, (TO*)w_out, rowvec_out)
+#define GN_FOLD(TO) { if (C <= 512) GN_FOLD_(TO, 1); else if (C <= 1024) GN_FOLD_(TO, 2); else GN_FOLD_(TO, 3); }
+    if (out_dtype == RF_BF16) GN_FOLD(bf16_t) else GN_FOLD(float)
+#undef GN_FOLD
+#undef GN_FOLD_
+    RF_LAUNCH_CHECK("rf_groupnorm_fold_linear");
     return 0;
 }
 

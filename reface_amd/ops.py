@@ -366,7 +366,7 @@ def conv_gemm(src0, W, out, *, M, N, K, C0, ld0, src1=None, C1=0, ld1=0, Hin=1, 
 
 
 def linear(x, W, out, bias=None, *, act=ACT_NONE, residual=None, rowvec=None, rows_per_sample=0, alpha=1.0, act_vec=None, x3=False, ln_u=None,
-           name="linear"):
+           w_per_sample=None, name="linear"):
     """out[M, N] = act(x[M, K] @ W[N, K]^T + bias) (+ residual).  x / out may be row-strided 2-D views.  x3: x is the split-bf16 form
     [M, 2K] of an fp32 matrix and W comes from pack_x3 ([N, 3K])."""
     if x3:
@@ -392,7 +392,27 @@ def linear(x, W, out, bias=None, *, act=ACT_NONE, residual=None, rowvec=None, ro
         assert ln_u.dtype == torch.float32 and ln_u.is_contiguous() and ln_u.numel() == N
         l.keep[0].ln_u = _p(ln_u)
         l.keep = tuple(l.keep) + (ln_u,)
+    if w_per_sample is not None:          # [S, N, K] weights, W = w_per_sample[0]: the rows of sample s multiply w_per_sample[s] (groupnorm_fold_linear)
+        assert w_per_sample.is_contiguous() and w_per_sample.shape[1:] == W.shape and W.data_ptr() == w_per_sample.data_ptr() and rows_per_sample > 0
+        assert M == w_per_sample.shape[0] * rows_per_sample
+        l.keep[0].w_sample_stride = N * K
+        l.keep = tuple(l.keep) + (w_per_sample,)
     return l
+
+
+def groupnorm_fold_linear(W, gamma, beta, bias, partial, nchunks, *, B, HW, eps, dtype, name="groupnorm.fold"):
+    """GroupNorm(32) folded into the Linear / 1x1 conv behind it (rf_groupnorm_fold_linear): W fp32 [N, C] -> (launch, W' [B, N, C] in `dtype`,
+    per-sample vector fp32 [B, N]).  The GEMM then reads the UN-normalised tensor: linear(x, W'[0], out, None, rowvec=vec, rows_per_sample=HW,
+    w_per_sample=W') -- the rf_groupnorm_apply pass (a read + a write of [B, HW, C]) and the normalised copy are gone."""
+    lib = _lib.load()
+    N, Cc = W.shape
+    _require_gpu(W, gamma, beta, partial)
+    assert W.dtype == torch.float32 and W.is_contiguous() and Cc % 32 == 0 and partial.dtype == torch.float64
+    wout = torch.empty((B, N, Cc), dtype=dtype, device=W.device)
+    rv = torch.empty((B, N), dtype=torch.float32, device=W.device)
+    l = Launch(lib.rf_groupnorm_fold_linear, (_p(W), N, Cc, B, HW, nchunks, _p(partial), _p(gamma), _p(beta), _p(bias), float(eps), code(dtype), _p(wout), _p(rv)),
+               (W, gamma, beta, bias, partial, wout, rv), name)
+    return l, wout, rv
 
 
 def conv2d(x, W, out, bias=None, *, ksize=3, stride=1, pad=(1, 1), ups=0, x2=None, residual=None, rowvec=None,
@@ -439,6 +459,16 @@ def _gn_out_code(x, out, split):
         assert x.dtype == torch.float32 and out.dtype == torch.bfloat16 and out.shape[-1] == 2 * x.shape[-1]
         return RF_BF16X3
     return code(out.dtype)
+
+
+def groupnorm_stats(x, partial, name="groupnorm"):
+    """The statistics pass alone -> (launch, chunks per sample)."""
+    lib = _lib.load()
+    B, H, W_, Cc = x.shape
+    n = gn_chunks(B, H * W_)
+    _require_gpu(x, partial)
+    assert partial.dtype == torch.float64 and partial.numel() >= B * n * 64
+    return Launch(lib.rf_groupnorm_stats, (code(x.dtype), _p(x), B, H * W_, Cc, x.stride(2), n, _p(partial)), (x, partial), name + ".stats"), n
 
 
 def groupnorm(x, gamma, beta, out, partial, *, eps, silu, split=False, name="groupnorm"):

@@ -111,6 +111,10 @@ class UNetEngine:
         self.ln_fold_gemm = os.environ.get("REFACE_LN_FOLD_GEMM", "1") == "1"
         # row-extended A tiles for the 3x3 stride-1 convolutions (korder 2): REFACE_HX=0 keeps the tap-major K order
         self.hx_on = os.environ.get("REFACE_HX", "1") == "1"
+        # SpatialTransformer.norm (GroupNorm, no SiLU) folded into proj_in's weights per sample (rf_groupnorm_fold_linear): REFACE_GN_FOLD=0 keeps the pass
+        self.gn_fold_lin = os.environ.get("REFACE_GN_FOLD", "1") == "1"
+        self.gn_fold_maxc = int(os.environ.get("REFACE_GN_FOLD_MAXC", "640"))
+        self.n_gn_folded = 0
         self.n_hx = 0
         self.n_ln_folded = 0
         self.n_cu = torch.cuda.get_device_properties(device).multi_processor_count if torch.cuda.is_available() else 256
@@ -320,6 +324,21 @@ class UNetEngine:
                                        silu=silu, split=split, name=key)
         return out
 
+    def _gn_stats(self, x):
+        """GroupNorm(32) statistics of x alone (no normalised copy): from the producing GEMMs' epilogues when they can, else the statistics pass.
+        -> (partial, chunks per sample); the launches are appended."""
+        if self.gn_fuse:
+            prods = self.tracker.producers(x)
+            if prods is not None:
+                fused = ops.fuse_groupnorm_stats(x, prods)
+                if fused is not None:
+                    self.main += fused[2]
+                    self.gn_fused += 1
+                    return fused[0], fused[1]
+        l, n = ops.groupnorm_stats(x, self.gn_partial)
+        self.main.append(l)
+        return self.gn_partial, n
+
     def _res(self, p, x, cin, cout, dst):
         B, H, W, _ = x.shape
         t1 = self._gn(x, f"{p}.in_layers.0", 1e-5, True, fp8=self.a8, split=self.x3_ok(9 * cin, cin))
@@ -367,12 +386,25 @@ class UNetEngine:
         t = f"{p}.transformer_blocks.0"
         nb = 2 if pair else 1                   # batch fan-out at the cross-attention
         a8 = self.a8
-        g = self._gn(x, f"{p}.norm", 1e-6, False, fp8=a8)
         tok = self.pool.get((M, c), self.dt)
         w_pi = self.sd[f"{p}.proj_in.weight"].reshape(c, c)
-        l_pi = ops.linear(g.view(M, c), self.gw8(w_pi, 1, c) if a8 else self.gw(w_pi), tok, self.f32(f"{p}.proj_in.bias"), name=f"{p}.proj_in")
+        l_pi = None
+        if self.gn_fold_lin and self.dt == torch.bfloat16 and not a8 and not self.w8 and c <= self.gn_fold_maxc and x.is_contiguous() and (H * W) % 256 == 0:
+            # `norm` folded into proj_in (bf16 mode, C <= 640: B x C x C folded weights cost less than the pass they replace): the statistics of x
+            # scale W's columns per sample, proj_in multiplies the UN-normalised x, the mean / beta terms ride in its per-sample vector
+            part, nch = self._gn_stats(x)
+            fl, wps, rv = ops.groupnorm_fold_linear(w_pi.float().contiguous(), self.f32(f"{p}.norm.weight"), self.f32(f"{p}.norm.bias"),
+                                                    self.f32(f"{p}.proj_in.bias"), part, nch, B=B, HW=H * W, eps=1e-6, dtype=self.dt, name=f"{p}.norm.fold")
+            cand = ops.linear(x.view(M, c), wps[0], tok, None, rowvec=rv, rows_per_sample=H * W, w_per_sample=wps, name=f"{p}.proj_in")
+            ops.gemm_plan2(cand)          # (raises if a tile would straddle samples: H W is a multiple of every tile height)
+            self.main.append(fl)
+            l_pi = cand
+            self.n_gn_folded += 1
+        if l_pi is None:
+            g = self._gn(x, f"{p}.norm", 1e-6, False, fp8=a8)
+            l_pi = ops.linear(g.view(M, c), self.gw8(w_pi, 1, c) if a8 else self.gw(w_pi), tok, self.f32(f"{p}.proj_in.bias"), name=f"{p}.proj_in")
+            (self.aput if a8 else self.pool.put)(g)
         self.main.append(l_pi)
-        (self.aput if a8 else self.pool.put)(g)
         ln = self.aget((M, c)) if a8 else self.pool.get((M, c), self.dt)
         qkv = self.pool.get((M, 3 * c), self.dt)
         # to_q carries d^-0.5 * log2(e): the scores reach the attention kernels in the exp2 domain (scale = ln 2 below) -- the product

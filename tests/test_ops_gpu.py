@@ -727,6 +727,45 @@ def _split_ref(x):
     return hi, lo
 
 
+@pytest.mark.parametrize("B,hw,c", [(4, 32, 320), (2, 32, 640), (3, 16, 320)])
+def test_groupnorm_folded_into_linear(B, hw, c):
+    """SpatialTransformer `norm` (GroupNorm 32, eps 1e-6, no SiLU) folded into proj_in (attention.py:262-266, 276-279): rf_groupnorm_fold_linear
+    scales W's columns per sample from the GroupNorm statistics, rf_conv_gemm multiplies the UN-normalised tensor with per-sample weights
+    (w_sample_stride) and adds the per-sample vector.  Against the fp32 reference Linear(GroupNorm(x)) on the bf16-rounded x, beside the unfused
+    bf16 pair (normalise pass + GEMM) -- the fold must not be less accurate than what it replaces."""
+    dt = torch.bfloat16
+    HW = hw * hw
+    x, xr = q(rnd((B, hw, hw, c), 310) * 1.5 + rnd((B, 1, 1, c), 311) * 2.0, dt)          # channel offsets: means far from 0
+    w = rnd((c, c), 312) / math.sqrt(c)
+    bias = rnd((c,), 313)
+    g, be = rnd((c,), 314) * 0.3 + 1, rnd((c,), 315) * 0.3
+    ref = F.linear(F.group_norm(xr.permute(0, 3, 1, 2), 32, g, be, 1e-6).permute(0, 2, 3, 1), w, bias)
+    part = torch.empty(B * ops.GN_MAX_CHUNKS * 64, dtype=torch.float64, device=DEV)
+    ls, n = ops.groupnorm_stats(x, part)
+    fl, wps, rv = ops.groupnorm_fold_linear(w.to(DEV), g.to(DEV), be.to(DEV), bias.to(DEV), part, n, B=B, HW=HW, eps=1e-6, dtype=dt)
+    out = torch.empty((B * HW, c), dtype=dt, device=DEV)
+    lg = ops.linear(x.view(B * HW, c), wps[0], out, None, rowvec=rv, rows_per_sample=HW, w_per_sample=wps)
+    plan = ops.gemm_plan2(lg)
+    if HW % plan["bm"]:
+        with pytest.raises(ops._lib.RefaceHipError):          # a tile would straddle samples: refused, not mis-computed
+            lg()
+        return
+    ls(); fl(); lg()
+    # the unfused pair
+    xn = torch.empty_like(x)
+    out2 = torch.empty_like(out)
+    a, b_ = ops.groupnorm(x, g.to(DEV), be.to(DEV), xn, part, eps=1e-6, silu=False)
+    a(); b_()
+    ops.linear(xn.view(B * HW, c), w.to(dt).to(DEV), out2, bias.to(DEV))()
+    torch.cuda.synchronize()
+    e_fold = ((out.float().cpu().view(ref.shape) - ref).norm() / ref.norm()).item()
+    e_pair = ((out2.float().cpu().view(ref.shape) - ref).norm() / ref.norm()).item()
+    print(f"GroupNorm folded into Linear (B {B}, {hw}x{hw}, C {c}): rel L2 {e_fold:.2e} (normalise pass + GEMM: {e_pair:.2e})")
+    assert e_fold < 8e-3 and e_fold < 1.5 * e_pair + 1e-3, (e_fold, e_pair)
+    # per-sample weights really are per sample
+    assert not torch.equal(wps[0], wps[1])
+
+
 def test_split_bf16_kernel_bit_exact():
     x = rnd((3, 5, 7, 64), 900) * 3.0
     out = torch.zeros((3, 5, 7, 128), dtype=torch.bfloat16, device=DEV)
