@@ -989,6 +989,12 @@ static int launch_attn(const AttnParams& p, int B, hipStream_t st) {
             return launch_attn_qb<T, D, 2>(p, B, st);
         }
     }
+    // d = 80 (the 32x32 / 48x48 levels): 128 keys per stage and 8 waves per block -- both waves of a SIMD share one staged K / V tile, half the barriers;
+    // 73 us against 85 at N = 1024 (tools/run_r04x.sh: 64-key stages with 8 waves 85, 128-key stages with 4 waves 105, two query blocks per wave 81-99).
+    // d = 160 keeps the 4-wave / 64-key form (N = 256: four stages of 64 keys already cover the sequence).
+    if constexpr (sizeof(T) == 2 && D == 80) {
+        if (p.Nk >= 512 && (long long)((p.Nq + 255) / 256) * B * p.heads >= 256) return launch_attn_qb<T, D, 1, 128, 8>(p, B, st);
+    }
     return launch_attn_qb<T, D, 1>(p, B, st);
 }
 
