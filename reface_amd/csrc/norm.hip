@@ -413,9 +413,10 @@ extern "C" int rf_groupnorm_apply(int dtype, const void* x, int B, int HW, int C
     RF_CHECK(out_dtype == RF_F32 || out_dtype == RF_BF16 || split, "rf_groupnorm_apply: bad out_dtype");
     RF_CHECK(!split || (dtype == RF_F32 && ldo >= 2 * C), "rf_groupnorm_apply: split-bf16 output needs fp32 input and ldo >= 2C");
     RF_CHECK(ldo % 8 == 0, "rf_groupnorm_apply: ldo=%d must be a multiple of 8", ldo);
-    // blocks of >= ~16 pixels, about 4 blocks per CU in total
+    // about 4 blocks per CU in total, down to 2 pixels per block: the launches of the 16x16 / 8x8 levels are latency chains (statistics -> scale / shift -> pixels
+    // one after the other), 16 pixels per block left them at ~10 us whatever the tensor's size (2 pixels: -0.85 % per batch, profiles/r04ab_gn_apply_blocks.txt)
     int achunks = (1024 + B - 1) / B;
-    const int maxc = (HW + 15) / 16;
+    const int maxc = (HW + 1) / 2;
     if (achunks > maxc) achunks = maxc;
     if (achunks < 1) achunks = 1;
     dim3 grid(achunks, B);
@@ -559,7 +560,7 @@ extern "C" int rf_groupnorm_apply_fp8(const void* x, int B, int HW, int C, int l
     RF_CHECK((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 && ((uintptr_t)q & 7) == 0, "rf_groupnorm_apply_fp8: gamma / beta / q alignment");
     RF_CHECK(ldq >= C && ldq % 8 == 0 && lds >= C / 32, "rf_groupnorm_apply_fp8: ldq=%d lds=%d for C=%d", ldq, lds, C);
     int achunks = (1024 + B - 1) / B;
-    const int maxc = (HW + 15) / 16;
+    const int maxc = (HW + 1) / 2;          // (as rf_groupnorm_apply)
     if (achunks > maxc) achunks = maxc;
     if (achunks < 1) achunks = 1;
     dim3 grid(achunks, B);
