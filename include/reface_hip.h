@@ -178,6 +178,18 @@ int rf_groupnorm_apply(int dtype, const void* x, int B, int HW, int C, int ldx, 
 int rf_groupnorm_fold_linear(const float* W, int N, int C, int B, int HW, int nchunks, const double* partial, const float* gamma, const float* beta,
                              const float* bias, float eps, int out_dtype, void* w_out, float* rowvec_out, void* stream);
 
+/* GroupNorm(32) + SiLU + 3x3 convolution (stride 1, pad 1) to No <= 4 output channels in one pass over the RAW tensor -- the UNet's `out` head
+ * (openaimodel.py:737-741: normalization(ch), nn.SiLU(), conv_nd(dims, model_channels, out_channels, 3, padding=1)): x bf16 [B][H*W][ldx] un-normalised,
+ * `partial` its GroupNorm partial sums (the records rf_groupnorm_apply reads), W bf16 [No][9 C] (k = tap * C + c), out [B*H*W][ldo] fp32 / bf16.
+ * Kernel 1 normalises + activates every pixel's C values in registers (rounded to bf16 as the apply pass stores them) and multiplies them with
+ * all nine taps' weights on the matrix pipe (per-tap partial products, fp32, into `workspace`: B*H*W * 160 bytes); kernel 2 sums, per output pixel,
+ * the taps whose source pixel lies inside the image.  Replaces rf_groupnorm_apply + rf_conv_gemm for this layer: one read of the tensor instead of a
+ * write + nine tap-shifted reads.  C in {320, 128, 64}. */
+int rf_gn_silu_conv3x3_small(const void* x, int B, int H, int W, int C, int ldx, int nchunks, const double* partial, const float* gamma,
+                             const float* beta, float eps, int silu, const void* w, const float* bias, int No, int out_dtype, void* out, int ldo,
+                             float* workspace, long long workspace_bytes, void* stream);
+
+
 /* LayerNorm over the last dim of [M, C] (eps, affine).  Replaces nn.LayerNorm (attention.py:231-233,
  * xf.py:22-28, HF CLIP layer norms). */
 int rf_layernorm(int dtype, const void* x, int M, int C, int ldx, const float* gamma, const float* beta, float eps,
@@ -275,7 +287,7 @@ int rf_mul_mask(const float* x, const float* mask, int B, int C, int HW, float* 
 /*
  * rf_resize_u8_linear : cv2.resize(img, (Wo, Ho), interpolation=cv2.INTER_LINEAR) of uint8 HWC images [B, H, W, C] (image b at
  * x + b * image_stride bytes) -> uint8 [B, Ho, Wo, C]: what albumentations' A.Resize(224, 224) runs on the source face
- * (ldm/data/test_bench_dataset.py:141-148, 324; scripts/inference_swap_selected.py:525-553).  OpenCV's integer algorithm bit for bit
+ * (ldm/data/test_bench_dataset.py:141-148, 324; scripts/inference_swap_selected.py:525-553).  OpenCV's integer algorithm and operation order (no cv2-generated golden exists here: last bit unpinned)
  * (half-pixel centres, two taps per axis, 11-bit weights, NO antialiasing; exact 2:1 -> the fast-area average); cv2 itself is a
  * third-party dependency absent from /root/reference and from this image: see reface_amd/data.py::resize_u8_linear for the restatement.
  */

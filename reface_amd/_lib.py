@@ -59,6 +59,8 @@ _SIGS = {
                                      C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "rf_groupnorm_fold_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rf_gn_silu_conv3x3_small": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]),
     "rf_quantize_fp8_act": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "rf_groupnorm_apply_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                          C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

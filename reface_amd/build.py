@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libreface_hip.so")
-SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "encoder.hip", "ffn.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "encoder.hip", "ffn.hip", "smallconv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 # per-file extras.  attention: keep MFMA accumulators in VGPRs -- the online softmax reads every score and rescales O each
 # tile, and with AGPR accumulators hipcc emitted ~160 v_accvgpr_read/write per KV tile (40 % of the loop's VALU work).
@@ -34,12 +34,18 @@ def _digest(paths, extra):
     return h.hexdigest()
 
 
+_HIPCC_ID = {}
+
+
 def _hipcc_id(hipcc):
-    try:
-        out = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
-        return " ".join(l.strip() for l in out.splitlines() if "version" in l.lower())          # (no install paths: the key must not depend on them)
-    except OSError:
-        return "unknown"
+    """Compiler version string (one `hipcc --version` per process), or None when there is no hipcc on this box."""
+    if hipcc not in _HIPCC_ID:
+        try:
+            out = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+            _HIPCC_ID[hipcc] = " ".join(l.strip() for l in out.splitlines() if "version" in l.lower())          # (no install paths: the key must not depend on them)
+        except OSError:
+            _HIPCC_ID[hipcc] = None
+    return _HIPCC_ID[hipcc]
 
 
 def _read(path):
@@ -55,8 +61,12 @@ def unit_key(unit, hipcc=None):
     `<unit>.o.key`; an object whose key file does not match is rebuilt -- file times play no part (a checkout or a snapshot copy
     sets them arbitrarily)."""
     hipcc = hipcc or os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    src = os.path.join(CSRC, unit)
-    return _digest([src] + HEADERS, FLAGS + EXTRA_FLAGS.get(unit, []) + [_hipcc_id(hipcc)])
+    return _digest([], [source_key(unit), _hipcc_id(hipcc) or "unknown"])
+
+
+def source_key(unit):
+    """The compiler-independent part of a unit's key: sha256 of (source, headers, compile flags)."""
+    return _digest([os.path.join(CSRC, unit)] + HEADERS, FLAGS + EXTRA_FLAGS.get(unit, []))
 
 
 def build(force=False, verbose=True):
@@ -66,6 +76,16 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     force = force or os.environ.get("REFACE_BUILD_FORCE", "0") == "1"
     objs, procs, report = [], [], {}
+    if _hipcc_id(hipcc) is None:
+        # a box that received the prebuilt objects and library but has no compiler: accept them when every unit's SOURCE part (source, headers,
+        # flags) still matches what the stored key was made from -- nothing can be rebuilt here anyway
+        ok = os.path.exists(LIB) and all(_read(os.path.join(LIBDIR, s.replace(".hip", ".o.src"))) == source_key(s) for s in SOURCES)
+        if not ok:
+            raise RuntimeError(f"reface_amd.build: no hipcc at {hipcc} and the prebuilt library is missing or stale (sources changed since it was built)")
+        if verbose:
+            print("[build] no hipcc on this box: prebuilt library accepted (source keys match)", flush=True)
+        build.last_report = {s: {"key": (_read(os.path.join(LIBDIR, s.replace(".hip", ".o.key"))) or "")[:16], "compiled": False} for s in SOURCES}
+        return LIB
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
@@ -87,6 +107,11 @@ def build(force=False, verbose=True):
             raise RuntimeError(f"hipcc failed on {s}")
         with open(obj + ".key", "w") as f:
             f.write(key + "\n")
+    for s in SOURCES:          # the compiler-independent part, kept beside every object (boxes without hipcc check it)
+        srcf = os.path.join(LIBDIR, s.replace(".hip", ".o.src"))
+        if _read(srcf) != source_key(s):
+            with open(srcf, "w") as f:
+                f.write(source_key(s) + "\n")
     # the library's key = the keys of its objects: relinked whenever one of them changed
     lib_key = _digest([], [report[s]["key"] for s in SOURCES])
     if force or procs or not os.path.exists(LIB) or _read(LIB + ".key") != lib_key:

@@ -166,7 +166,7 @@ __global__ void mul_mask_kernel(const float* __restrict__ x, const float* __rest
 }
 
 // cv2.resize(img, (Wo, Ho), interpolation=cv2.INTER_LINEAR) of uint8 HWC images (A.Resize(224, 224) on the source face,
-// ldm/data/test_bench_dataset.py:141-148, 324), bit for bit in OpenCV's integer arithmetic (resize.cpp: HResizeLinear<uchar, int, short,
+// ldm/data/test_bench_dataset.py:141-148, 324), in OpenCV's integer arithmetic and operation order (cv2 itself is absent here: last bit unpinned) (resize.cpp: HResizeLinear<uchar, int, short,
 // 2048> + the u8 VResizeLinear): two taps per axis at half-pixel centres, 11-bit weights rounded to nearest-even, columns clamped
 // with their weight ((s, f) = (0, 0) left of the image, (W - 1, 0) from the last column on), rows clipped with the weights kept;
 //   out = (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2,   Hk = S[yk][sx] * a0 + S[yk][sx + 1] * a1.
@@ -196,8 +196,9 @@ __global__ void resize_u8_linear_kernel(const uint8_t* __restrict__ x, int B, in
         return;
     }
     int sx, a0, a1, sy, b0, b1;
-    cv_linear_tap(dx, (double)W / (double)Wo, W, true, sx, a0, a1);
-    cv_linear_tap(dy, (double)H / (double)Ho, H, false, sy, b0, b1);
+    // (OpenCV's order: inv_scale = dsize / ssize, scale = 1. / inv_scale -- two roundings in double, as reface_amd/data.py:_linear_taps)
+    cv_linear_tap(dx, 1.0 / ((double)Wo / (double)W), W, true, sx, a0, a1);
+    cv_linear_tap(dy, 1.0 / ((double)Ho / (double)H), H, false, sy, b0, b1);
     const int sx1 = min(sx + 1, W - 1), y0 = min(max(sy, 0), H - 1), y1 = min(max(sy + 1, 0), H - 1);
     const uint8_t* r0 = img + (long long)y0 * W * C;
     const uint8_t* r1 = img + (long long)y1 * W * C;

@@ -71,7 +71,9 @@ struct GemmParams {
     int splitk;      // > 1: blockIdx.z owns a K range and writes raw fp32 partial sums to `ws` (epilogue in splitk_reduce_kernel)
     float* ws;       // [splitk][M][N] fp32
     // fused GroupNorm statistics of `out` (rf_conv_gemm_desc.gn_*): up to two consumers with their own channel grouping
-    int mfast;             // tile order inside an XCD's run: 0 N-fastest, 1 M-fastest
+    int pm, pn;            // tile order inside an XCD's run: patches of pm x pn tiles (M-fastest inside a patch), patches N-fastest inside a super-row
+                           // of pm tile rows.  (1, tiles_n) = N-fastest strips, (tiles_m, 1) = M-fastest strips; chosen per launch by estimated
+                           // L2-miss traffic (launch_cfg)
     int gn_rows;
     double* gn_part[2];
     int gn_cpg[2], gn_coff[2], gn_slot[2], gn_nch[2];
@@ -243,8 +245,20 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    // (mfast: M-fastest runs -- the M-tiles that share a W panel hit the same L2; chosen per launch by estimated traffic, launch_cfg)
-    const int tile_m = p.mfast ? bid % p.tiles_m : bid / p.tiles_n, tile_n = p.mfast ? bid / p.tiles_m : bid % p.tiles_n;
+    // ... in 2-D patches: the ~32 tiles an XCD works on at any time (one block per CU) form a pm x pn patch, so that they share pm A panels and
+    // pn W panels (a strip of 32 tiles along N touches every W panel of a wide layer: more than the 4 MB of L2 hold, re-streamed from the
+    // Infinity Cache at ~7 TB/s -- tools/fill_probe.py: 11 B/clk/CU against 50 for L2 hits)
+    int tile_m, tile_n;
+    {
+        const int srow = p.pm * p.tiles_n;                           // tiles per super-row of pm tile rows
+        const int sr = bid / srow, rem = bid - sr * srow;
+        const int h = min(p.pm, p.tiles_m - sr * p.pm);              // (the last super-row may be shorter)
+        const int pw = h * p.pn;
+        const int pc = rem / pw, r2 = rem - pc * pw;
+        const int c = r2 / h;
+        tile_m = sr * p.pm + (r2 - c * h);
+        tile_n = pc * p.pn + c;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const long long zb = blockIdx.y;
@@ -1430,7 +1444,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                         sq = as_f32(sw[0]) + as_f32(sw[1]);
                     }
                     const int row = m0 + (wm * TM + i) * 32 + lrow;
-                    if (lhalf == 0 && row < p.M) *(f32x2_t*)(p.ln_out + ((long long)row * p.ln_out_parts + part) * 2) = f32x2_t{mean, sq};
+                    // (a WN = 2 tile whose BN does not divide N has a wave-tile stripe beyond N: no record -- part would be >= ln_out_parts)
+                    if (lhalf == 0 && row < p.M && part < p.ln_out_parts) *(f32x2_t*)(p.ln_out + ((long long)row * p.ln_out_parts + part) * 2) = f32x2_t{mean, sq};
                 }
             }
         }
@@ -1896,6 +1911,9 @@ __global__ __launch_bounds__(64 * TN) void splitk_reduce_frag_kernel(const GemmP
     }
 }
 
+#ifdef RF_KERNEL_ONLY          // (diagnostics: tools/kernel_regs.sh compiles single instantiations of the kernels above)
+}  // namespace rf
+#else
 // Split-K factor for a launch of `tiles` output tiles, by a two-term cost model: GEMM time at ~600 TFLOP/s stretched by the
 // fraction of the 256 CUs left idle, plus the fp32 partial-sum traffic (write + re-read of sk * M * N floats at ~4 TB/s).
 static int pick_splitk(const rf_conv_gemm_desc* d, const GemmParams& p, long long tiles, int bk) {
@@ -1937,21 +1955,55 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     p.tiles_n = (p.N + BN - 1) / BN;
     RF_CHECK(!p.w_ps || (p.rows_per_sample > 0 && p.rows_per_sample % BM == 0 && p.M % p.rows_per_sample == 0),
              "rf_conv_gemm: per-sample weights need rows_per_sample (%d) to be a multiple of the %d-row tile", p.rows_per_sample, BM);
-    {
-        // Tile order inside each XCD's contiguous run of tiles (8 XCDs, one L2 each): the run touches m_x A panels and n_x W panels.
-        // N-fastest keeps an A panel in one L2 (large images); M-fastest keeps a W panel there -- at the 8x8 / 16x16 levels W is the big
-        // operand and N-fastest makes every XCD stream ALL of it (1024 x 1280 x 11520: 239 MB instead of 69 MB through the fabric).
-        static const int mf_env = tune_env("RF_GEMM_MFAST", -1);
-        const long long tiles = (long long)p.tiles_m * p.tiles_n, run = (tiles + 7) / 8;
-        const double a_panel = (double)BM * (conv ? p.Ctot : p.K) * sizeof(T), w_panel = (double)BN * p.K * (W8 ? 1 : (int)sizeof(T));
-        const double n_mx = (double)((run + p.tiles_n - 1) / p.tiles_n + (run % p.tiles_n ? 1 : 0)), n_nx = (double)(run < p.tiles_n ? run : p.tiles_n);
-        const double m_mx = (double)(run < p.tiles_m ? run : p.tiles_m), m_nx = (double)((run + p.tiles_m - 1) / p.tiles_m + (run % p.tiles_m ? 1 : 0));
-        const double cost_n = n_mx * a_panel + n_nx * w_panel, cost_m = m_mx * a_panel + m_nx * w_panel;
-        p.mfast = mf_env >= 0 ? mf_env : (cost_m < 0.8 * cost_n ? 1 : 0);
-    }
     // split-K for launches that cannot fill the chip: each z-slice owns a K range, partial sums go through the caller's workspace
     p.splitk = pick_splitk(d, p, (long long)p.tiles_m * p.tiles_n, 128 / (int)sizeof(T));
     if (p.splitk > 1) p.ws = (float*)d->workspace;
+    {
+        // Tile order inside each XCD's contiguous run of tiles (8 XCDs, one 4 MB L2 each, 32 CUs): at any time the XCD works on ~`conc` consecutive
+        // tiles of its run (x the K slices of split-K, which share nothing).  Estimated L2-miss bytes of a run ordered in pm x pn patches:
+        // per super-row of pm tile rows the patches sweep along N -- the pm A panels stay resident if they fit beside the patch's pn W panels, the
+        // W panels are streamed once per super-row unless all of W fits beside the A panels.  Strips along N (pm = 1) keep an A panel in one L2
+        // (large images); strips along M (pn = 1) keep a W panel there -- at the 8x8 / 16x16 levels W is the big operand and N-fastest makes every
+        // XCD stream ALL of it (1024 x 1280 x 11520: 239 MB instead of 69 MB through the fabric); wide layers at the 32x32 / 16x16 levels (GEGLU
+        // 16384 x 5120 x 640: 20 W panels of 327 KB) want both bounded.
+        static const int pm_env = tune_env("RF_GEMM_PM", 0), pn_env = tune_env("RF_GEMM_PN", 0), patch_on = tune_env("RF_GEMM_PATCH", 1);
+        static const int mf_env = tune_env("RF_GEMM_MFAST", -1);
+        const long long tiles = (long long)p.tiles_m * p.tiles_n, run = (tiles + 7) / 8;
+        const double a_panel = (double)BM * (conv ? p.Ctot : p.K) * sizeof(T), w_panel = (double)BN * p.K * (W8 ? 1 : (int)sizeof(T));
+        // strips: the panels a run touches (the rule of rounds 2-4, kept as it was: every split-K and two-blocks-per-CU launch was tuned on it)
+        const double n_mx = (double)((run + p.tiles_n - 1) / p.tiles_n + (run % p.tiles_n ? 1 : 0)), n_nx = (double)(run < p.tiles_n ? run : p.tiles_n);
+        const double m_mx = (double)(run < p.tiles_m ? run : p.tiles_m), m_nx = (double)((run + p.tiles_m - 1) / p.tiles_m + (run % p.tiles_m ? 1 : 0));
+        const double cost_n = n_mx * a_panel + n_nx * w_panel, cost_m = m_mx * a_panel + m_nx * w_panel;
+        const bool mfast = mf_env >= 0 ? mf_env != 0 : cost_m < 0.8 * cost_n;
+        int pm = mfast ? p.tiles_m : 1, pn = mfast ? 1 : p.tiles_n;
+        // patches: only launches of several rounds of one 8-wave block per CU without split-K (measured, profiles/r05c_tile_order_fetch.txt: GEGLU
+        // 16384 x 5120 x 640 296 -> 169 MB of fabric reads per launch, 4096 x 10240 x 1280 284 -> 243 MB and 129 -> 125 us, 4096 x 1280 x 5760
+        // 346 -> 51 MB; the two-blocks-per-CU 128 x 160 launches and the split-K levels LOSE -- their whole run is in flight at once and the
+        // dispatch-order neighbours that share an A panel stream it in step).  Estimated L2-miss bytes of a run: per super-row the patches sweep
+        // along N -- the pm A panels stay resident if they fit beside the patch's pn W panels, the W panels are streamed once per super-row.
+        if (patch_on && p.splitk == 1 && WM * WN == 8 && tiles >= 2 * 256 && mf_env < 0) {
+            const double conc = 32.0, cap = 3.0 * 1024 * 1024;          // tiles in flight per XCD; L2 bytes the operands may take (4 MB minus output lines)
+            auto cost_of = [&](int h, int w) {
+                const double nsr = (double)run / ((double)h * p.tiles_n) < 1.0 ? 1.0 : (double)run / ((double)h * p.tiles_n);          // super-rows per run
+                const double npc = (double)p.tiles_n / w;                                                                            // patches per super-row
+                const double a_t = (h * a_panel + w * w_panel <= cap) ? h * a_panel : npc * h * a_panel;
+                return nsr * (a_t + p.tiles_n * w_panel);
+            };
+            double best = mfast ? cost_m : cost_n;
+            const double strip_model = mfast ? cost_of(p.tiles_m, 1) : cost_of(1, p.tiles_n);
+            if (strip_model > best) best = strip_model;
+            for (int h = 2; h < p.tiles_m && h <= 32; h *= 2) {
+                int w = (int)((conc + h - 1) / h);
+                if (w < 1) w = 1;
+                if (w >= p.tiles_n) continue;                        // (a full-width patch is the strip order)
+                const double c = cost_of(h, w);
+                if (c < 0.6 * best) { pm = h; pn = w; best = c / 0.6; }
+            }
+        }
+        if (pm_env > 0 && pn_env > 0) { pm = pm_env < p.tiles_m ? pm_env : p.tiles_m; pn = pn_env < p.tiles_n ? pn_env : p.tiles_n; }
+        p.pm = pm;
+        p.pn = pn;
+    }
     // Split-K through fragment-ordered slabs (direct-epilogue kernels + splitk_reduce_frag_kernel): wherever the reduce pass has nothing to do
     // but alpha / bias / per-sample vector / residual (+ statistics) on 16-byte aligned rows
     static const int frag_env = tune_env("RF_SK_FRAG", 1);
@@ -2165,6 +2217,37 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
                 //  co-resident blocks keep loads, residual reads and stores of different tiles in flight together, 61 -> 48 us with cold
                 //  operands; together -0.7 % per batch, tools/exp_r03_14.sh)
                 const double rounds = (double)(mt256 * nt) / 256.0, rfill = rounds / (double)((mt256 * nt + 255) / 256);
+                // 256-wide tiles (GEGLU, N not a multiple of 320) whose last round is 20-60 % full -- 4096 x 10240 x 1280, the GEGLU projection of
+                // the 16x16 level: 640 tiles = 2.5 rounds, three round times -- are split along N: the whole rounds on 256-row tiles, the columns of
+                // the partial round as a second launch, which this dispatcher gives 128-row tiles (one full round of half-size tiles).  Launches
+                // that carry nothing tile-numbered (no fused GroupNorm statistics, no LayerNorm producer role, no fp8 output, one W).
+                static const int tail_on = tune_env("RF_TAIL_SPLIT", 1);
+                const long long tiles_ = mt256 * nt, full_ = tiles_ / 256, rem_ = tiles_ - full_ * 256;
+                if (tail_on && !n320 && full_ >= 1 && rem_ * 5 >= 256 && rem_ * 5 <= 3 * 256 && (full_ * 256) % mt256 == 0 && p.gn_rows == 0 && !p.ln_out && !p.oscale &&
+                    !p.w_ps && !p.x3 && d->batch == 1 && (d->act == RF_ACT_NONE || d->act == RF_ACT_GEGLU)) {
+                    const int n1 = (int)(full_ * 256 / mt256) * 256;                       // columns of the whole rounds
+                    auto part = [&](int n_off, int n_len) {
+                        GemmParams q = p;
+                        const int esw = W8 ? 1 : (int)sizeof(T);
+                        q.N = n_len;
+                        q.W = (const char*)p.W + (long long)n_off * p.ldw * esw;
+                        q.w_bytes = (unsigned)(W8 ? (long long)n_len * p.ldw : ((long long)(n_len - 1) * p.ldw + p.K) * esw);
+                        if (p.bias) q.bias = p.bias + n_off;
+                        if (p.rowvec) q.rowvec = p.rowvec + n_off;
+                        if (p.ln_u) q.ln_u = p.ln_u + n_off;
+                        if (p.wscale) q.wscale = p.wscale + n_off;
+                        if (p.act_vec) q.act_vec = p.act_vec + n_off;
+                        const int o_off = d->act == RF_ACT_GEGLU ? n_off / 2 : n_off;       // GEGLU: 32 value | 32 gate column blocks -> N / 2 output columns
+                        q.out = (char*)p.out + (long long)o_off * sizeof(TO);
+                        if (p.residual) q.residual = (const char*)p.residual + (long long)o_off * sizeof(TO);
+                        return q;
+                    };
+                    GemmParams q1 = part(0, n1);
+                    const int rc = launch_cfg<T, TO, 4, 2, 2, 4, W8>(d, q1, conv, st);
+                    if (rc != 0 || p.plan) return rc;                                        // (a plan query reports the whole-round tiling)
+                    GemmParams q2 = part(n1, N - n1);
+                    return launch_typed<T, TO, W8>(d, q2, conv, st);
+                }
                 if (n320 && (rfill < 0.6 || (rfill < 0.8 && rounds > 1.0) || (d->residual && p.K <= 320))) return launch_cfg<T, TO, 4, 1, 1, 5, W8>(d, p, conv, st);
                 return n320 ? launch_cfg<T, TO, 4, 2, 2, 5, W8>(d, p, conv, st) : launch_cfg<T, TO, 4, 2, 2, 4, W8>(d, p, conv, st);
             }
@@ -2388,3 +2471,5 @@ extern "C" int rf_conv_gemm_plan2(const rf_conv_gemm_desc* d, int32_t* info8) {
     for (int i = 0; i < 8; ++i) info8[i] = plan[i];
     return rc;
 }
+
+#endif          // RF_KERNEL_ONLY

@@ -1,0 +1,182 @@
+// GroupNorm(32) + SiLU + 3x3 convolution (stride 1, pad 1) to a HANDFUL of output channels, fused: the UNet's `out` head
+//   openaimodel.py:737-741  self.out = nn.Sequential(normalization(ch), nn.SiLU(), zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1)))
+// (320 -> 4 channels on the full-resolution tensor).  As an implicit GEMM this layer stages the activation nine times (one tap-shifted copy per
+// filter tap: 364 MB through the fabric for a 42 MB tensor, 55 us at 27 TFLOP/s on a 128 x 64 tile that is 94 % padding) behind a normalisation
+// pass that writes and re-reads the tensor (13 us).  Here the raw tensor is read ONCE:
+//   kernel 1 (per 32 pixels and wave, pixels on lanes as in ffn.hip): the pixel's C raw values -> registers, scale / shift / SiLU per (sample, channel)
+//            from the fused GroupNorm statistics, rounded to bf16 (what the normalisation pass would have stored), then
+//            Y^T[9 No, pixel] = Wt[9 No, C] . act(X)^T on the matrix pipe -- the per-TAP partial products of every pixel (row = tap * No + o);
+//   kernel 2 (one thread per output pixel): out[p, o] = bias[o] + sum over the taps whose source pixel lies inside the image of Y[p + offset(tap), tap, o].
+// Zero padding costs nothing: a tap whose source pixel is outside the image is simply not added (act(0) is never formed).
+// The products are the ones the unfused pair forms (bf16 activation x bf16 weight, fp32 accumulation); only the order of the fp32 additions differs.
+#include "common.h"
+
+namespace rf {
+
+struct SmallConvParams {
+    const bf16_t* x; int ldx;          // [B * HW][ldx] raw (un-normalised) activations
+    int B, H, W, C, No;
+    int nchunks; const double* partial;          // GroupNorm(32) partial sums of x: [B][nchunks][32][2] (rf_groupnorm_stats layout)
+    const float* gamma; const float* beta; float eps; int silu;
+    const bf16_t* w;                   // [No][9 C] conv weight, k = tap * C + c (ops.pack_conv_weight)
+    float* y;                          // [B * HW][YP] per-tap partial products (workspace)
+};
+constexpr int SC_YP = 40;              // floats per pixel in y (9 No <= 36 used; 160-byte rows keep the 16-byte vectors aligned)
+
+// kernel 1: block = 4 waves = 128 pixels of one sample
+template <int C>
+__global__ __launch_bounds__(256) void gn_silu_taps_kernel(const SmallConvParams p) {
+    constexpr int KS = C / 16;                                   // k-steps of 16 channels
+    constexpr int WP = C * 2 + 16;                               // row pitch of the weight table in LDS (bytes): 16-byte skew against bank conflicts
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const wl = smem;                                       // [36][WP]  Wt rows (tap * No + o), bf16
+    float* const scl = (float*)(smem + 36 * WP);                 // [C] scale, [C] shift of this block's sample
+    float* const shl = scl + C;
+    __shared__ float mean_s[32], rstd_s[32];
+    __shared__ double red[256][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int HW = p.H * p.W;
+    const int blocks_per_sample = (HW + 127) / 128;
+    const int b = blockIdx.x / blocks_per_sample, pb = blockIdx.x - b * blocks_per_sample;
+    const int pix = pb * 128 + wave * 32 + lrow;                 // pixel inside the sample
+    const bool live = pix < HW;
+    const long long grow = (long long)b * HW + pix;
+
+    // ---- the pixel's raw values: issued first (one memory latency for the block: statistics and weight table follow while they fly)
+    u32x4_t xq[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        xq[s] = u32x4_t{0u, 0u, 0u, 0u};
+        if (live) xq[s] = *(const u32x4_t*)(p.x + grow * p.ldx + s * 16 + lhalf * 8);
+    }
+    // ---- weight table: row r = tap * No + o  <-  w[o][tap * C .. + C)
+    const int rows = 9 * p.No;
+    for (int i = tid; i < rows * (C / 8); i += 256) {
+        const int r = i / (C / 8), v = i - r * (C / 8);
+        const int tap = r / p.No, o = r - tap * p.No;
+        *(u32x4_t*)(wl + r * WP + v * 16) = *(const u32x4_t*)(p.w + ((long long)o * 9 + tap) * C + v * 8);
+    }
+    // ---- statistics of sample b -> per-channel scale / shift (the preamble of gn_apply_kernel, norm.hip)
+    {
+        const int g = tid & 31, part = tid >> 5;
+        double a = 0.0, q = 0.0;
+        for (int c = part; c < p.nchunks; c += 8) {
+            const double* pp = p.partial + (((long long)b * p.nchunks + c) * 32 + g) * 2;
+            a += pp[0];
+            q += pp[1];
+        }
+        red[tid][0] = a;
+        red[tid][1] = q;
+        __syncthreads();
+        if (tid < 32) {
+            double sa = 0.0, sq = 0.0;
+            for (int k = 0; k < 8; ++k) { sa += red[tid + 32 * k][0]; sq += red[tid + 32 * k][1]; }
+            const double n = (double)HW * (C / 32);
+            const double mean = sa / n;
+            double var = sq / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            mean_s[tid] = (float)mean;
+            rstd_s[tid] = (float)(1.0 / sqrt(var + (double)p.eps));
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            const int g2 = c / (C / 32);
+            const float a2 = rstd_s[g2] * p.gamma[c];
+            scl[c] = a2;
+            shl[c] = p.beta[c] - mean_s[g2] * a2;
+        }
+        __syncthreads();
+    }
+    // ---- normalise + SiLU in registers, rounded to bf16 as the normalisation pass stores them
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        float f[8];
+        unpack16<bf16_t>(xq[s], f);
+        const int c0 = s * 16 + lhalf * 8;
+        const f32x4_t a0 = *(const f32x4_t*)(scl + c0), a1 = *(const f32x4_t*)(scl + c0 + 4), h0 = *(const f32x4_t*)(shl + c0), h1 = *(const f32x4_t*)(shl + c0 + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = f[e] * (e < 4 ? a0[e] : a1[e - 4]) + (e < 4 ? h0[e] : h1[e - 4]);
+            if (p.silu) v = silu_exact(v);
+            f[e] = v;
+        }
+        xq[s] = pack16<bf16_t>(f);
+    }
+    // ---- Y^T = Wt . act(X)^T : two 32-row blocks (rows >= 9 No read a clamped row: their results are never used)
+    f32x16_t acc[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    const int r0 = min(lrow, rows - 1), r1 = min(32 + lrow, rows - 1);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const u32x4_t w0 = *(const u32x4_t*)(wl + r0 * WP + (s * 16 + lhalf * 8) * 2), w1 = *(const u32x4_t*)(wl + r1 * WP + (s * 16 + lhalf * 8) * 2);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w0), __builtin_bit_cast(bf16x8_t, xq[s]), acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w1), __builtin_bit_cast(bf16x8_t, xq[s]), acc[1], 0, 0, 0);
+    }
+    // accumulator register r of block k = row 32 k + (r & 3) + 8 (r >> 2) + 4 half of this lane's pixel: four 16-byte row runs per block
+    if (live) {
+        float* const yr = p.y + grow * SC_YP;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = 8 * q + 4 * lhalf;
+            if (row < rows) *(f32x4_t*)(yr + row) = f32x4_t{acc[0][4 * q], acc[0][4 * q + 1], acc[0][4 * q + 2], acc[0][4 * q + 3]};
+        }
+        if (lhalf == 0 && 32 < rows) *(f32x4_t*)(yr + 32) = f32x4_t{acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
+        if (lhalf == 1 && 36 < rows) *(f32x4_t*)(yr + 36) = f32x4_t{acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
+    }
+}
+
+// kernel 2: out[p, o] = bias[o] + sum_{taps inside the image} y[p + (dy - 1) W + (dx - 1)][tap * No + o]
+template <typename TO>
+__global__ __launch_bounds__(256) void gather_taps_kernel(const float* __restrict__ y, int B, int H, int W, int No, const float* __restrict__ bias,
+                                                          TO* __restrict__ out, int ldo) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int HW = H * W;
+    if (i >= (long long)B * HW) return;
+    const int pix = (int)(i % HW), py = pix / W, px = pix - py * W;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = (bias && o < No) ? bias[o] : 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int sy = py + dy - 1, sx = px + dx - 1;
+            if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) {
+                const float* src = y + (i + (dy - 1) * W + (dx - 1)) * SC_YP + (dy * 3 + dx) * No;
+                for (int o = 0; o < No; ++o) acc[o] += src[o];
+            }
+        }
+    for (int o = 0; o < No; ++o) elem<TO>::store(out + i * ldo + o, acc[o]);
+}
+
+}  // namespace rf
+
+extern "C" int rf_gn_silu_conv3x3_small(const void* x, int B, int H, int W, int C, int ldx, int nchunks, const double* partial, const float* gamma,
+                                        const float* beta, float eps, int silu, const void* w, const float* bias, int No, int out_dtype, void* out, int ldo,
+                                        float* workspace, long long workspace_bytes, void* stream) {
+    using namespace rf;
+    RF_CHECK(x && partial && gamma && beta && w && out && workspace, "rf_gn_silu_conv3x3_small: null argument");
+    RF_CHECK(B > 0 && H > 0 && W > 0 && nchunks > 0 && No >= 1 && No <= 4, "rf_gn_silu_conv3x3_small: bad sizes (1 <= No <= 4: 9 No rows fit SC_YP), got No=%d", No);
+    RF_CHECK(C == 320 || C == 128 || C == 64, "rf_gn_silu_conv3x3_small: built for C = 320 (REFace), 128, 64 (reduced-width tests), got %d", C);
+    RF_CHECK(ldx % 8 == 0 && ((uintptr_t)x | (uintptr_t)w) % 16 == 0 && (uintptr_t)workspace % 16 == 0, "rf_gn_silu_conv3x3_small: operands must be 16-byte aligned, ldx a multiple of 8");
+    RF_CHECK(out_dtype == RF_F32 || out_dtype == RF_BF16, "rf_gn_silu_conv3x3_small: bad out_dtype %d", out_dtype);
+    const long long M = (long long)B * H * W;
+    RF_CHECK(workspace_bytes >= M * SC_YP * 4, "rf_gn_silu_conv3x3_small: workspace of %lld bytes needed", M * SC_YP * 4);
+    SmallConvParams p;
+    p.x = (const bf16_t*)x; p.ldx = ldx; p.B = B; p.H = H; p.W = W; p.C = C; p.No = No; p.nchunks = nchunks; p.partial = partial;
+    p.gamma = gamma; p.beta = beta; p.eps = eps; p.silu = silu; p.w = (const bf16_t*)w; p.y = workspace;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = B * ((H * W + 127) / 128);
+#define RF_SC(C_) { const int smem = 36 * (C_ * 2 + 16) + 2 * C_ * 4; hipLaunchKernelGGL(gn_silu_taps_kernel<C_>, dim3(nb), dim3(256), smem, st, p); }
+    if (C == 320) RF_SC(320) else if (C == 128) RF_SC(128) else RF_SC(64)
+#undef RF_SC
+    const int gb = (int)((M + 255) / 256);
+    if (out_dtype == RF_F32) hipLaunchKernelGGL(gather_taps_kernel<float>, dim3(gb), dim3(256), 0, st, workspace, B, H, W, No, bias, (float*)out, ldo);
+    else hipLaunchKernelGGL(gather_taps_kernel<bf16_t>, dim3(gb), dim3(256), 0, st, workspace, B, H, W, No, bias, (bf16_t*)out, ldo);
+    RF_LAUNCH_CHECK("rf_gn_silu_conv3x3_small");
+    return 0;
+}

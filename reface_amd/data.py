@@ -50,7 +50,9 @@ def _linear_taps(n_src, n_dst, clamp_high):
     f = float((d + 0.5) * scale - 0.5) with scale in double, s = floor(f), weights (1 - f, f) scaled by 2048 and rounded to nearest-even
     to int16 (`saturate_cast<short>`).  Columns (`clamp_high`): s < 0 -> (s, f) = (0, 0); s >= n_src - 1 -> (n_src - 1, 0).  Rows keep
     their weights and have the two source rows clipped to [0, n_src - 1] instead."""
-    scale = float(n_src) / float(n_dst)                           # double, as `scale_x = 1. / inv_scale_x` for an integer dsize
+    # OpenCV's operation order (resize.cpp): inv_scale = dsize / ssize, then scale = 1. / inv_scale -- TWO roundings in double; n_src / n_dst in one
+    # rounding can differ by an ulp for non-power-of-two sizes and flip a floor() at a boundary
+    scale = 1.0 / (float(n_dst) / float(n_src))
     d = np.arange(n_dst, dtype=np.float64)
     f = ((d + 0.5) * scale - 0.5).astype(np.float32)
     s = np.floor(f).astype(np.int32)
@@ -69,7 +71,8 @@ def resize_u8_linear(img, out_h, out_w):
     """`cv2.resize(img, (out_w, out_h), interpolation=cv2.INTER_LINEAR)` for uint8 images [H, W] / [H, W, C] -- what albumentations'
     `A.Resize(height, width)` runs on the source face (ldm/data/test_bench_dataset.py:141-148, 296-324; scripts/inference_swap_selected.py:
     525-553).  cv2 is not in this image; this restates OpenCV's published u8 algorithm (resize.cpp: `resizeGeneric_` with
-    `HResizeLinear<uchar, int, short, 2048>` and the u8 specialisation of `VResizeLinear`), bit for bit in integer arithmetic:
+    `HResizeLinear<uchar, int, short, 2048>` and the u8 specialisation of `VResizeLinear`) in the same integer arithmetic and operation order
+    (pinned by hand vectors and against the HIP kernel; NOT yet against a cv2-generated golden -- cv2 is absent here -- so the last bit is unpinned):
 
       * two taps per axis at half-pixel centres, NO antialiasing whatever the ratio (PIL's BILINEAR widens its kernel when shrinking);
       * horizontal pass in int32:  Hrow[x] = S[sx] * a0 + S[sx + 1] * a1  with 11-bit weights (a0 + a1 = 2048);

@@ -415,6 +415,28 @@ def groupnorm_fold_linear(W, gamma, beta, bias, partial, nchunks, *, B, HW, eps,
     return l, wout, rv
 
 
+SMALLCONV_CHANNELS = (320, 128, 64)
+
+
+def gn_silu_conv3x3_small(x, gamma, beta, partial, nchunks, W, bias, out, *, eps, silu=True, workspace=None, name="gn_silu_conv3x3"):
+    """GroupNorm(32) + SiLU + 3x3 conv (stride 1, pad 1) to <= 4 channels on the RAW bf16 tensor x [B, H, W, C] (rf_gn_silu_conv3x3_small; the
+    UNet's `out` head): W packed [No, 9 C] bf16 (pack_conv_weight), out [B, H, W, No] fp32 / bf16, partial / nchunks from fuse_groupnorm_stats or
+    groupnorm_stats.  workspace: fp32 tensor of >= B*H*W*40 elements (per-tap partial products)."""
+    lib = _lib.load()
+    B, H, W_, Cc = x.shape
+    No = W.shape[0]
+    _require_gpu(x, gamma, beta, partial, W, bias, out)
+    assert x.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and W.shape[1] == 9 * Cc and x.stride(3) == 1 and out.stride(3) == 1 and out.shape[:3] == x.shape[:3]
+    assert Cc in SMALLCONV_CHANNELS and 1 <= No <= 4 and partial.dtype == torch.float64
+    assert x.stride(0) == H * W_ * x.stride(2) and x.stride(1) == W_ * x.stride(2) and out.stride(0) == H * W_ * out.stride(2) and out.stride(1) == W_ * out.stride(2)
+    if workspace is None:
+        workspace = torch.empty((B * H * W_ * 40,), dtype=torch.float32, device=x.device)
+    assert workspace.dtype == torch.float32 and workspace.numel() >= B * H * W_ * 40
+    return Launch(lib.rf_gn_silu_conv3x3_small, (_p(x), B, H, W_, Cc, x.stride(2), nchunks, _p(partial), _p(gamma), _p(beta), float(eps), int(bool(silu)), _p(W), _p(bias),
+                                                 No, code(out.dtype), _p(out), out.stride(2), _p(workspace), workspace.numel() * 4),
+                  (x, gamma, beta, partial, W, bias, out, workspace), name)
+
+
 def conv2d(x, W, out, bias=None, *, ksize=3, stride=1, pad=(1, 1), ups=0, x2=None, residual=None, rowvec=None,
            act=ACT_NONE, act_vec=None, korder=0, x3=False, name="conv2d"):
     """Channels-last convolution.  x: [B, Hin, Win, C0] (+ optional x2 [B, Hin, Win, C1] concatenated

@@ -111,14 +111,17 @@ def paths(outdir, sid):
 class OutputWriter:
     """PNG encoding off the launch thread: ``submit`` takes host arrays of one batch and returns at once; ``close`` drains."""
 
-    def __init__(self, outdir, skip_grid=False, depth=4, threads=8, compress_level=None):
+    def __init__(self, outdir, skip_grid=False, depth=4, threads=8, compress_level=None, aux_compress_level=None):
         # One job per IMAGE, `threads` workers: the six PNG encodes of an image are ~0.3 s of zlib on incompressible content (zlib runs
         # outside the GIL), so a single worker caps the CLI at ~3 images/s -- below one MI355X (tools/host_scaling_probe.py: 2.86 s per
         # batch of 8 with one worker against 0.9 s of device time)
         self.outdir, self.skip_grid = outdir, skip_grid
         # zlib level of the PNG files: None = PIL's default (6), what the reference's Image.save writes; a lower level gives the same
         # pixels in larger files for a third of the CPU time (RF_PNG_LEVEL / --png_level)
+        # aux_compress_level (--fast_aux_png): its own level for the four samples/ panels and the grid/ file; results/<id>.png -- the file a user
+        # compares with the reference's -- keeps `compress_level`
         self.save_kw = {} if compress_level is None else {"compress_level": int(compress_level)}
+        self.aux_kw = self.save_kw if aux_compress_level is None else {"compress_level": int(aux_compress_level)}
         self.q = queue.Queue(maxsize=depth * 8)
         self.err = None
         self.n = 0
@@ -142,7 +145,7 @@ class OutputWriter:
                     arrs = compose(res, tgt, inp, msk, ref, skip_grid=self.skip_grid)
                 p = paths(self.outdir, sid)
                 for k, a in arrs.items():
-                    Image.fromarray(a).save(p[k], **self.save_kw)
+                    Image.fromarray(a).save(p[k], **(self.save_kw if k == "result" else self.aux_kw))
                 with self.lock:
                     self.n += 1
             except Exception as e:          # surfaced on the next submit / close

@@ -113,6 +113,7 @@ class UNetEngine:
         self.hx_on = os.environ.get("REFACE_HX", "1") == "1"
         # SpatialTransformer.norm (GroupNorm, no SiLU) folded into proj_in's weights per sample (rf_groupnorm_fold_linear): REFACE_GN_FOLD=0 keeps the pass
         self.gn_fold_lin = os.environ.get("REFACE_GN_FOLD", "1") == "1"
+        self.out_fuse = os.environ.get("REFACE_OUT_FUSE", "1") == "1"          # `out` head (GroupNorm + SiLU + 3x3 conv to 4 channels) as one pass (csrc/smallconv.hip)
         self.gn_fold_maxc = int(os.environ.get("REFACE_GN_FOLD_MAXC", "640"))
         self.n_gn_folded = 0
         self.n_hx = 0
@@ -669,6 +670,17 @@ class UNetEngine:
                 dst = None
             final = self._block(f"output_blocks.{i}", layers, cats[i], dst)
         c_fin = final.shape[3]
+        if (self.out_fuse and self.dt == torch.bfloat16 and not self.x3 and final.dtype == torch.bfloat16 and c_fin in ops.SMALLCONV_CHANNELS and
+                self.sd["out.2.weight"].shape[0] <= 4 and final.is_contiguous()):
+            # `out` = GroupNorm + SiLU + 3x3 conv to 4 channels: one pass over the raw tensor (csrc/smallconv.hip) instead of the normalisation pass
+            # (a write + a read of the tensor) and an implicit GEMM that stages it nine times for a tile that is 94 % padding
+            part, nch = self._gn_stats(final)
+            self.out_ws = torch.empty((final.shape[0] * final.shape[1] * final.shape[2] * 40,), dtype=F32, device=dev)
+            self.main.append(ops.gn_silu_conv3x3_small(final, self.f32("out.0.weight"), self.f32("out.0.bias"), part, nch,
+                                                       ops.pack_conv_weight(self.sd["out.2.weight"], self.dt), self.f32("out.2.bias"), self.eps, eps=1e-5, silu=True,
+                                                       workspace=self.out_ws, name="out"))
+            self.cats = cats
+            return
         g = self._gn(final, "out.0", 1e-5, True, split=self.x3_ok(9 * c_fin, c_fin))
         if g.dtype == torch.bfloat16 and self.x3:
             self.main.append(ops.conv2d(g, ops.pack_x3(ops.pack_conv_weight(self.sd["out.2.weight"], F32)), self.eps, self.f32("out.2.bias"), x3=True,

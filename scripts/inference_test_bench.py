@@ -67,6 +67,10 @@ def build_parser():
     p.add_argument("--dump_tensors", type=str, default=None, help="directory for per-batch .npz dumps of the tensors fed to / produced by the engines (tests)")
     p.add_argument("--clip_vision_config", type=str, default=None, help="JSON dict overriding the CLIP ViT dims (tests)")
     p.add_argument("--num_workers", type=int, default=4, help="DataLoader workers of the folder readers (reference: 4)")
+    p.add_argument("--png_level", type=int, default=None, help="zlib level of the PNG files (default: PIL's, 6 = the reference's files byte for byte; "
+                   "lower = the same pixels in larger files for less host time)")
+    p.add_argument("--fast_aux_png", action="store_true", help="samples/ and grid/ PNGs at zlib level 1 (same pixels, larger files); results/<id>.png keeps --png_level "
+                   "(multi-GPU runs: the host's PNG encoding is what caps 8 processes per node)")
     p.add_argument("--gpu_prep", action="store_true", help="folder readers hand over uint8 arrays; normalise / mask / resize run on the GPU")
     return p
 
@@ -183,13 +187,16 @@ def main(argv=None):
     if not opt.skip_save:
         from reface_amd.output import OutputWriter
         from reface_amd.output import default_writer_threads
-        lvl = os.environ.get("RF_PNG_LEVEL")
         # PNG encodes run on worker threads, bounded by this process's share of the host (8 processes per node share it).  zlib level: PIL's
-        # default (6, the reference's files) for a single process; 1 when several processes share the host -- the same pixels in larger files:
-        # photo-like panels at level 6 cost 2.4 s per batch of 8 with 8 processes at once, 1.03 s at level 1 (tools/host_scaling_probe.py
-        # --natural, profiles/r04d_host_probe_natural*.json).  RF_PNG_LEVEL overrides.
-        level = int(lvl) if lvl else (1 if world > 1 else None)
-        writer = OutputWriter(outpath, skip_grid=opt.skip_grid, threads=default_writer_threads(world), compress_level=level)
+        # default (6) = the reference's files byte for byte, whatever the number of processes (--png_level / RF_PNG_LEVEL change it: same pixels,
+        # other bytes).  --fast_aux_png writes the four samples/ panels and the grid/ file at level 1 and keeps results/<id>.png -- the file a user
+        # compares -- at the reference's level: photo-like panels at level 6 cost 2.4 s of host time per batch of 8 with 8 processes at once against
+        # 1.03 s at level 1 (tools/host_scaling_probe.py --natural, profiles/r04d_host_probe_natural*.json); with only results/ at level 6 the
+        # probe's estimate is (5 x level-1 + 1 x level-6) / 6 of that -- see README "Known limits" for the 8-GPU host cap.
+        lvl = os.environ.get("RF_PNG_LEVEL")
+        level = int(lvl) if lvl else opt.png_level
+        writer = OutputWriter(outpath, skip_grid=opt.skip_grid, threads=default_writer_threads(world), compress_level=level,
+                              aux_compress_level=1 if opt.fast_aux_png else None)
     host_compose = os.environ.get("RF_HOST_COMPOSE") == "1"          # debug: the reference's per-image float passes on the host (round-3 form)
     def with_landmark_prefetch(batches):
         """Yield (batch, landmarks136 or None): the dlib landmarks of batch i+1 are detected on a worker thread while the GPU works

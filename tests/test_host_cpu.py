@@ -565,3 +565,22 @@ def test_resize_u8_linear_is_cv2_inter_linear():
     x = rng.integers(0, 256, (1024, 1024, 3), dtype=np.uint8)
     pil = np.asarray(Image.fromarray(x).resize((224, 224), Image.BILINEAR)).astype(np.int32)
     assert np.abs(resize_u8_linear(x, 224, 224).astype(np.int32) - pil).mean() > 20
+
+
+def test_e4m3_numpy_reference_is_self_consistent():
+    """The numpy e4m3fn reference of the GPU quantiser tests (tests/e4m3_ref.py): every finite code round-trips, midpoints go
+    to the even neighbour, +-448 saturates."""
+    import numpy as np
+    from e4m3_ref import e4m3fn_decode_np, e4m3fn_encode_rne_sat_np
+    codes = np.array([c for c in range(256) if (c & 0x7f) != 0x7f], dtype=np.int64)
+    vals = e4m3fn_decode_np(codes)
+    back = e4m3fn_encode_rne_sat_np(vals)
+    assert np.array_equal(back & 0x7f, (codes & 0x7f).astype(np.uint8)) and np.array_equal((back >> 7)[vals != 0], ((codes >> 7).astype(np.uint8))[vals != 0])
+    pos = np.sort(vals[vals >= 0])
+    mid = (pos[:-1] + pos[1:]) / 2
+    enc = e4m3fn_encode_rne_sat_np(mid)
+    assert (enc & 1 == 0).all()                               # ties land on the even mantissa
+    assert e4m3fn_encode_rne_sat_np(np.array([1e9, -1e9, 448.0, 464.0, 479.9]))[0] == 0x7e and e4m3fn_encode_rne_sat_np(np.array([-1e9]))[0] == 0xfe
+    # and it agrees with torch's own float8_e4m3fn cast on 100 k random values over 7 decades (finite range)
+    x = (torch.randn(100000, generator=torch.Generator().manual_seed(5)) * torch.logspace(-4, 2.6, 100000)).clamp(-448, 448)
+    assert np.array_equal(e4m3fn_encode_rne_sat_np(x.numpy()), x.to(torch.float8_e4m3fn).view(torch.uint8).numpy())

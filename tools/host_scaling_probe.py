@@ -44,7 +44,7 @@ def make_tree(root, n, natural=False):
         Image.fromarray(lab).save(os.path.join(root, "CelebA-HQ-mask", "Overall_mask", f"{i}.png"))
 
 
-def worker(tree, outdir, batches, device_ms, B=8, legacy=False, world=1, png_level=None, gpu_prep=False, natural=False):
+def worker(tree, outdir, batches, device_ms, B=8, legacy=False, world=1, png_level=None, gpu_prep=False, natural=False, aux_level=None):
     import numpy as np
     import torch
     from reface_amd import output as O
@@ -58,7 +58,7 @@ def worker(tree, outdir, batches, device_ms, B=8, legacy=False, world=1, png_lev
     [os.makedirs(os.path.join(outdir, d), exist_ok=True) for d in ("results", "grid", "samples")]
     # round 4: the panels / grid are composed on the GPU and arrive as ONE packed uint8 record per image; the writer's worker count is the
     # process's share of the host.  --legacy: the round-3 host half (fp32 panels composed on the host, 8 workers per process)
-    writer = O.OutputWriter(outdir) if legacy else O.OutputWriter(outdir, threads=O.default_writer_threads(world), compress_level=png_level)
+    writer = O.OutputWriter(outdir) if legacy else O.OutputWriter(outdir, threads=O.default_writer_threads(world), compress_level=png_level, aux_compress_level=aux_level)
     nbytes, _ = O.record_layout(512, 512)
     rng = np.random.default_rng(0)
     pool_u8 = rng.integers(0, 256, (B, nbytes), dtype=np.uint8)              # stand-in for the D2H'd records (noise: zlib's worst case)
@@ -106,16 +106,19 @@ def main():
     ap.add_argument("--natural", action="store_true", help="photo-like images in and out (smooth content + sensor noise) instead of uniform noise, the codecs' worst case")
     ap.add_argument("--gpu-prep", action="store_true", help="readers hand over uint8 arrays only (the CLI's --gpu_prep)")
     ap.add_argument("--png-level", type=int, default=None, help="zlib level of the PNG files (default: PIL's 6, the reference's files)")
+    ap.add_argument("--aux-png-level", type=int, default=None, help="zlib level of the samples/ and grid/ files only (the CLI's --fast_aux_png = 1); results/ keeps --png-level")
     a = ap.parse_args()
     if a.worker:
-        worker(a.worker[0], a.worker[1], a.batches, a.device_ms, legacy=a.legacy, world=a.world, png_level=a.png_level, gpu_prep=a.gpu_prep, natural=a.natural)
+        worker(a.worker[0], a.worker[1], a.batches, a.device_ms, legacy=a.legacy, world=a.world, png_level=a.png_level, gpu_prep=a.gpu_prep, natural=a.natural,
+               aux_level=a.aux_png_level)
         return
     with tempfile.TemporaryDirectory() as tmp:
         tree = os.path.join(tmp, "CelebAMask-HQ")
         make_tree(tree, a.batches * 8, natural=a.natural)
         out = {}
         for n in (1, a.procs):
-            extra = (["--legacy"] if a.legacy else []) + (["--png-level", str(a.png_level)] if a.png_level is not None else []) + (["--gpu-prep"] if a.gpu_prep else []) + (["--natural"] if a.natural else [])
+            extra = (["--legacy"] if a.legacy else []) + (["--png-level", str(a.png_level)] if a.png_level is not None else []) + (["--gpu-prep"] if a.gpu_prep else []) + (["--natural"] if a.natural else []) + \
+                    (["--aux-png-level", str(a.aux_png_level)] if a.aux_png_level is not None else [])
             ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", tree, os.path.join(tmp, f"out_{n}_{r}"), "--batches", str(a.batches),
                                     "--device-ms", str(a.device_ms), "--world", str(n)] + extra, stdout=subprocess.PIPE, text=True) for r in range(n)]
             rs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in ps]
@@ -124,6 +127,7 @@ def main():
         out["cpus"] = len(os.sched_getaffinity(0))
         out["host_half"] = "round 3 (fp32 panels composed on the host, 8 PNG workers)" if a.legacy else \
             f"round 4 (packed uint8 records from the device, PNG workers = share of the host, zlib level {a.png_level if a.png_level is not None else 6}" + \
+            (f" for results/, {a.aux_png_level} for samples/ + grid/" if a.aux_png_level is not None else "") + \
             (", readers decode / resize only: --gpu_prep)" if a.gpu_prep else ")")
         out["content"] = "photo-like (smooth + sensor noise)" if a.natural else "uniform noise (worst case of JPEG decode and zlib)"
         out["device_ms_assumed"] = a.device_ms
