@@ -149,6 +149,32 @@ int rf_conv_gemm_plan2(const rf_conv_gemm_desc* d, int32_t* info8);
 int rf_ffn_geglu(const void* x, int ldx, const void* w1p, const float* b1p, const void* w2q, const float* b2, const void* residual, int ldr,
                  void* out, int ldo, int M, int C, float ln_eps, void* stream);
 
+/* The same kernel with SpatialTransformer.proj_out behind the feed-forward (attention.py:268-272, 288-289) -- the token-resident tail of the block:
+ *   out = ((GEGLU(LN?(x) W1^T + b1)) W2^T + b2 + residual) Wpo^T + bpo + res2[row % res2_rows]
+ * The feed-forward's output row (rounded to bf16 where the unfused path stores it) never leaves the CU: it is re-laid-out in registers as the B operand
+ * of one more MFMA contraction against wpo [C][C] (plain rows, bf16), streamed through the W2 buffers.  res2 = the transformer's input x_in
+ * (`return x + x_in`); res2_rows > 0: the residual has that many rows and is shared by the batch halves (the CFG-shared first block).  gn_*: the
+ * GroupNorm(32) partial sums of `out` for up to two consumers, as rf_conv_gemm_desc.gn_* (one chunk slot per 128-token block: slot = gn_slot + block
+ * within the sample; gn_rows = H*W a multiple of 128).  wpo = NULL: exactly rf_ffn_geglu.  Replaces FeedForward.forward + the residual add +
+ * proj_out + `x + x_in` -- and the statistics pass of the GroupNorm that reads the block's output. */
+typedef struct rf_ffn_desc {
+    const void* x; int32_t ldx;
+    const void* w1p; const float* b1p;
+    const void* w2q; const float* b2;
+    const void* residual; int32_t ldr;
+    void* out; int32_t ldo;
+    int32_t M, C;
+    float ln_eps;
+    const void* wpo; const float* bpo;
+    const void* res2; int32_t ldr2, res2_rows;
+    int32_t gn_rows;
+    double* gn_part0;
+    int32_t gn_cpg0, gn_coff0, gn_slot0, gn_nchunks0;
+    double* gn_part1;
+    int32_t gn_cpg1, gn_coff1, gn_slot1, gn_nchunks1;
+} rf_ffn_desc;
+int rf_ffn_block(const rf_ffn_desc* d, void* stream);
+
 /* Per-row fp8 quantisation of a weight matrix for the w_dtype = RF_FP8_E4M3 path: w [N][K] fp32 (row pitch K) ->
  * q [N][ldq] e4m3fn bytes (ldq >= K, a multiple of 128; the pad bytes are written as zero) and scale [N] = the smallest power of
  * two with max|w[n,:]| / scale <= 448 (e4m3fn's largest finite value); q = round-to-nearest-even(w / scale), saturating.

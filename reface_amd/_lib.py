@@ -44,6 +44,24 @@ class ConvGemmDesc(C.Structure):
     ]
 
 
+class FfnDesc(C.Structure):
+    """Mirror of ``rf_ffn_desc`` (include/reface_hip.h)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int32),
+        ("w1p", C.c_void_p), ("b1p", C.c_void_p),
+        ("w2q", C.c_void_p), ("b2", C.c_void_p),
+        ("residual", C.c_void_p), ("ldr", C.c_int32),
+        ("out", C.c_void_p), ("ldo", C.c_int32),
+        ("M", C.c_int32), ("C", C.c_int32),
+        ("ln_eps", C.c_float),
+        ("wpo", C.c_void_p), ("bpo", C.c_void_p),
+        ("res2", C.c_void_p), ("ldr2", C.c_int32), ("res2_rows", C.c_int32),
+        ("gn_rows", C.c_int32),
+        ("gn_part0", C.c_void_p), ("gn_cpg0", C.c_int32), ("gn_coff0", C.c_int32), ("gn_slot0", C.c_int32), ("gn_nchunks0", C.c_int32),
+        ("gn_part1", C.c_void_p), ("gn_cpg1", C.c_int32), ("gn_coff1", C.c_int32), ("gn_slot1", C.c_int32), ("gn_nchunks1", C.c_int32),
+    ]
+
+
 _SIGS = {
     "rf_last_error": (C.c_char_p, []),
     "rf_version": (C.c_int, []),
@@ -52,6 +70,7 @@ _SIGS = {
     "rf_conv_gemm_plan2": (C.c_int, [C.POINTER(ConvGemmDesc), C.POINTER(C.c_int32)]),
     "rf_ffn_geglu": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "rf_ffn_block": (C.c_int, [C.POINTER(FfnDesc), C.c_void_p]),
     "rf_quantize_fp8_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rf_groupnorm_stats": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "rf_groupnorm_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -199,6 +199,25 @@ template <typename T> __device__ __forceinline__ float gelu_for(float x) {
 }
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + expf(-1.702f * x)); }
 
+// Reduce-scatter over the 32 lanes of a half-wave: every lane brings 32 values (index k), lane `lrow` leaves with the total of value index
+// lrow in gx[0].  After the stage with mask m a lane keeps the half of its values selected by its own bit m: 16 + 8 + 4 + 2 + 1 exchanges.
+// (bit select, not ?: -- the compiler turns a select between two array elements into a lane-indexed array access, i.e. a 32-way compare
+//  chain per value)
+__device__ __forceinline__ void halfwave_reduce_scatter32(float (&gx)[32], int lrow) {
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int m = 16 >> st, n = 16 >> st;           // lane mask, values kept after this stage
+        const unsigned up = (lrow & m) ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int k = 0; k < n; ++k) {
+            const unsigned a = __float_as_uint(gx[k]), b = __float_as_uint(gx[k + n]);
+            const float send = __uint_as_float((a & up) | (b & ~up));
+            const float keep = __uint_as_float((b & up) | (a & ~up));
+            gx[k] = keep + __shfl_xor(send, m, 64);
+        }
+    }
+}
+
 // Sum over the 64 lanes, result in every lane.  DPP / permlane-swap steps (a few cycles of latency each) instead of six dependent
 // ds_bpermute round trips (__shfl_xor: ~120 cycles each -- the two reductions of a LayerNorm row were 1.5k cycles of pure latency).
 // Within a row of 16 lanes: xor 1, xor 2, half-mirror, mirror; then v_permlane16_swap / v_permlane32_swap (gfx950) for rows / halves.

@@ -25,11 +25,20 @@ struct FfnParams {
     bf16_t* out; int ldo;
     int M;
     float ln_eps;          // > 0: x rows are LayerNorm-ed in registers first (no affine: gamma / beta are folded into w1 / b1 by the host)
+    // SpatialTransformer.proj_out behind the feed-forward (attention.py:268-272, 288-289; round 5): the block's output tokens never leave the CU --
+    //   out = ((GEGLU ...) W2^T + b2 + residual) Wpo^T + bpo + res2[row % res2_rows]
+    // wpo [C][C] plain rows (no column permutation: the B operand is built in natural K order, see the epilogue); NULL = no projection.
+    const bf16_t* wpo; const float* bpo;
+    const bf16_t* res2; int ldr2; int res2_rows;
+    // GroupNorm(32) partial sums of `out` for up to two consumers (the layout rf_conv_gemm's epilogue writes: one slot per 128-row block and sample)
+    int gn_rows;
+    double* gn_part[2];
+    int gn_cpg[2], gn_coff[2], gn_slot[2], gn_nch[2];
 };
 
 __device__ __forceinline__ int ffn_lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
-template <int C>
+template <int C, bool PROJ>
 __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
     constexpr int CK = C / 64;               // K tiles of GEMM 1
     constexpr int NB = C / 32;               // 32-row blocks of the output (transposed)
@@ -244,10 +253,38 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
         __builtin_amdgcn_s_barrier();
     }
 
-    // ---- epilogue: lane (token, half) holds output columns 32*nb + 16*half + r; b2 parked in LDS (the operand stages are dead)
+    // ---- epilogue: lane (token, half) holds output columns 32*nb + 16*half + r; b2 (and proj_out's bias) parked in LDS (the operand stages are dead)
     float* const b2l = (float*)smem;
-    for (int i = tid; i < C; i += 256) b2l[i] = p.b2[i];
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    constexpr bool proj = PROJ;
+    for (int i = tid; i < C; i += 256) {
+        b2l[i] = p.b2[i];
+        if (proj) b2l[C + i] = p.bpo[i];
+    }
+    // proj_out: K tile kt of Wpo (C rows x 64 k) has the geometry of a W2 chunk and takes its buffers; tiles 0, 1 and 2 go out now
+    const __amdgpu_buffer_rsrc_t rsWp = __builtin_amdgcn_make_buffer_rsrc((void*)(proj ? p.wpo : p.w2), 0, (unsigned)(C * C * 2), 0x00020000);
+    // (three buffers: the two W2 buffers and 40 KB of the dead W1 ring behind the bias / statistics scratch -- three tiles in flight: a K tile's 40
+    //  MFMAs per wave are shorter than an L2 round trip)
+#ifndef RF_WP_BUFS
+#define RF_WP_BUFS 2          // (3 = + 40 KB of the dead W1 ring: measured equal, profiles/r05i_fused_tail_ab.txt)
+#endif
+    constexpr int WPB = RF_WP_BUFS;
+    auto wp_buf = [&](int kt) -> char* { return kt % WPB == 2 ? smem + W1B : smem + OFF_W2 + (kt % WPB) * W2B; };
+    static_assert(W1B >= 4096 + 2 * 4 * C * 4 && W1B + W2B <= NS1 * W1B, "proj_out: third buffer inside the W1 ring, behind b2l / gcs");
+    auto issue_wp = [&](int kt) {
+        char* base = wp_buf(kt);
+#pragma unroll
+        for (int q = 0; q < NPW2; ++q) {
+            const int rg = wave + 4 * q, r = rg * 8 + prow;
+            const int off = r * C * 2 + kslot(r);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsWp, (__attribute__((address_space(3))) void*)(base + rg * 1024), 16, off, kt * 128, 0, 0);
+        }
+    };
+    if (proj) {
+#pragma unroll
+        for (int kt = 0; kt < WPB; ++kt) issue_wp(kt);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!proj) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     constexpr int PFD = 4;
     u32x4_t rq[PFD][2];
@@ -258,47 +295,217 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
             r[1] = rp[1];
         }
     };
+    if constexpr (!proj) {
+#pragma unroll
+        for (int nb = 0; nb < PFD; ++nb) load_res(nb, rq[nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = nb * 32 + lhalf * 16;
+            if (row < p.M) {
+                bf16_t* dst = p.out + (long long)row * p.ldo + col;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float f[8], v[8];
+                    const f32x4_t c0 = *(const f32x4_t*)(b2l + col + 8 * h), c1 = *(const f32x4_t*)(b2l + col + 8 * h + 4);
+                    if (p.res) unpack16<bf16_t>(rq[nb % PFD][h], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = acc2[nb][8 * h + e] + (e < 4 ? c0[e] : c1[e - 4]) + (p.res ? f[e] : 0.f);
+                    ((u32x4_t*)dst)[h] = pack16<bf16_t>(v);
+                }
+            }
+            if (nb + PFD < NB) load_res(nb + PFD, rq[nb % PFD]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    } else {
+
+    // ---- proj_out fused.  (a) the feed-forward's output row (bias + residual, rounded to bf16 as the unfused path stores it) becomes the B operand of
+    // one more GEMM: lane (token, half h) holds columns 32 nb + 16 h + r of block nb; the fragment of k-step s = 2 nb + t wants columns 16 s + 8 h' .. + 8
+    // in half h' -- one v_permlane32_swap per packed register pair moves the two middle quarters between the halves (natural K order: Wpo needs no
+    // column permutation)
+    u32x4_t hb3[2 * NB];
 #pragma unroll
     for (int nb = 0; nb < PFD; ++nb) load_res(nb, rq[nb]);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int col = nb * 32 + lhalf * 16;
+        u32x4_t pk[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float f[8], v[8];
+            const f32x4_t c0 = *(const f32x4_t*)(b2l + col + 8 * h), c1 = *(const f32x4_t*)(b2l + col + 8 * h + 4);
+            if (p.res) unpack16<bf16_t>(rq[nb % PFD][h], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (row < p.M) ? acc2[nb][8 * h + e] + (e < 4 ? c0[e] : c1[e - 4]) + (p.res ? f[e] : 0.f) : 0.f;
+            pk[h] = pack16<bf16_t>(v);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(pk[0][e], pk[1][e], false, false);
+            hb3[2 * nb][e] = sw[0];
+            hb3[2 * nb + 1][e] = sw[1];
+        }
+        if (nb + PFD < NB) load_res(nb + PFD, rq[nb % PFD]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // (b) Z^T = Wpo . X2^T : CK K tiles of 64 through three buffers
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < CK; ++kt) {
+        // tile kt landed; the (up to two) tiles issued behind it may still fly
+        if (kt == 0 || kt + 1 >= CK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (kt + WPB - 1 < CK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WPB - 1) * NPW2) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW2) : "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            const char* const w2base = wp_buf(kt) + brow * 128;
+            u32x4_t af[2];
+            af[0] = *(const u32x4_t*)(w2base + (((0 + lhalf) ^ bsw) << 4));
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int it = kk * NB + nb, cur = it & 1;
+                    if (it + 1 < 4 * NB) {
+                        const int nkk = (it + 1) / NB, nnb = (it + 1) % NB;
+                        af[cur ^ 1] = *(const u32x4_t*)(w2base + nnb * 4096 + (((nkk * 2 + lhalf) ^ bsw) << 4));
+                    }
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[cur]), __builtin_bit_cast(bf16x8_t, hb3[kt * 4 + kk]), acc2[nb], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // every wave is done with this buffer
+        if (kt + WPB < CK) issue_wp(kt + WPB);
+    }
+    // (c) + bpo + the transformer's input (attention.py:289 `return x + x_in`; the CFG-shared first block: both batch halves read the same rows),
+    // 16-byte stores, GroupNorm partial sums of the values as stored
+    const float* const bpl = b2l + C;
+    const int rrow = p.res2_rows > 0 ? row % p.res2_rows : row;
+    auto load_res2 = [&](int nb, u32x4_t* r) {
+        if (p.res2 && row < p.M) {
+            const u32x4_t* rp = (const u32x4_t*)(p.res2 + (long long)rrow * p.ldr2 + nb * 32 + lhalf * 16);
+            r[0] = rp[0];
+            r[1] = rp[1];
+        }
+    };
+    const bool gn_on = p.gn_rows > 0;
+    float* const gcs = (float*)(smem + 4096);                 // [2][4 waves][C] column sums / sums of squares per wave
+#pragma unroll
+    for (int nb = 0; nb < PFD; ++nb) load_res2(nb, rq[nb]);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int col = nb * 32 + lhalf * 16;
+        float y[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) y[e] = 0.f;
         if (row < p.M) {
             bf16_t* dst = p.out + (long long)row * p.ldo + col;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 float f[8], v[8];
-                const f32x4_t c0 = *(const f32x4_t*)(b2l + col + 8 * h), c1 = *(const f32x4_t*)(b2l + col + 8 * h + 4);
-                if (p.res) unpack16<bf16_t>(rq[nb % PFD][h], f);
+                const f32x4_t c0 = *(const f32x4_t*)(bpl + col + 8 * h), c1 = *(const f32x4_t*)(bpl + col + 8 * h + 4);
+                if (p.res2) unpack16<bf16_t>(rq[nb % PFD][h], f);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = acc2[nb][8 * h + e] + (e < 4 ? c0[e] : c1[e - 4]) + (p.res ? f[e] : 0.f);
-                ((u32x4_t*)dst)[h] = pack16<bf16_t>(v);
+                for (int e = 0; e < 8; ++e) v[e] = acc2[nb][8 * h + e] + (e < 4 ? c0[e] : c1[e - 4]) + (p.res2 ? f[e] : 0.f);
+                const u32x4_t wv = pack16<bf16_t>(v);
+                ((u32x4_t*)dst)[h] = wv;
+                if (gn_on) {
+                    unpack16<bf16_t>(wv, f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[8 * h + e] = f[e];
+                }
             }
         }
-        if (nb + PFD < NB) load_res(nb + PFD, rq[nb % PFD]);
+        if (nb + PFD < NB) load_res2(nb + PFD, rq[nb % PFD]);
+        if (gn_on) {
+            float gx[32];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { gx[k] = y[k]; gx[16 + k] = y[k] * y[k]; }
+            halfwave_reduce_scatter32(gx, lrow);          // lane lrow: total over the wave's 32 tokens of column lrow (sums) / lrow - 16 (squares)
+            gcs[((lrow >> 4) * 4 + wave) * C + nb * 32 + lhalf * 16 + (lrow & 15)] = gx[0];
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (gn_on) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid < 64) {
+            const int c = tid >> 5, g = tid & 31;
+            if (p.gn_part[c] && m0 < p.M) {
+                const int cpg = p.gn_cpg[c], base = p.gn_coff[c];            // consumer channel of output column 0
+                const int lo = max(0, g * cpg - base), hi = min(C, (g + 1) * cpg - base);
+                double sa = 0.0, sq = 0.0;
+                for (int k = lo; k < hi; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sa += (double)gcs[r * C + k]; sq += (double)gcs[(4 + r) * C + k]; }
+                const int b = m0 / p.gn_rows, mt = (m0 - b * p.gn_rows) / 128;
+                double* o = p.gn_part[c] + (((long long)b * p.gn_nch[c] + p.gn_slot[c] + mt) * 32 + g) * 2;
+                o[0] = sa;
+                o[1] = sq;
+            }
+        }
+    }
+    }          // (PROJ)
 }
 
 }  // namespace rf
 
+static int ffn_launch(const rf::FfnParams& p, int C, void* stream) {
+    using namespace rf;
+    RF_CHECK(p.x && p.w1 && p.b1 && p.w2 && p.b2 && p.out && p.M > 0, "rf_ffn_geglu: bad arguments");
+    RF_CHECK(C == 320, "rf_ffn_geglu: built for C = 320 (the 64x64 level), got %d", C);
+    RF_CHECK(p.ldx % 8 == 0 && p.ldo % 8 == 0 && (!p.res || p.ldr % 8 == 0) && (!p.res2 || p.ldr2 % 8 == 0), "rf_ffn_geglu: row pitches must be multiples of 8");
+    RF_CHECK(((uintptr_t)p.x | (uintptr_t)p.w1 | (uintptr_t)p.w2 | (uintptr_t)p.out | (uintptr_t)p.res | (uintptr_t)p.b1 | (uintptr_t)p.b2 | (uintptr_t)p.wpo | (uintptr_t)p.bpo |
+              (uintptr_t)p.res2) % 16 == 0, "rf_ffn_geglu: operands must be 16-byte aligned");
+    RF_CHECK((long long)p.M * p.ldx * 2 < 0x7fff0000LL, "rf_ffn_geglu: x too large for 31-bit byte offsets");
+    RF_CHECK(!p.wpo || p.bpo, "rf_ffn_block: proj_out needs its bias");
+    RF_CHECK(p.wpo || (!p.res2 && p.gn_rows == 0), "rf_ffn_block: res2 / GroupNorm statistics belong to the fused proj_out");
+    if (p.gn_rows > 0) {
+        RF_CHECK(p.gn_rows % 128 == 0 && p.M % p.gn_rows == 0, "rf_ffn_block: fused GroupNorm statistics need gn_rows (%d) to be a multiple of the 128-token block and M a multiple of it", p.gn_rows);
+        for (int c = 0; c < 2; ++c)
+            RF_CHECK(!p.gn_part[c] || (p.gn_cpg[c] > 0 && p.gn_slot[c] >= 0 && p.gn_slot[c] + p.gn_rows / 128 <= p.gn_nch[c]),
+                     "rf_ffn_block: GroupNorm consumer %d: cpg=%d slot=%d needs %d slots of %d", c, p.gn_cpg[c], p.gn_slot[c], p.gn_rows / 128, p.gn_nch[c]);
+    }
+    constexpr int smem = 4 * 16384 + 2 * 320 * 128 + 2 * 4 * 512;
+    if (p.wpo) {
+        auto k = ffn_geglu_kernel<320, true>;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+        hipLaunchKernelGGL(k, dim3((p.M + 127) / 128), dim3(256), smem, (hipStream_t)stream, p);
+    } else {
+        auto k = ffn_geglu_kernel<320, false>;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+        hipLaunchKernelGGL(k, dim3((p.M + 127) / 128), dim3(256), smem, (hipStream_t)stream, p);
+    }
+    RF_LAUNCH_CHECK("rf_ffn_geglu");
+    return 0;
+}
+
 extern "C" int rf_ffn_geglu(const void* x, int ldx, const void* w1p, const float* b1p, const void* w2q, const float* b2, const void* residual,
                             int ldr, void* out, int ldo, int M, int C, float ln_eps, void* stream) {
     using namespace rf;
-    RF_CHECK(x && w1p && b1p && w2q && b2 && out && M > 0, "rf_ffn_geglu: bad arguments");
-    RF_CHECK(C == 320, "rf_ffn_geglu: built for C = 320 (the 64x64 level), got %d", C);
-    RF_CHECK(ldx % 8 == 0 && ldo % 8 == 0 && (!residual || ldr % 8 == 0), "rf_ffn_geglu: row pitches must be multiples of 8");
-    RF_CHECK(((uintptr_t)x | (uintptr_t)w1p | (uintptr_t)w2q | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)b1p | (uintptr_t)b2) % 16 == 0,
-             "rf_ffn_geglu: operands must be 16-byte aligned");
-    RF_CHECK((long long)M * ldx * 2 < 0x7fff0000LL, "rf_ffn_geglu: x too large for 31-bit byte offsets");
     FfnParams p;
+    memset(&p, 0, sizeof(p));
     p.x = (const bf16_t*)x; p.ldx = ldx; p.w1 = (const bf16_t*)w1p; p.b1 = b1p; p.w2 = (const bf16_t*)w2q; p.b2 = b2;
     p.res = (const bf16_t*)residual; p.ldr = ldr; p.out = (bf16_t*)out; p.ldo = ldo; p.M = M; p.ln_eps = ln_eps;
-    constexpr int smem = 4 * 16384 + 2 * 320 * 128 + 2 * 4 * 512;
-    auto k = ffn_geglu_kernel<320>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
-    hipLaunchKernelGGL(k, dim3((M + 127) / 128), dim3(256), smem, (hipStream_t)stream, p);
-    RF_LAUNCH_CHECK("rf_ffn_geglu");
-    return 0;
+    return ffn_launch(p, C, stream);
+}
+
+extern "C" int rf_ffn_block(const rf_ffn_desc* d, void* stream) {
+    using namespace rf;
+    RF_CHECK(d != nullptr, "rf_ffn_block: null descriptor");
+    FfnParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)d->x; p.ldx = d->ldx; p.w1 = (const bf16_t*)d->w1p; p.b1 = d->b1p; p.w2 = (const bf16_t*)d->w2q; p.b2 = d->b2;
+    p.res = (const bf16_t*)d->residual; p.ldr = d->ldr; p.out = (bf16_t*)d->out; p.ldo = d->ldo; p.M = d->M; p.ln_eps = d->ln_eps;
+    p.wpo = (const bf16_t*)d->wpo; p.bpo = d->bpo; p.res2 = (const bf16_t*)d->res2; p.ldr2 = d->ldr2; p.res2_rows = d->res2_rows;
+    p.gn_rows = (d->gn_part0 || d->gn_part1) ? d->gn_rows : 0;
+    p.gn_part[0] = d->gn_part0; p.gn_cpg[0] = d->gn_cpg0; p.gn_coff[0] = d->gn_coff0; p.gn_slot[0] = d->gn_slot0; p.gn_nch[0] = d->gn_nchunks0;
+    p.gn_part[1] = d->gn_part1; p.gn_cpg[1] = d->gn_cpg1; p.gn_coff[1] = d->gn_coff1; p.gn_slot[1] = d->gn_slot1; p.gn_nch[1] = d->gn_nchunks1;
+    return ffn_launch(p, d->C, stream);
 }

@@ -169,25 +169,6 @@ template <typename TO> __device__ __forceinline__ float load_out(const TO* p);
 template <> __device__ __forceinline__ float load_out<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float load_out<bf16_t>(const bf16_t* p) { return bf2f(*p); }
 
-// Reduce-scatter over the 32 lanes of a half-wave: every lane brings 32 values (index k), lane `lrow` leaves with the total of value index
-// lrow in gx[0].  After the stage with mask m a lane keeps the half of its values selected by its own bit m: 16 + 8 + 4 + 2 + 1 exchanges.
-// (bit select, not ?: -- the compiler turns a select between two array elements into a lane-indexed array access, i.e. a 32-way compare
-//  chain per value)
-__device__ __forceinline__ void halfwave_reduce_scatter32(float (&gx)[32], int lrow) {
-#pragma unroll
-    for (int st = 0; st < 5; ++st) {
-        const int m = 16 >> st, n = 16 >> st;           // lane mask, values kept after this stage
-        const unsigned up = (lrow & m) ? 0xffffffffu : 0u;
-#pragma unroll
-        for (int k = 0; k < n; ++k) {
-            const unsigned a = __float_as_uint(gx[k]), b = __float_as_uint(gx[k + n]);
-            const float send = __uint_as_float((a & up) | (b & ~up));
-            const float keep = __uint_as_float((b & up) | (a & ~up));
-            gx[k] = keep + __shfl_xor(send, m, 64);
-        }
-    }
-}
-
 // EPI = 1: "direct" epilogue.  The MFMA operands are swapped (W fragment as the row operand, A fragment as the column operand)
 // and the W rows of each 32-row block are read in the order  row(i') = 16*((i'>>2)&1) + 4*(i'>>3) + (i'&3), so that lane
 // (m = l & 31, h = l >> 5) ends up with accumulator register r = output column 16*h + r of its row: 16 CONTIGUOUS columns per
@@ -2223,7 +2204,10 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
                 // that carry nothing tile-numbered (no fused GroupNorm statistics, no LayerNorm producer role, no fp8 output, one W).
                 static const int tail_on = tune_env("RF_TAIL_SPLIT", 1);
                 const long long tiles_ = mt256 * nt, full_ = tiles_ / 256, rem_ = tiles_ - full_ * 256;
-                if (tail_on && !n320 && full_ >= 1 && rem_ * 5 >= 256 && rem_ * 5 <= 3 * 256 && (full_ * 256) % mt256 == 0 && p.gn_rows == 0 && !p.ln_out && !p.oscale &&
+                // (... and whose tail still fills the chip with 8-wave 128-row tiles: smaller tails fall to 4-wave tiles without the direct epilogue a
+                //  LayerNorm consumer needs)
+                const long long tail_nt_ = full_ >= 1 && mt256 > 0 ? nt - full_ * 256 / mt256 : 0;
+                if (tail_on && !n320 && full_ >= 1 && rem_ * 5 >= 256 && rem_ * 5 <= 3 * 256 && (full_ * 256) % mt256 == 0 && mt128 * tail_nt_ >= 192 && p.gn_rows == 0 && !p.ln_out && !p.oscale &&
                     !p.w_ps && !p.x3 && d->batch == 1 && (d->act == RF_ACT_NONE || d->act == RF_ACT_GEGLU)) {
                     const int n1 = (int)(full_ * 256 / mt256) * 256;                       // columns of the whole rounds
                     auto part = [&](int n_off, int n_len) {

@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_PRELU, ACT_QUICK_GELU, ACT_RELU, ACT_SIGMOID, ACT_SILU, RF_BF16, RF_BF16X3, RF_F32,
-                   RF_FP8_E4M3, ConvGemmDesc)
+                   RF_FP8_E4M3, ConvGemmDesc, FfnDesc)
 
 # Attention scores in the exp2 domain: the UNet folds d^-0.5 * log2(e) into the to_q weights and calls rf_attention with scale = ln 2
 # (the kernels then multiply by exactly 1: no second rounding of q * scale to bf16 in the pipelined d = 40 kernel).
@@ -143,6 +143,27 @@ def ffn_geglu(x, w1p, b1p, w2q, b2, out, *, residual=None, ln_eps=0.0, name="ffn
     return Launch(lib.rf_ffn_geglu, (_p(x), x.stride(0), _p(w1p), _p(b1p), _p(w2q), _p(b2), _p(residual),
                                      residual.stride(0) if residual is not None else 0, _p(out), out.stride(0), M, Cc, float(ln_eps)),
                   (x, w1p, b1p, w2q, b2, out, residual), name)
+
+
+def ffn_block(x, w1p, b1p, w2q, b2, out, *, residual, wpo, bpo, res2, res2_rows=0, ln_eps=0.0, name="ffn_block"):
+    """The token-resident tail of a SpatialTransformer block at C = 320 (rf_ffn_block): out[M, C] = ((GEGLU(LN?(x) W1^T + b1)) W2^T + b2 + residual)
+    Wpo^T + bpo + res2[row % res2_rows] in one kernel.  x / residual / res2 / out: bf16 row-strided 2-D views; wpo [C, C] bf16 contiguous (plain rows).
+    The launch can emit the GroupNorm statistics of `out` (fuse_groupnorm_stats accepts it as a producer: 128-row blocks, all C columns)."""
+    lib = _lib.load()
+    _require_gpu(x, w1p, b1p, w2q, b2, out, residual, wpo, bpo, res2)
+    M, Cc = x.shape
+    assert x.dtype == w1p.dtype == w2q.dtype == out.dtype == wpo.dtype == torch.bfloat16 and b1p.dtype == b2.dtype == bpo.dtype == torch.float32
+    assert w1p.shape == (8 * Cc, Cc) and w2q.shape == (Cc, 4 * Cc) and wpo.shape == (Cc, Cc) and w1p.is_contiguous() and w2q.is_contiguous() and wpo.is_contiguous()
+    assert x.stride(1) == 1 and out.stride(1) == 1 and out.shape == (M, Cc)
+    assert residual is None or (residual.stride(1) == 1 and residual.dtype == out.dtype and residual.shape == (M, Cc))
+    assert res2 is None or (res2.stride(1) == 1 and res2.dtype == out.dtype and res2.shape == ((res2_rows or M), Cc))
+    d = FfnDesc()
+    d.x, d.ldx, d.w1p, d.b1p, d.w2q, d.b2 = _p(x), x.stride(0), _p(w1p), _p(b1p), _p(w2q), _p(b2)
+    d.residual, d.ldr = _p(residual), (residual.stride(0) if residual is not None else 0)
+    d.out, d.ldo, d.M, d.C, d.ln_eps = _p(out), out.stride(0), M, Cc, float(ln_eps)
+    d.wpo, d.bpo = _p(wpo), _p(bpo)
+    d.res2, d.ldr2, d.res2_rows = _p(res2), (res2.stride(0) if res2 is not None else 0), int(res2_rows)
+    return Launch(lib.rf_ffn_block, (C.byref(d),), (d, x, w1p, b1p, w2q, b2, out, residual, wpo, bpo, res2), name)
 
 
 class Fp8Weight:
@@ -597,11 +618,16 @@ def fuse_groupnorm_stats(x, producers):
     plans, slot_of, nslots = [], {}, 0
     for l, row0, rows, col0, cols in producers:
         d = l.keep[0]
-        if l.fn.__name__ != "rf_conv_gemm" or d.act == ACT_GEGLU or d.batch != 1 or (d.gn_part0 and d.gn_part1):
-            return None
-        if row0 % HW or rows % HW or d.M != rows or d.N != cols:
-            return None
-        bm, bn, sk = gemm_plan(l)
+        if l.fn.__name__ == "rf_ffn_block":          # the fused transformer tail: 128-token blocks over all C columns
+            if (d.gn_part0 and d.gn_part1) or not d.wpo or row0 % HW or rows % HW or d.M != rows or d.C != cols:
+                return None
+            bm, bn = 128, cols
+        else:
+            if l.fn.__name__ != "rf_conv_gemm" or d.act == ACT_GEGLU or d.batch != 1 or (d.gn_part0 and d.gn_part1):
+                return None
+            if row0 % HW or rows % HW or d.M != rows or d.N != cols:
+                return None
+            bm, bn, sk = gemm_plan(l)
         if HW % bm:
             return None
         per_sample = (HW // bm) * ((cols + bn - 1) // bn)

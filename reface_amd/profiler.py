@@ -21,6 +21,8 @@ def launch_family(l):
         if d.dtype == 3:
             return "rf_conv_gemm[bf16x3]"        # split-bf16 operand pairs, three bf16 MFMA passes per product, fp32 accumulate / output
         return f"rf_conv_gemm[{'bf16' if d.dtype == 1 else 'f32'}]"
+    if n == "rf_ffn_block":
+        return "rf_ffn_geglu"          # (one family with the plain fused feed-forward: the same kernel)
     return n
 
 
@@ -37,6 +39,9 @@ def gemm_flops(l):
 
 def ffn_flops(l):
     """rf_ffn_geglu: 2*M*C*8C (GEGLU projection) + 2*M*4C*C (ff.net.2)."""
+    if l.fn.__name__ == "rf_ffn_block":          # + proj_out (2*M*C*C) when fused behind the feed-forward
+        d = l.keep[0]
+        return 2.0 * d.M * d.C * 8 * d.C + 2.0 * d.M * 4 * d.C * d.C + (2.0 * d.M * d.C * d.C if d.wpo else 0.0)
     if l.fn.__name__ != "rf_ffn_geglu":
         return 0.0
     M, C_ = l.args[10], l.args[11]

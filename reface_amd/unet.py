@@ -113,6 +113,9 @@ class UNetEngine:
         self.hx_on = os.environ.get("REFACE_HX", "1") == "1"
         # SpatialTransformer.norm (GroupNorm, no SiLU) folded into proj_in's weights per sample (rf_groupnorm_fold_linear): REFACE_GN_FOLD=0 keeps the pass
         self.gn_fold_lin = os.environ.get("REFACE_GN_FOLD", "1") == "1"
+        # proj_out fused behind the feed-forward kernel of the C = 320 blocks (rf_ffn_block): REFACE_TAIL_FUSE=0 keeps the separate proj_out launches
+        self.tail_fuse = os.environ.get("REFACE_TAIL_FUSE", "1") == "1"
+        self.n_tail_fused = 0
         self.out_fuse = os.environ.get("REFACE_OUT_FUSE", "1") == "1"          # `out` head (GroupNorm + SiLU + 3x3 conv to 4 channels) as one pass (csrc/smallconv.hip)
         self.gn_fold_maxc = int(os.environ.get("REFACE_GN_FOLD_MAXC", "640"))
         self.n_gn_folded = 0
@@ -483,6 +486,23 @@ class UNetEngine:
             x2 = ln
             self.main.append(ops.linear(gg, self.gw(self.sd[f"{t}.ff.net.2.weight"]), x2, self.f32(f"{t}.ff.net.2.bias"), residual=x1, name=f"{t}.ff.net.2"))
             self.pool.put(gg)
+        elif fused_ffn and self.tail_fuse and x.stride(3) == 1 and x.stride(1) == W * x.stride(2) and (B == 1 or x.stride(0) == H * x.stride(1)):
+            # one kernel for the whole token-resident tail of the block: feed-forward (hidden tensor in registers) + residual + proj_out + `x + x_in`
+            # (csrc/ffn.hip, rf_ffn_block) -- the feed-forward's output never leaves the CU, the proj_out launches and their re-read of it are gone;
+            # the statistics of the GroupNorm that reads the block's output come from this kernel's epilogue (the launch is a statistics producer)
+            y = dst if dst is not None else self.pool.get((nb * B, H, W, c), self.dt)
+            y2 = y.as_strided((nb * M, c), (y.stride(2), 1))
+            assert y.stride(3) == 1 and y.stride(1) == W * y.stride(2) and y.stride(0) == H * y.stride(1)
+            x_rows = x.as_strided((M, c), (x.stride(2), 1))
+            self._add(ops.ffn_block(x1 if fold else ln, wg.to(self.dt).contiguous(), bg, ops.pack_ffn_w2(self.sd[f"{t}.ff.net.2.weight"], self.dt),
+                                    self.f32(f"{t}.ff.net.2.bias"), y2, residual=x1, wpo=self.sd[f"{p}.proj_out.weight"].reshape(c, c).to(self.dt).contiguous(),
+                                    bpo=self.f32(f"{p}.proj_out.bias"), res2=x_rows, res2_rows=M if nb > 1 else 0, ln_eps=1e-5 if fold else 0.0,
+                                    name=f"{t}.ff+proj_out"), y)
+            if not fold:
+                self.pool.put(ln)
+            self.pool.put(x1)
+            self.n_tail_fused += 1
+            return y
         elif fused_ffn:
             # one kernel: the [M, 4C] hidden tensor (168 MB at 64x64) stays in registers (csrc/ffn.hip)
             x2 = self.pool.get((nb * M, c), self.dt)

@@ -574,7 +574,7 @@ def test_quantize_fp8_rows_edge_rows_vs_numpy_e4m3(k):
     rows[2, :len(up)] = up
     rows[2, len(up):2 * len(up)] = -dn
     rows[2, K - 1] = np.float32(448.0 * sc)
-    put(3, [2.0 ** -11, 2.0 ** -10, 3 * 2.0 ** -11, 2.0 ** -10 * 0.999, 2.0 ** -9, 1.5 * 2.0 ** -9, 2.5 * 2.0 ** -9, 7.5 * 2.0 ** -9, 0.0, -0.0, -2.0 ** -10, -3 * 2.0 ** -11, 2.0 ** -20])
+    put(3, [2.0 ** -11, 2.0 ** -10, 3 * 2.0 ** -11, 2.0 ** -10 * (1 - 2.0 ** -24), 2.0 ** -9, 1.5 * 2.0 ** -9, 2.5 * 2.0 ** -9, 7.5 * 2.0 ** -9, 0.0, -0.0, -2.0 ** -10, -3 * 2.0 ** -11, 2.0 ** -20])
     rows[4, 0] = np.nextafter(np.float32(448.0 * sc), np.float32(np.inf))
     rows[4, 1] = np.float32(448.0 * sc)
     rows[4, 2] = np.float32(-447.0 * sc)
@@ -710,6 +710,75 @@ def test_ffn_geglu_fused_with_layernorm(M):
     d = (out.float() - out_u.float()).abs().max().item()
     print(f"ffn + in-kernel LayerNorm vs LayerNorm pass + ffn (M = {M}): max |d| = {d:.3e} at |out| max {ref.abs().max().item():.2f}")
     assert d <= 2.0 ** -5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,hw,pair,concat", [(2, 32, False, False), (16, 64, False, False), (4, 32, True, False), (3, 16, False, True), (16, 64, True, True)])
+def test_ffn_block_fused_tail(B, hw, pair, concat):
+    """rf_ffn_block: the token-resident tail of a SpatialTransformer block at C = 320 -- norm3 + GEGLU feed-forward + residual (attention.py:40-76,
+    231-233, 243) + proj_out + `x + x_in` (attention.py:268-272, 288-289) in ONE kernel, with the GroupNorm statistics of the block's output from its
+    epilogue.  Against the unfused chain on the GPU (rf_ffn_geglu, then proj_out as rf_conv_gemm with the residual): the same bf16 roundings (the
+    feed-forward's output row is rounded to bf16 where the chain stores it), so a few bf16 steps at most; against an fp32 reference with those
+    roundings; statistics through rf_groupnorm_apply against F.group_norm of the stored output.  pair: the residual x_in has half the rows and is
+    shared by both batch halves (the CFG-shared first block).  concat: the output is the right half of a [.., 640] concat buffer whose left half
+    another GEMM produces -- the decoder's GroupNorm over [h | skip] takes its statistics from both producers."""
+    dt, Cc = torch.bfloat16, 320
+    HW = hw * hw
+    nb = 2 if pair else 1
+    M = nb * B * HW
+    x1, x1r = q(rnd((M, Cc), 820) * 1.3 + 0.3, dt)                       # the post-attention residual stream (input of norm3 / the feed-forward)
+    xin, xinr = q(rnd((B * HW, Cc), 821), dt)                           # the transformer's input x_in (B samples; shared by the halves when pair)
+    gamma, beta = rnd((Cc,), 822) * 0.3 + 1.0, rnd((Cc,), 823) * 0.2
+    w1 = rnd((8 * Cc, Cc), 824) / math.sqrt(Cc)
+    b1 = rnd((8 * Cc,), 825) * 0.5
+    w2 = rnd((Cc, 4 * Cc), 826) / math.sqrt(4 * Cc)
+    b2 = rnd((Cc,), 827)
+    wpo = rnd((Cc, Cc), 828) / math.sqrt(Cc)
+    bpo = rnd((Cc,), 829)
+    w1f, b1f = ops.fold_layernorm_geglu(w1, b1, gamma, beta)
+    w1p, b1p = ops.pack_geglu(w1f, b1f, dt)
+    w2q = ops.pack_ffn_w2(w2.to(DEV), dt)
+    Ct = 2 * Cc if concat else Cc
+    buf = torch.zeros((nb * B, hw, hw, Ct), dtype=dt, device=DEV)
+    y = buf[..., Ct - Cc:]
+    y2 = y.as_strided((M, Cc), (y.stride(2), 1))
+    lf = ops.ffn_block(x1, w1p.to(DEV), b1p.to(DEV), w2q, b2.to(DEV), y2, residual=x1, wpo=wpo.to(dt).to(DEV), bpo=bpo.to(DEV), res2=xin,
+                       res2_rows=B * HW if pair else 0, ln_eps=1e-5)
+    prods = [(lf, 0, M, Ct - Cc, Cc)]
+    if concat:
+        a0, _ = q(rnd((M, 64), 830), dt)
+        wl = rnd((Cc, 64), 831) / 8.0
+        left = buf[..., :Cc]
+        ll = ops.linear(a0, wl.to(dt).to(DEV), left.as_strided((M, Cc), (left.stride(2), 1)), rnd((Cc,), 832).to(DEV))
+        prods.insert(0, (ll, 0, M, 0, Cc))
+    fused = ops.fuse_groupnorm_stats(buf, prods)
+    assert fused is not None
+    if concat:
+        ll()
+    lf()
+    ops.run(fused[2])
+    g2, be2 = rnd((Ct,), 833) * 0.2 + 1, rnd((Ct,), 834) * 0.2
+    yn = torch.empty_like(buf)
+    ops.groupnorm_apply(buf, g2.to(DEV), be2.to(DEV), yn, fused[0], fused[1], eps=1e-5, silu=True)()
+    # the unfused chain: fused feed-forward kernel (its own output tensor), then proj_out + residual as a GEMM
+    x2 = torch.empty((M, Cc), dtype=dt, device=DEV)
+    ops.ffn_geglu(x1, w1p.to(DEV), b1p.to(DEV), w2q, b2.to(DEV), x2, residual=x1, ln_eps=1e-5)()
+    yu = torch.empty((M, Cc), dtype=dt, device=DEV)
+    for hf in range(nb):
+        ops.linear(x2[hf * B * HW:(hf + 1) * B * HW], wpo.to(dt).to(DEV), yu[hf * B * HW:(hf + 1) * B * HW], bpo.to(DEV), residual=xin)()
+    torch.cuda.synchronize()
+    # fp32 reference with the chain's roundings
+    xhat = F.layer_norm(x1r, (Cc,), None, None, 1e-5).to(dt).float()
+    a, g = F.linear(xhat, w1f.to(dt).float(), b1f).chunk(2, -1)
+    hid = (a * F.gelu(g, approximate="tanh")).to(dt).float()
+    x2r = (F.linear(hid, w2.to(dt).float(), b2) + x1r).to(dt).float()
+    ref = F.linear(x2r, wpo.to(dt).float(), bpo) + xinr.repeat(nb, 1)
+    got = y2.float().cpu()
+    check(got, ref, dt)
+    d = (got - yu.float().cpu()).abs().max().item()
+    print(f"fused tail vs unfused chain (B {B}, {hw}x{hw}, pair {pair}, concat {concat}): max |d| = {d:.3e} at |out| max {ref.abs().max().item():.2f}")
+    assert d <= 2.0 ** -5 * max(1.0, ref.abs().max().item())
+    refn = F.silu(F.group_norm(buf.float().cpu().permute(0, 3, 1, 2), 32, g2, be2, 1e-5)).permute(0, 2, 3, 1)
+    check(yn, refn, dt)
 
 
 @pytest.mark.parametrize("M,K0,Cc,N,geglu,res", [(4096, 320, 320, 960, False, False), (65536, 320, 320, 960, False, True), (16384, 640, 640, 5120, True, True),
