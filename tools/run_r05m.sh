@@ -1,0 +1,24 @@
+#!/bin/bash
+# r05m: the round's evidence on the FINAL library, one call per part (tools/run_r05m.sh a|b|c)
+part=$1
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+T=r05m
+case $part in
+a)  # c1: GPU suite, rocprofv3 stats, bench lines, PMC traffic, matrix-pipe occupancy
+    timeout 3000 python -m pytest tests/ -x -q -m gpu > gpurun_out/${T}_pytest_gpu.log 2>&1; tail -3 gpurun_out/${T}_pytest_gpu.log
+    python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${T}_smoke.log 2>&1; tail -1 gpurun_out/${T}_smoke.log
+    EXTRA="" bash tools/profile_round.sh $T c1 2>&1 | tail -4
+    EXTRA="" bash tools/pmc_mfma.sh ${T}_c1 c1 2>&1 | head -8
+    ;;
+b)  # c3 and both c4 forms: bench lines + PMC traffic
+    EXTRA="" bash tools/profile_round.sh $T c3 2>&1 | tail -4
+    EXTRA="" bash tools/profile_round.sh $T c4 2>&1 | tail -4
+    EXTRA="--dtype fp8c" bash tools/pmc_traffic.sh ${T}_c4fp8c c4 | head -6
+    rm -rf gpurun_out/${T}_c4fp8c_pmc_FETCH_SIZE gpurun_out/${T}_c4fp8c_pmc_WRITE_SIZE
+    ;;
+c)  # the default line as the driver runs it (after the PMC passes are committed: traffic matched by digest)
+    python3 bench.py --steps 5 --warmup 2 > gpurun_out/${T}_default_bench.json 2> gpurun_out/${T}_default_bench.log
+    tail -12 gpurun_out/${T}_default_bench.log
+    python3 tools/clock_probe.py > gpurun_out/${T}_clock_probe.txt 2>&1; tail -2 gpurun_out/${T}_clock_probe.txt
+    ;;
+esac
