@@ -15,6 +15,10 @@
 // per-wave bias slots -- 148 KB.  Hidden dimension in chunks of 64 (20 chunks).
 #include "common.h"
 
+#ifndef RF_FFN_SPREAD
+#define RF_FFN_SPREAD 2          // 0: bursts behind the barriers (rounds 3-4) | 1: the W2 pieces two per K tile | 2: every LDS-DMA piece between MFMAs (profiles/r05n_ffn_dma_spread.txt)
+#endif
+
 namespace rf {
 
 struct FfnParams {
@@ -142,6 +146,24 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (__attribute__((address_space(3))) void*)(base + rg * 1024), 16, off, c * 128, 0, 0);
         }
     };
+    auto issue_w1_piece = [&](int g, int q) {                  // piece q of W1 tile g (RF_FFN_SPREAD 2)
+        const int c = g / CK, kt = g - c * CK;
+        char* base = smem + (g % NS1) * W1B;
+        const int rg = wave + 4 * q, r = rg * 8 + prow;
+        const int off = (c * 128 + r) * C * 2 + kslot(r);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (__attribute__((address_space(3))) void*)(base + rg * 1024), 16, off, kt * 128, 0, 0);
+    };
+    auto issue_w2_part = [&](int c, int q0, int q1) {          // pieces [q0, q1) of W2 chunk c (RF_FFN_SPREAD)
+        char* base = smem + OFF_W2 + (c & 1) * W2B;
+#pragma unroll
+        for (int q = 0; q < NPW2; ++q) {
+            if (q >= q0 && q < q1) {
+                const int rg = wave + 4 * q, r = rg * 8 + prow;
+                const int off = r * F * 2 + kslot(r);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (__attribute__((address_space(3))) void*)(base + rg * 1024), 16, off, c * 128, 0, 0);
+            }
+        }
+    };
     auto issue_b1 = [&](int c) {                          // this wave's private copy of the chunk's 128 bias values (2 x 64 floats)
         char* base = smem + OFF_B + ((c & 1) * 4 + wave) * 512;
 #pragma unroll
@@ -151,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
 
     // ---- prologue: W1 tiles 0 .. NS1-1, W2 chunk 0, bias chunk 0
 #pragma unroll
-    for (int g = 0; g < NS1; ++g) issue_w1(g);
+    for (int g = 0; g < (RF_FFN_SPREAD == 2 ? NS1 - 1 : NS1); ++g) issue_w1(g);
     issue_w2(0);
     issue_b1(0);
 
@@ -194,10 +216,43 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
                     acc1[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[cur][b]), __builtin_bit_cast(bf16x8_t, xq[kt * 4 + kk]), acc1[b], 0, 0, 0);
+#if RF_FFN_SPREAD == 2
+                // one LDS-DMA piece behind every k-step's MFMAs (their issue slots hide under the matrix pipe): W1 tile g + 3 into the stage tile g - 1
+                // left at the last barrier, the next chunk's W2 pieces behind k-steps 1 and 3, its bias behind the last k-step of K tile 0
+                static_assert(NPW1 == 4, "one W1 piece per k-step");
+                if (g + NS1 - 1 < NCH * CK) issue_w1_piece(g + NS1 - 1, kk);
+                if (!last && (kk & 1)) issue_w2_part(c + 1, kt * (NPW2 / CK) + (kk >> 1), kt * (NPW2 / CK) + (kk >> 1) + 1);
+                if (!last && kt == 0 && kk == 3) issue_b1(c + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             }
             // Tile g+1 must have landed.  Loads complete in order, so it suffices that at most the pieces issued AFTER it are still in
             // flight: W1(g+2), W1(g+3) (8 pieces) and, for kt = 1..3, the W2 / bias group of the next chunk issued behind W1(g0+4).
             // The last chunk drains everything (the ring is running empty there).
+#if RF_FFN_SPREAD == 2
+            // Behind the last piece of W1(g+1) -- issued at k-step 3 of iteration g - 2 -- lie that iteration's second W2 piece (+ bias) and two whole
+            // iterations of 6 pieces (+ 2 for a bias): 13, + 2 when one of the three iterations was a K tile 0 (kt in {0, 1, 2})
+            static_assert(NPW2 / CK == 2 && NPW2 % CK == 0, "two W2 pieces per K tile");
+            if (last) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else if (kt <= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(13 + NPB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(13) : "memory");
+            __builtin_amdgcn_s_barrier();                 // every wave is done with tile g: its stage is refilled during the next iteration
+#elif RF_FFN_SPREAD
+            // The next chunk's W2 pieces go out two per K tile instead of ten behind K tile 0 (one wave per SIMD: a burst of 16 LDS-DMA pieces stalls
+            // the wave's issue for ~1.5 k cycles with nothing else to feed the matrix pipe).  Behind W1(g+1) -- issued first thing three iterations
+            // ago -- lie that iteration's W2 part (+ bias) and two whole iterations: 3 x 2 + 2 x 4 pieces, + 2 when one of them was a K tile 0.
+            constexpr int PW2 = NPW2 / CK;
+            static_assert(NPW2 % CK == 0, "W2 pieces spread evenly over the K tiles");
+            if (last) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else if (kt >= 1 && kt <= 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NPW1 + 3 * PW2 + NPB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NPW1 + 3 * PW2) : "memory");
+            __builtin_amdgcn_s_barrier();                 // every wave is done with tile g: its stage may be refilled
+            if (g + NS1 < NCH * CK) issue_w1(g + NS1);
+            if (!last) {
+                issue_w2_part(c + 1, kt * PW2, (kt + 1) * PW2);          // buffer (c+1)&1 was last read by GEMM 2 of chunk c-1 (barrier at its end)
+                if (kt == 0) issue_b1(c + 1);
+            }
+#else
             if (last) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             else if (kt >= 1 && kt <= 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NPW1 + NPW2 + NPB) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NPW1) : "memory");
@@ -207,6 +262,7 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
                 issue_w2(c + 1);                          // buffer (c+1)&1 was last read by GEMM 2 of chunk c-1 (barrier at its end)
                 issue_b1(c + 1);
             }
+#endif
         }
         // ---- GEGLU in registers: h = (value + bv) * gelu(gate + bg), packed to the B fragments of GEMM 2
         u32x4_t hb[4];
@@ -265,7 +321,7 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
     // (three buffers: the two W2 buffers and 40 KB of the dead W1 ring behind the bias / statistics scratch -- three tiles in flight: a K tile's 40
     //  MFMAs per wave are shorter than an L2 round trip)
 #ifndef RF_WP_BUFS
-#define RF_WP_BUFS 2          // (3 = + 40 KB of the dead W1 ring: measured equal, profiles/r05i_fused_tail_ab.txt)
+#define RF_WP_BUFS (RF_FFN_SPREAD == 2 ? 3 : 2)          // (bursts through two or three buffers: measured equal, profiles/r05i_fused_tail_ab.txt)
 #endif
     constexpr int WPB = RF_WP_BUFS;
     auto wp_buf = [&](int kt) -> char* { return kt % WPB == 2 ? smem + W1B : smem + OFF_W2 + (kt % WPB) * W2B; };
@@ -281,7 +337,7 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
     };
     if (proj) {
 #pragma unroll
-        for (int kt = 0; kt < WPB; ++kt) issue_wp(kt);
+        for (int kt = 0; kt < (RF_FFN_SPREAD == 2 ? 2 : WPB); ++kt) issue_wp(kt);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (!proj) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -348,18 +404,39 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
         if (nb + PFD < NB) load_res(nb + PFD, rq[nb % PFD]);
         __builtin_amdgcn_sched_barrier(0);
     }
-    // (b) Z^T = Wpo . X2^T : CK K tiles of 64 through three buffers
+    // (b) Z^T = Wpo . X2^T : CK K tiles of 64
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
+    auto issue_wp_part = [&](int kt, int q0, int q1) {
+        char* base = wp_buf(kt);
+#pragma unroll
+        for (int q = 0; q < NPW2; ++q) {
+            if (q >= q0 && q < q1) {
+                const int rg = wave + 4 * q, r = rg * 8 + prow;
+                const int off = r * C * 2 + kslot(r);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsWp, (__attribute__((address_space(3))) void*)(base + rg * 1024), 16, off, kt * 128, 0, 0);
+            }
+        }
+    };
 #pragma unroll
     for (int kt = 0; kt < CK; ++kt) {
+#if RF_FFN_SPREAD == 2
+        // three buffers, the pieces of tile kt + 2 between the MFMAs of tile kt (buffer (kt + 2) % 3 was last read by tile kt - 1: every wave has left it
+        // at the barrier below) -- one barrier per tile, no burst
+        static_assert(WPB == 3, "interleaved Wpo stream: three buffers");
+        if (kt + 1 < CK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW2) : "memory");          // tile kt landed; tile kt + 1 may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#else
         // tile kt landed; the (up to two) tiles issued behind it may still fly
         if (kt == 0 || kt + 1 >= CK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (kt + WPB - 1 < CK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WPB - 1) * NPW2) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW2) : "memory");
         __builtin_amdgcn_s_barrier();
+#endif
         {
             const char* const w2base = wp_buf(kt) + brow * 128;
             u32x4_t af[2];
@@ -375,11 +452,17 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
                     }
                     acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[cur]), __builtin_bit_cast(bf16x8_t, hb3[kt * 4 + kk]), acc2[nb], 0, 0, 0);
                 }
+#if RF_FFN_SPREAD == 2
+                if (kt + 2 < CK) issue_wp_part(kt + 2, kk * 3, kk * 3 + 3 < NPW2 ? kk * 3 + 3 : NPW2);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         }
+#if RF_FFN_SPREAD != 2
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // every wave is done with this buffer
         if (kt + WPB < CK) issue_wp(kt + WPB);
+#endif
     }
     // (c) + bpo + the transformer's input (attention.py:289 `return x + x_in`; the CFG-shared first block: both batch halves read the same rows),
     // 16-byte stores, GroupNorm partial sums of the values as stored

@@ -119,6 +119,21 @@ def test_cabi_exports_match_header():
         names = line.split(None, 1)[1] if not line.startswith("const") else line.split("*", 1)[1]
         cfields += [n.strip().lstrip("*") for n in names.replace("*", " ").split(",") if n.strip()]
     assert [f[0] for f in _lib.ConvGemmDesc._fields_] == cfields, cfields
+    # ... and of rf_ffn_desc (declarations separated by ';', several per line)
+    m2 = re.search(r"typedef struct rf_ffn_desc \{(.*?)\} rf_ffn_desc;", hdr, re.S)
+    body = re.sub(r"/\*.*?\*/", "", m2.group(1), flags=re.S)
+    ffields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split("*", 1)[1] if "*" in decl else decl.split(None, 1)[1]
+        ffields += [n.strip().lstrip("*") for n in names.split(",") if n.strip()]
+    assert [f[0] for f in _lib.FfnDesc._fields_] == ffields, ffields
+    sizes = {"x": 8, "ldx": 4, "ln_eps": 4, "gn_part1": 8, "gn_nchunks1": 4}
+    for f, t in _lib.FfnDesc._fields_:
+        if f in sizes:
+            assert ctypes.sizeof(t) == sizes[f], f
     # argument validation happens before any launch, so it is testable without a GPU
     d = _lib.ConvGemmDesc()
     assert lib.rf_conv_gemm(ctypes.byref(d), None) != 0

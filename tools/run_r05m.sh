@@ -20,5 +20,12 @@ c)  # the default line as the driver runs it (after the PMC passes are committed
     python3 bench.py --steps 5 --warmup 2 > gpurun_out/${T}_default_bench.json 2> gpurun_out/${T}_default_bench.log
     tail -12 gpurun_out/${T}_default_bench.log
     python3 tools/clock_probe.py > gpurun_out/${T}_clock_probe.txt 2>&1; tail -2 gpurun_out/${T}_clock_probe.txt
+    # host half of the CLI at 8 processes (no GPU used: the device is a sleep of the measured batch time): the reference's PNG level for every file,
+    # results/ at the reference's level + the aux files at level 1 (--fast_aux_png), everything at level 1
+    for v in "" "--aux-png-level 1" "--png-level 1"; do
+      tagv=$(echo "png6$v" | tr -d ' -')
+      python3 tools/host_scaling_probe.py --natural --gpu-prep --device-ms 830 $v > gpurun_out/${T}_host_probe_${tagv}.json 2> gpurun_out/${T}_host_probe_${tagv}.log
+      cat gpurun_out/${T}_host_probe_${tagv}.json | cut -c1-400
+    done
     ;;
 esac
