@@ -105,6 +105,7 @@ class UNetEngine:
         # GEGLU + ff.net.2 of the C = 320 blocks as ONE kernel (csrc/ffn.hip): 213 us against 150 + 80 for the pair inside the step -- the pair's
         # epilogues are store-bound and ff.net.2's residual segments cost ~20 us; -0.4 % per batch, same box (tools/exp_r03_17.sh).  =0: the pair
         self.ffn_fuse = os.environ.get("REFACE_FFN_FUSE", "1") == "1"
+        self.ffn_whole = float(os.environ.get("REFACE_FFN_WHOLE", "0.9"))          # least fill of the fused kernel's last round of 128-token blocks
         # norm3 inside the fused feed-forward kernel (C = 320 blocks): REFACE_LN_FOLD=0 keeps the separate LayerNorm pass
         self.ln_fold = os.environ.get("REFACE_LN_FOLD", "1") == "1"
         # norm1 / norm3 folded around their neighbour GEMMs (producer statistics + consumer epilogue affine; bf16 mode): REFACE_LN_FOLD_GEMM=0 off
@@ -454,7 +455,7 @@ class UNetEngine:
         #  are 2.25 rounds of 256 CUs and lose 0.5 % per batch against the pair, tools/exp_r03_20.sh)
         nblk = (nb * M + 127) // 128
         whole = nblk / (self.n_cu * ((nblk + self.n_cu - 1) // self.n_cu))
-        fused_ffn = self.ffn_fuse and c == 320 and self.dt == torch.bfloat16 and not self.w8 and whole >= 0.9
+        fused_ffn = self.ffn_fuse and c == 320 and self.dt == torch.bfloat16 and not self.w8 and whole >= self.ffn_whole
         fold = fused_ffn and self.ln_fold
         w1s, b1s = self.sd[f"{t}.ff.net.0.proj.weight"], self.sd[f"{t}.ff.net.0.proj.bias"]
         if fold:
