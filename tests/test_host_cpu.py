@@ -326,6 +326,19 @@ def test_output_writer_packed_records(tmp_path):
     for f in files:
         assert np.array_equal(np.asarray(Image.open(outs[0] / f)), np.asarray(Image.open(outs[1] / f))), f
     assert 2 <= O.default_writer_threads(8) <= 8 and 2 <= O.default_writer_threads(1) <= 8
+    # --fast_aux_png (aux_compress_level): results/<id>.png keeps the reference's bytes (PIL's default level), the samples/ and grid/ files change level
+    # only -- same pixels, other bytes
+    d = tmp_path / "c"
+    for sub in ("samples", "results", "grid"):
+        (d / sub).mkdir(parents=True)
+    w = O.OutputWriter(str(d), threads=2, aux_compress_level=1)
+    w.submit_u8(ids, recs, H, H)
+    assert w.close() == B
+    for f in files:
+        assert np.array_equal(np.asarray(Image.open(outs[0] / f)), np.asarray(Image.open(d / f))), f
+        same = (outs[0] / f).read_bytes() == (d / f).read_bytes()
+        assert same if f.startswith("results") else True, f
+    assert any((outs[0] / f).read_bytes() != (d / f).read_bytes() for f in files if not f.startswith("results"))
 
 
 def test_checkpoint_missing_engine_tensor_is_an_error():
