@@ -50,6 +50,21 @@ __global__ __launch_bounds__(256) void gn_silu_taps_kernel(const SmallConvParams
         xq[s] = u32x4_t{0u, 0u, 0u, 0u};
         if (live) xq[s] = *(const u32x4_t*)(p.x + grow * p.ldx + s * 16 + lhalf * 8);
     }
+    // ---- everything the scale / shift need is fetched NOW, beside the pixel values: the statistics partials of this thread's (group, part) and the
+    // affine parameters of its channels (one memory latency for the block, not three in a row)
+    double st_a = 0.0, st_q = 0.0;
+    {
+        const int g = tid & 31, part = tid >> 5;
+        for (int c = part; c < p.nchunks; c += 8) {
+            const double* pp = p.partial + (((long long)b * p.nchunks + c) * 32 + g) * 2;
+            st_a += pp[0];
+            st_q += pp[1];
+        }
+    }
+    float gm0 = 0.f, bt0 = 0.f, gm1 = 0.f, bt1 = 0.f;
+    if (tid < C) { gm0 = p.gamma[tid]; bt0 = p.beta[tid]; }
+    if (tid + 256 < C) { gm1 = p.gamma[tid + 256]; bt1 = p.beta[tid + 256]; }
+    static_assert(C <= 512, "two channels per thread");
     // ---- weight table: row r = tap * No + o  <-  w[o][tap * C .. + C)
     const int rows = 9 * p.No;
     for (int i = tid; i < rows * (C / 8); i += 256) {
@@ -59,15 +74,8 @@ __global__ __launch_bounds__(256) void gn_silu_taps_kernel(const SmallConvParams
     }
     // ---- statistics of sample b -> per-channel scale / shift (the preamble of gn_apply_kernel, norm.hip)
     {
-        const int g = tid & 31, part = tid >> 5;
-        double a = 0.0, q = 0.0;
-        for (int c = part; c < p.nchunks; c += 8) {
-            const double* pp = p.partial + (((long long)b * p.nchunks + c) * 32 + g) * 2;
-            a += pp[0];
-            q += pp[1];
-        }
-        red[tid][0] = a;
-        red[tid][1] = q;
+        red[tid][0] = st_a;
+        red[tid][1] = st_q;
         __syncthreads();
         if (tid < 32) {
             double sa = 0.0, sq = 0.0;
@@ -80,11 +88,17 @@ __global__ __launch_bounds__(256) void gn_silu_taps_kernel(const SmallConvParams
             rstd_s[tid] = (float)(1.0 / sqrt(var + (double)p.eps));
         }
         __syncthreads();
-        for (int c = tid; c < C; c += 256) {
-            const int g2 = c / (C / 32);
-            const float a2 = rstd_s[g2] * p.gamma[c];
+        if (tid < C) {
+            const int g2 = tid / (C / 32);
+            const float a2 = rstd_s[g2] * gm0;
+            scl[tid] = a2;
+            shl[tid] = bt0 - mean_s[g2] * a2;
+        }
+        if (tid + 256 < C) {
+            const int c = tid + 256, g2 = c / (C / 32);
+            const float a2 = rstd_s[g2] * gm1;
             scl[c] = a2;
-            shl[c] = p.beta[c] - mean_s[g2] * a2;
+            shl[c] = bt1 - mean_s[g2] * a2;
         }
         __syncthreads();
     }
@@ -147,7 +161,12 @@ __global__ __launch_bounds__(256) void gather_taps_kernel(const float* __restric
             const int sy = py + dy - 1, sx = px + dx - 1;
             if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) {
                 const float* src = y + (i + (dy - 1) * W + (dx - 1)) * SC_YP + (dy * 3 + dx) * No;
-                for (int o = 0; o < No; ++o) acc[o] += src[o];
+                if (No == 4) {          // (16-byte aligned: 160-byte rows, 16-byte tap groups)
+                    const f32x4_t v = *(const f32x4_t*)src;
+                    acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+                } else {
+                    for (int o = 0; o < No; ++o) acc[o] += src[o];
+                }
             }
         }
     for (int o = 0; o < No; ++o) elem<TO>::store(out + i * ldo + o, acc[o]);
