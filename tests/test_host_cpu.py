@@ -149,6 +149,14 @@ def test_fails_loudly_without_gpu():
     x = torch.zeros(4, 8)
     with pytest.raises(_lib.RefaceHipError, match="no CPU fallback"):
         ops.linear(x, torch.zeros(8, 8), torch.zeros(4, 8))
+    # the round-5 entry points too: the fused transformer tail and the fused `out` head refuse host tensors before anything is launched
+    bf = torch.bfloat16
+    with pytest.raises(_lib.RefaceHipError, match="no CPU fallback"):
+        ops.ffn_block(torch.zeros(128, 320, dtype=bf), torch.zeros(2560, 320, dtype=bf), torch.zeros(2560), torch.zeros(320, 1280, dtype=bf), torch.zeros(320),
+                      torch.zeros(128, 320, dtype=bf), residual=None, wpo=torch.zeros(320, 320, dtype=bf), bpo=torch.zeros(320), res2=None)
+    with pytest.raises(_lib.RefaceHipError, match="no CPU fallback"):
+        ops.gn_silu_conv3x3_small(torch.zeros(1, 8, 8, 64, dtype=bf), torch.ones(64), torch.zeros(64), torch.zeros(64, dtype=torch.float64), 1,
+                                  torch.zeros(4, 576, dtype=bf), torch.zeros(4), torch.zeros(1, 8, 8, 4), eps=1e-5)
     m = UNetModel(in_channels=9, model_channels=64, out_channels=4, num_res_blocks=2, attention_resolutions=(4, 2, 1),
                   channel_mult=(1, 2, 4, 4), num_heads=8, use_spatial_transformer=True, context_dim=768, legacy=False)
     with pytest.raises(RuntimeError, match="GPU only"):
