@@ -215,6 +215,29 @@ int rf_gn_silu_conv3x3_small(const void* x, int B, int H, int W, int C, int ldx,
                              const float* beta, float eps, int silu, const void* w, const float* bias, int No, int out_dtype, void* out, int ldo,
                              float* workspace, long long workspace_bytes, void* stream);
 
+/* The UNet's stem -- 3x3 convolution (stride 1, pad 1) from the 9 input channels (stored in 16) to C = model_channels (openaimodel.py:666-671:
+ * TimestepEmbedSequential(conv_nd(dims, in_channels, model_channels, 3, padding=1))) -- as one pixels-on-lanes kernel: x bf16 [B][H*W][ldx]
+ * (channels 0..15 of a pixel; pad channels zero), W bf16 [C][144] with k = tap * 16 + c, bias fp32 [C], out bf16 [B*H*W][ldo].
+ * dup_off != 0: every output row is also stored at out + dup_off elements (classifier-free guidance feeds both batch halves the same latent: one
+ * half is computed).  GroupNorm(32) partial sums of the values as stored for up to THREE consumers, as rf_conv_gemm_desc.gn_* (one chunk slot per
+ * 128-pixel block: slot = gn_slot + block within the sample; sample b of the kernel writes sample b of gn_part -- point gn_part at the consumer's first
+ * sample of this producer, e.g. the duplicate half).  H*W a multiple of 128; C in {320, 128, 64}.  Replaces rf_conv_gemm for this layer and the
+ * rf_groupnorm_stats pass over its output. */
+typedef struct rf_stem_desc {
+    const void* x; int32_t ldx;
+    int32_t B, H, W, C;
+    const void* w; const float* bias;
+    void* out; int32_t ldo;
+    long long dup_off;
+    double* gn_part0;
+    int32_t gn_cpg0, gn_coff0, gn_slot0, gn_nchunks0;
+    double* gn_part1;
+    int32_t gn_cpg1, gn_coff1, gn_slot1, gn_nchunks1;
+    double* gn_part2;
+    int32_t gn_cpg2, gn_coff2, gn_slot2, gn_nchunks2;
+} rf_stem_desc;
+int rf_conv3x3_stem(const rf_stem_desc* d, void* stream);
+
 
 /* LayerNorm over the last dim of [M, C] (eps, affine).  Replaces nn.LayerNorm (attention.py:231-233,
  * xf.py:22-28, HF CLIP layer norms). */

@@ -62,6 +62,20 @@ class FfnDesc(C.Structure):
     ]
 
 
+class StemDesc(C.Structure):
+    """Mirror of ``rf_stem_desc`` (include/reface_hip.h)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int32),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+        ("w", C.c_void_p), ("bias", C.c_void_p),
+        ("out", C.c_void_p), ("ldo", C.c_int32),
+        ("dup_off", C.c_longlong),
+        ("gn_part0", C.c_void_p), ("gn_cpg0", C.c_int32), ("gn_coff0", C.c_int32), ("gn_slot0", C.c_int32), ("gn_nchunks0", C.c_int32),
+        ("gn_part1", C.c_void_p), ("gn_cpg1", C.c_int32), ("gn_coff1", C.c_int32), ("gn_slot1", C.c_int32), ("gn_nchunks1", C.c_int32),
+        ("gn_part2", C.c_void_p), ("gn_cpg2", C.c_int32), ("gn_coff2", C.c_int32), ("gn_slot2", C.c_int32), ("gn_nchunks2", C.c_int32),
+    ]
+
+
 _SIGS = {
     "rf_last_error": (C.c_char_p, []),
     "rf_version": (C.c_int, []),
@@ -80,6 +94,7 @@ _SIGS = {
                                            C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rf_gn_silu_conv3x3_small": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "rf_conv3x3_stem": (C.c_int, [C.POINTER(StemDesc), C.c_void_p]),
     "rf_quantize_fp8_act": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "rf_groupnorm_apply_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                          C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

@@ -172,6 +172,135 @@ __global__ __launch_bounds__(256) void gather_taps_kernel(const float* __restric
     for (int o = 0; o < No; ++o) elem<TO>::store(out + i * ldo + o, acc[o]);
 }
 
+
+// ---- The UNet's stem: 3x3 convolution (stride 1, pad 1) from a HANDFUL of input channels (9 stored in 16) to C = 32 NB channels
+//   openaimodel.py:666-671  TimestepEmbedSequential(conv_nd(dims, in_channels, model_channels, 3, padding=1))
+// As an implicit GEMM it is K = 144 of 128 x 64 tiles behind a statistics pass over its output (its two GroupNorm consumers -- the first ResBlock and
+// the last decoder block's concat -- read different row sets of it, which the GEMM's fused statistics cannot serve).  Pixels on lanes: a lane pair
+// holds the 9 x 16 input values of its pixel (one 16-byte load per tap and lane: the B fragments of nine k-steps, zero for taps outside the image),
+// the whole weight table sits in LDS, O^T[C, pixel] = W[C, 144] X^T on the matrix pipe, bias + bf16 rounding + 16-byte stores from the accumulators.
+// `dup_off`: under classifier-free guidance both batch halves of the input are the same latent -- the block computes one and stores it twice.
+// GroupNorm(32) partial sums of the values as stored for up to three consumers (one chunk slot per 128-pixel block), as ffn.hip's tail epilogue.
+struct StemParams {
+    const bf16_t* x; int ldx;          // [B * HW][ldx], channels 0..15 of a pixel (pad channels zero)
+    int B, H, W;
+    const bf16_t* w;                   // [C][144], k = tap * 16 + c (ops.pack_conv_weight with cin_pad = 16)
+    const float* bias;
+    bf16_t* out; int ldo;
+    long long dup_off;                 // elements from a row of `out` to its duplicate (0: none)
+    double* gn_part[3]; int gn_cpg[3], gn_coff[3], gn_slot[3], gn_nch[3];
+};
+
+template <int NB>
+__global__ __launch_bounds__(256) void stem_conv3x3_kernel(const StemParams p) {
+    constexpr int C = 32 * NB;
+    constexpr int WP = 144 * 2 + 16;                             // row pitch of the weight table in LDS (bytes), 16-byte skew
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const wl = smem;                                       // [C][WP]
+    float* const bl = (float*)(smem + C * WP);                   // [C] bias
+    float* const gcs = bl + C;                                   // [2][4 waves][C] column sums / sums of squares per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int HW = p.H * p.W;
+    const int blocks_per_sample = HW / 128;
+    const int b = blockIdx.x / blocks_per_sample, pb = blockIdx.x - b * blocks_per_sample;
+    const int pix = pb * 128 + wave * 32 + lrow;
+    const int py = pix / p.W, px = pix - py * p.W;
+    const long long grow = (long long)b * HW + pix;
+
+    // ---- the pixel's nine taps: issued first
+    u32x4_t xq[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int sy = py + t / 3 - 1, sx = px + t % 3 - 1;
+        xq[t] = u32x4_t{0u, 0u, 0u, 0u};
+        if ((unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W)
+            xq[t] = *(const u32x4_t*)(p.x + (grow + (t / 3 - 1) * p.W + (t % 3 - 1)) * p.ldx + lhalf * 8);
+    }
+    // ---- weight table + bias: every load in flight before the first LDS write (one memory latency for the block, beside the taps')
+    constexpr int NV = C * 18, NIT = (NV + 255) / 256;
+    u32x4_t wv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + 256 * it;
+        wv[it] = u32x4_t{0u, 0u, 0u, 0u};
+        if (i < NV) wv[it] = *(const u32x4_t*)(p.w + (long long)i * 8);
+    }
+    float bv[(C + 255) / 256];
+#pragma unroll
+    for (int it = 0; it < (C + 255) / 256; ++it) bv[it] = (p.bias && tid + 256 * it < C) ? p.bias[tid + 256 * it] : 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + 256 * it, r = i / 18, v = i - r * 18;
+        if (i < NV) *(u32x4_t*)(wl + r * WP + v * 16) = wv[it];
+    }
+#pragma unroll
+    for (int it = 0; it < (C + 255) / 256; ++it)
+        if (tid + 256 * it < C) bl[tid + 256 * it] = bv[it];
+    __syncthreads();
+
+    f32x16_t acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    // MFMA row i of a 32-row block reads weight row brow(i): accumulator register r of lane (pixel, half) is then channel 32 nb + 16 half + r
+    const int brow = 16 * ((lrow >> 2) & 1) + 4 * (lrow >> 3) + (lrow & 3);
+    const char* const wb = wl + brow * WP + lhalf * 16;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const u32x4_t af = *(const u32x4_t*)(wb + nb * 32 * WP + t * 32);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, xq[t]), acc[nb], 0, 0, 0);
+        }
+
+    const bool gn_on = p.gn_part[0] || p.gn_part[1] || p.gn_part[2];
+    bf16_t* const orow = p.out + grow * p.ldo;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int col = nb * 32 + lhalf * 16;
+        float y[16];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float v[8], f[8];
+            const f32x4_t c0 = *(const f32x4_t*)(bl + col + 8 * h), c1 = *(const f32x4_t*)(bl + col + 8 * h + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[nb][8 * h + e] + (e < 4 ? c0[e] : c1[e - 4]);
+            const u32x4_t wv = pack16<bf16_t>(v);
+            *(u32x4_t*)(orow + col + 8 * h) = wv;
+            if (p.dup_off) *(u32x4_t*)(orow + p.dup_off + col + 8 * h) = wv;
+            unpack16<bf16_t>(wv, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[8 * h + e] = f[e];
+        }
+        if (gn_on) {
+            float gx[32];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { gx[k] = y[k]; gx[16 + k] = y[k] * y[k]; }
+            halfwave_reduce_scatter32(gx, lrow);          // lane lrow: total over the wave's 32 pixels of column lrow (sums) / lrow - 16 (squares)
+            gcs[((lrow >> 4) * 4 + wave) * C + nb * 32 + lhalf * 16 + (lrow & 15)] = gx[0];
+        }
+    }
+    if (gn_on) {
+        __syncthreads();
+        if (tid < 96) {
+            const int c = tid >> 5, g = tid & 31;
+            if (p.gn_part[c]) {
+                const int cpg = p.gn_cpg[c], base = p.gn_coff[c];            // consumer channel of output column 0
+                const int lo = max(0, g * cpg - base), hi = min(C, (g + 1) * cpg - base);
+                double sa = 0.0, sq = 0.0;
+                for (int k = lo; k < hi; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sa += (double)gcs[r * C + k]; sq += (double)gcs[(4 + r) * C + k]; }
+                double* o = p.gn_part[c] + (((long long)b * p.gn_nch[c] + p.gn_slot[c] + pb) * 32 + g) * 2;
+                o[0] = sa;
+                o[1] = sq;
+            }
+        }
+    }
+}
+
 }  // namespace rf
 
 extern "C" int rf_gn_silu_conv3x3_small(const void* x, int B, int H, int W, int C, int ldx, int nchunks, const double* partial, const float* gamma,
@@ -197,5 +326,33 @@ extern "C" int rf_gn_silu_conv3x3_small(const void* x, int B, int H, int W, int 
     if (out_dtype == RF_F32) hipLaunchKernelGGL(gather_taps_kernel<float>, dim3(gb), dim3(256), 0, st, workspace, B, H, W, No, bias, (float*)out, ldo);
     else hipLaunchKernelGGL(gather_taps_kernel<bf16_t>, dim3(gb), dim3(256), 0, st, workspace, B, H, W, No, bias, (bf16_t*)out, ldo);
     RF_LAUNCH_CHECK("rf_gn_silu_conv3x3_small");
+    return 0;
+}
+
+extern "C" int rf_conv3x3_stem(const rf_stem_desc* d, void* stream) {
+    using namespace rf;
+    RF_CHECK(d && d->x && d->w && d->out, "rf_conv3x3_stem: null argument");
+    RF_CHECK(d->B > 0 && d->H > 0 && d->W > 0 && (d->H * d->W) % 128 == 0, "rf_conv3x3_stem: H*W = %d must be a multiple of the 128-pixel block", d->H * d->W);
+    RF_CHECK(d->C == 320 || d->C == 128 || d->C == 64, "rf_conv3x3_stem: built for C = 320 (REFace), 128, 64 (reduced-width tests), got %d", d->C);
+    RF_CHECK(d->ldx >= 16 && d->ldx % 8 == 0 && d->ldo >= d->C && d->ldo % 8 == 0 && d->dup_off % 8 == 0, "rf_conv3x3_stem: ldx=%d (>= 16 stored channels) / ldo=%d / dup_off must be multiples of 8", d->ldx, d->ldo);
+    RF_CHECK(((uintptr_t)d->x | (uintptr_t)d->w | (uintptr_t)d->out) % 16 == 0, "rf_conv3x3_stem: operands must be 16-byte aligned");
+    StemParams p;
+    p.x = (const bf16_t*)d->x; p.ldx = d->ldx; p.B = d->B; p.H = d->H; p.W = d->W; p.w = (const bf16_t*)d->w; p.bias = d->bias;
+    p.out = (bf16_t*)d->out; p.ldo = d->ldo; p.dup_off = d->dup_off;
+    double* const parts[3] = {d->gn_part0, d->gn_part1, d->gn_part2};
+    const int cpg[3] = {d->gn_cpg0, d->gn_cpg1, d->gn_cpg2}, coff[3] = {d->gn_coff0, d->gn_coff1, d->gn_coff2};
+    const int slot[3] = {d->gn_slot0, d->gn_slot1, d->gn_slot2}, nch[3] = {d->gn_nchunks0, d->gn_nchunks1, d->gn_nchunks2};
+    for (int c = 0; c < 3; ++c) {
+        RF_CHECK(!parts[c] || (cpg[c] > 0 && slot[c] >= 0 && slot[c] + d->H * d->W / 128 <= nch[c]),
+                 "rf_conv3x3_stem: GroupNorm consumer %d: cpg=%d slot=%d needs %d slots of %d", c, cpg[c], slot[c], d->H * d->W / 128, nch[c]);
+        p.gn_part[c] = parts[c]; p.gn_cpg[c] = cpg[c]; p.gn_coff[c] = coff[c]; p.gn_slot[c] = slot[c]; p.gn_nch[c] = nch[c];
+    }
+    const int nb = d->B * (d->H * d->W / 128);
+#define RF_STEM(NB_) { constexpr int smem = 32 * NB_ * (144 * 2 + 16) + 32 * NB_ * 4 * 9; auto k = stem_conv3x3_kernel<NB_>; \
+        static bool attr = false; if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; } \
+        hipLaunchKernelGGL(k, dim3(nb), dim3(256), smem, (hipStream_t)stream, p); }
+    if (d->C == 320) RF_STEM(10) else if (d->C == 128) RF_STEM(4) else RF_STEM(2)
+#undef RF_STEM
+    RF_LAUNCH_CHECK("rf_conv3x3_stem");
     return 0;
 }

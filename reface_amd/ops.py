@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_PRELU, ACT_QUICK_GELU, ACT_RELU, ACT_SIGMOID, ACT_SILU, RF_BF16, RF_BF16X3, RF_F32,
-                   RF_FP8_E4M3, ConvGemmDesc, FfnDesc)
+                   RF_FP8_E4M3, ConvGemmDesc, FfnDesc, StemDesc)
 
 # Attention scores in the exp2 domain: the UNet folds d^-0.5 * log2(e) into the to_q weights and calls rf_attention with scale = ln 2
 # (the kernels then multiply by exactly 1: no second rounding of q * scale to bf16 in the pipelined d = 40 kernel).
@@ -458,6 +458,31 @@ def gn_silu_conv3x3_small(x, gamma, beta, partial, nchunks, W, bias, out, *, eps
                   (x, gamma, beta, partial, W, bias, out, workspace), name)
 
 
+def conv3x3_stem(x, W, bias, out, *, dup=None, name="conv_in"):
+    """The UNet's stem (rf_conv3x3_stem): 3x3 conv, stride 1, pad 1, from the 16 stored input channels of x [B, H, W, >= 16] bf16 to
+    out [B, H, W, C] bf16 (C in SMALLCONV_CHANNELS, H*W a multiple of 128), W packed [C, 144] (pack_conv_weight with cin_pad = 16).
+    dup: a second [B, H, W, C] view with out's strides that receives the same rows (the CFG-duplicated batch half).  The launch can emit the GroupNorm
+    statistics of `out` and of `dup` for up to three consumers (fuse_groupnorm_stats accepts it as a producer: 128-row blocks, all C columns)."""
+    lib = _lib.load()
+    _require_gpu(x, W, bias, out, dup)
+    B, H, W_, Ci = x.shape
+    Cc = W.shape[0]
+    assert x.dtype == W.dtype == out.dtype == torch.bfloat16 and (bias is None or bias.dtype == torch.float32)
+    assert Ci >= 16 and W.shape == (Cc, 144) and W.is_contiguous() and Cc in SMALLCONV_CHANNELS and (H * W_) % 128 == 0 and out.shape == (B, H, W_, Cc)
+    for t in (x, out) + ((dup,) if dup is not None else ()):
+        assert t.stride(3) == 1 and t.stride(1) == W_ * t.stride(2) and t.stride(0) == H * W_ * t.stride(2)
+    d = StemDesc()
+    d.x, d.ldx, d.B, d.H, d.W, d.C = _p(x), x.stride(2), B, H, W_, Cc
+    d.w, d.bias, d.out, d.ldo = _p(W), _p(bias), _p(out), out.stride(2)
+    d.dup_off = 0
+    if dup is not None:
+        assert dup.dtype == out.dtype and dup.shape == out.shape and dup.stride() == out.stride()
+        off = dup.data_ptr() - out.data_ptr()
+        assert off > 0 and off % 16 == 0
+        d.dup_off = off // 2
+    return Launch(lib.rf_conv3x3_stem, (C.byref(d),), (d, x, W, bias, out, dup), name)
+
+
 def conv2d(x, W, out, bias=None, *, ksize=3, stride=1, pad=(1, 1), ups=0, x2=None, residual=None, rowvec=None,
            act=ACT_NONE, act_vec=None, korder=0, x3=False, name="conv2d"):
     """Channels-last convolution.  x: [B, Hin, Win, C0] (+ optional x2 [B, Hin, Win, C1] concatenated
@@ -622,6 +647,11 @@ def fuse_groupnorm_stats(x, producers):
             if (d.gn_part0 and d.gn_part1) or not d.wpo or row0 % HW or rows % HW or d.M != rows or d.C != cols:
                 return None
             bm, bn = 128, cols
+        elif l.fn.__name__ == "rf_conv3x3_stem":     # the stem: 128-pixel blocks over all C columns; three consumer slots (its output and the
+            free = [i for i in range(3) if not getattr(d, f"gn_part{i}")]          # CFG duplicate are separate producer entries of one launch)
+            if len(free) < sum(1 for q in producers if q[0] is l) or d.H * d.W != HW or rows != d.B * HW or row0 % HW or d.C != cols:
+                return None
+            bm, bn = 128, cols
         else:
             if l.fn.__name__ != "rf_conv_gemm" or d.act == ACT_GEGLU or d.batch != 1 or (d.gn_part0 and d.gn_part1):
                 return None
@@ -644,6 +674,12 @@ def fuse_groupnorm_stats(x, producers):
     for l, row0, key in plans:
         d = l.keep[0]
         part = partial[row0 // HW:]
+        if l.fn.__name__ == "rf_conv3x3_stem":
+            i = next(i for i in range(3) if not getattr(d, f"gn_part{i}"))
+            for f, v in (("part", part.data_ptr()), ("cpg", Cc // 32), ("coff", key[0]), ("slot", slot_of[key][0]), ("nchunks", nslots)):
+                setattr(d, f"gn_{f}{i}", v)
+            l.keep = tuple(l.keep) + (partial,)
+            continue
         d.gn_rows = HW
         if not d.gn_part0:
             d.gn_part0, d.gn_cpg0, d.gn_coff0, d.gn_slot0, d.gn_nchunks0 = part.data_ptr(), Cc // 32, key[0], slot_of[key][0], nslots

@@ -118,6 +118,10 @@ class UNetEngine:
         self.tail_fuse = os.environ.get("REFACE_TAIL_FUSE", "1") == "1"
         self.n_tail_fused = 0
         self.out_fuse = os.environ.get("REFACE_OUT_FUSE", "1") == "1"          # `out` head (GroupNorm + SiLU + 3x3 conv to 4 channels) as one pass (csrc/smallconv.hip)
+        # the stem (3x3 conv from the 9 stored-in-16 input channels) as a pixels-on-lanes kernel that computes the CFG-duplicated half once and emits
+        # the statistics of both its GroupNorm consumers (csrc/smallconv.hip): REFACE_STEM_FUSE=0 keeps the implicit GEMM + the statistics pass
+        self.stem_fuse = os.environ.get("REFACE_STEM_FUSE", "1") == "1"
+        self.n_stem_fused = 0
         self.gn_fold_maxc = int(os.environ.get("REFACE_GN_FOLD_MAXC", "640"))
         self.n_gn_folded = 0
         self.n_hx = 0
@@ -598,6 +602,24 @@ class UNetEngine:
         self.pool.put(x2)
         return y
 
+    def _stem(self, p, x, cout, dst):
+        """input_blocks.0.0 (openaimodel.py:666-671) as rf_conv3x3_stem when the shapes allow; with cfg_pair the second batch half of x is a copy of
+        the first (the same latent under both conditionings): it is computed once and stored twice.  -> True when the launch was appended."""
+        B, H, W, ci = x.shape
+        if not (self.stem_fuse and self.dt == torch.bfloat16 and not self.x3 and dst is not None and ci == self.CPAD == 16 and
+                cout in ops.SMALLCONV_CHANNELS and (H * W) % 128 == 0 and p == "input_blocks.0.0"):
+            return False
+        w = ops.pack_conv_weight(self.sd[f"{p}.weight"], self.dt, cin_pad=self.CPAD)
+        if self.cfg_pair:
+            h = B // 2
+            l = ops.conv3x3_stem(x[:h], w, self.f32(f"{p}.bias"), dst[:h], dup=dst[h:], name=p)
+            self._add(l, dst[:h])
+            self.tracker.record(dst[h:], l)
+        else:
+            self._add(ops.conv3x3_stem(x, w, self.f32(f"{p}.bias"), dst, name=p), dst)
+        self.n_stem_fused += 1
+        return True
+
     def _block(self, prefix, layers, x, dst):
         """TimestepEmbedSequential (openaimodel.py:80-88); the last layer writes into ``dst``."""
         B = self.B
@@ -609,7 +631,9 @@ class UNetEngine:
             last = j == len(layers) - 1
             d = dst if last else None
             H, W = x.shape[1], x.shape[2]
-            if l[0] == "conv":
+            if l[0] == "conv" and self._stem(p, x, l[2], d):
+                y = d
+            elif l[0] == "conv":
                 y = d if d is not None else self.pool.get((B, H, W, l[2]), self.dt)
                 self._add(ops.conv2d(x, ops.pack_conv_weight(self.sd[f"{p}.weight"], self.dt, cin_pad=self.CPAD), y,
                                      self.f32(f"{p}.bias"), name=p), y)

@@ -134,6 +134,22 @@ def test_cabi_exports_match_header():
     for f, t in _lib.FfnDesc._fields_:
         if f in sizes:
             assert ctypes.sizeof(t) == sizes[f], f
+    # ... and of rf_stem_desc
+    m3 = re.search(r"typedef struct rf_stem_desc \{(.*?)\} rf_stem_desc;", hdr, re.S)
+    sfields = []
+    for decl in re.sub(r"/\*.*?\*/", "", m3.group(1), flags=re.S).split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split("*", 1)[1] if "*" in decl else decl.rsplit(None, 1)[1] if "," not in decl else decl.split(None, 1)[1]
+        sfields += [n.strip().lstrip("*") for n in names.split(",") if n.strip()]
+    assert [f[0] for f in _lib.StemDesc._fields_] == sfields, sfields
+    ssz = {"x": 8, "C": 4, "dup_off": 8, "gn_part2": 8, "gn_nchunks2": 4}
+    for f, t in _lib.StemDesc._fields_:
+        if f in ssz:
+            assert ctypes.sizeof(t) == ssz[f], f
+    sd = _lib.StemDesc()
+    assert lib.rf_conv3x3_stem(ctypes.byref(sd), None) != 0 and b"rf_conv3x3_stem" in lib.rf_last_error()
     # argument validation happens before any launch, so it is testable without a GPU
     d = _lib.ConvGemmDesc()
     assert lib.rf_conv_gemm(ctypes.byref(d), None) != 0
@@ -157,6 +173,8 @@ def test_fails_loudly_without_gpu():
     with pytest.raises(_lib.RefaceHipError, match="no CPU fallback"):
         ops.gn_silu_conv3x3_small(torch.zeros(1, 8, 8, 64, dtype=bf), torch.ones(64), torch.zeros(64), torch.zeros(64, dtype=torch.float64), 1,
                                   torch.zeros(4, 576, dtype=bf), torch.zeros(4), torch.zeros(1, 8, 8, 4), eps=1e-5)
+    with pytest.raises(_lib.RefaceHipError, match="no CPU fallback"):
+        ops.conv3x3_stem(torch.zeros(1, 16, 8, 16, dtype=bf), torch.zeros(64, 144, dtype=bf), torch.zeros(64), torch.zeros(1, 16, 8, 64, dtype=bf))
     m = UNetModel(in_channels=9, model_channels=64, out_channels=4, num_res_blocks=2, attention_resolutions=(4, 2, 1),
                   channel_mult=(1, 2, 4, 4), num_heads=8, use_spatial_transformer=True, context_dim=768, legacy=False)
     with pytest.raises(RuntimeError, match="GPU only"):

@@ -928,6 +928,58 @@ def test_gn_silu_conv3x3_small_fused(B, H, W_, c, No, odt):
     assert e_f < tol and e_fp < tol, (e_f, e_p, e_fp)
 
 
+@pytest.mark.parametrize("B,H,W_,c,dup", [(2, 64, 64, 320, True), (1, 96, 96, 320, False), (2, 16, 16, 64, True), (3, 16, 16, 128, False)])
+def test_conv3x3_stem_pixels_on_lanes(B, H, W_, c, dup):
+    """rf_conv3x3_stem, the UNet's stem (openaimodel.py:666-671: 3x3 conv, pad 1, 9 input channels stored in 16 -> model_channels): against
+    F.conv2d of the bf16-rounded operands in fp32 (output rounded to bf16: one bf16 step), BIT-compatible rows in the duplicate half, against the
+    implicit GEMM it replaces, and its GroupNorm statistics for three consumers -- the un-duplicated half alone (the first ResBlock under cfg_pair)
+    and both halves as the right column range of a [.., 2c] concat buffer whose left half another GEMM produces (the last decoder block) --
+    through rf_groupnorm_apply against F.group_norm of the stored tensor."""
+    dt = torch.bfloat16
+    nb = 2 if dup else 1
+    x, xr = q(rnd((B, H, W_, 16), 910), dt)
+    x[..., 9:] = 0
+    xr[..., 9:] = 0
+    w = rnd((c, 9, 3, 3), 911) / math.sqrt(81)
+    bias = rnd((c,), 912)
+    wp = ops.pack_conv_weight(w, dt, cin_pad=16).to(DEV)
+    cat = torch.zeros((nb * B, H, W_, 2 * c), dtype=dt, device=DEV)
+    y = cat[..., c:]
+    l = ops.conv3x3_stem(x, wp, bias.to(DEV), y[:B], dup=y[B:] if dup else None)
+    M = nb * B * H * W_
+    a0, _ = q(rnd((M, 64), 913), dt)
+    left = cat[..., :c]
+    ll = ops.linear(a0, (rnd((c, 64), 914) / 8.0).to(dt).to(DEV), left.as_strided((M, c), (left.stride(2), 1)), rnd((c,), 915).to(DEV))
+    # consumer 1: the first half alone; consumer 2: the concat of both halves
+    f1 = ops.fuse_groupnorm_stats(y[:B], [(l, 0, B * H * W_, 0, c)])
+    prods = [(ll, 0, M, 0, c), (l, 0, B * H * W_, c, c)] + ([(l, B * H * W_, B * H * W_, c, c)] if dup else [])
+    f2 = ops.fuse_groupnorm_stats(cat, prods)
+    assert f1 is not None and f2 is not None
+    if dup:          # all three consumer slots of the launch are taken
+        assert ops.fuse_groupnorm_stats(y[:B], [(l, 0, B * H * W_, 0, c)]) is None
+    ll(); l()
+    ops.run(f1[2]); ops.run(f2[2])
+    g1, b1 = rnd((c,), 916) * 0.2 + 1, rnd((c,), 917) * 0.2
+    g2, b2 = rnd((2 * c,), 918) * 0.2 + 1, rnd((2 * c,), 919) * 0.2
+    n1 = torch.empty((B, H, W_, c), dtype=dt, device=DEV)
+    n2 = torch.empty_like(cat)
+    ops.groupnorm_apply(y[:B], g1.to(DEV), b1.to(DEV), n1, f1[0], f1[1], eps=1e-5, silu=True)()
+    ops.groupnorm_apply(cat, g2.to(DEV), b2.to(DEV), n2, f2[0], f2[1], eps=1e-5, silu=False)()
+    y2 = torch.empty((B, H, W_, c), dtype=dt, device=DEV)
+    ops.conv2d(x, wp, y2, bias.to(DEV))()
+    torch.cuda.synchronize()
+    ref = F.conv2d(xr[..., :9].permute(0, 3, 1, 2), w.to(dt).float(), bias, padding=1).permute(0, 2, 3, 1)
+    got = y[:B].float().cpu()
+    check(got, ref, dt)
+    d = (got - y2.float().cpu()).abs().max().item()
+    print(f"stem (B {B}, {H}x{W_}, 9 -> {c}, dup {dup}): max |d| vs fp32 reference {(got - ref).abs().max().item():.2e}, vs the implicit GEMM {d:.2e}")
+    assert d <= 2.0 ** -6 * max(1.0, ref.abs().max().item())
+    if dup:
+        assert torch.equal(y[:B], y[B:])
+    check(n1, F.silu(F.group_norm(got.permute(0, 3, 1, 2), 32, g1, b1, 1e-5)).permute(0, 2, 3, 1), dt)
+    check(n2, F.group_norm(cat.float().cpu().permute(0, 3, 1, 2), 32, g2, b2, 1e-5).permute(0, 2, 3, 1), dt)
+
+
 def test_split_bf16_kernel_bit_exact():
     x = rnd((3, 5, 7, 64), 900) * 3.0
     out = torch.zeros((3, 5, 7, 128), dtype=torch.bfloat16, device=DEV)
