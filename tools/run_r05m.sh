@@ -2,7 +2,7 @@
 # r05m: the round's evidence on the FINAL library, one call per part (tools/run_r05m.sh a|b|c)
 part=$1
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-T=r05m
+T=${T:-r05m}
 case $part in
 a)  # c1: GPU suite, rocprofv3 stats, bench lines, PMC traffic, matrix-pipe occupancy
     timeout 3000 python -m pytest tests/ -x -q -m gpu > gpurun_out/${T}_pytest_gpu.log 2>&1; tail -3 gpurun_out/${T}_pytest_gpu.log
@@ -19,6 +19,13 @@ b)  # c3 and both c4 forms: bench lines + PMC traffic
 c)  # the default line as the driver runs it (after the PMC passes are committed: traffic matched by digest)
     python3 bench.py --steps 5 --warmup 2 > gpurun_out/${T}_default_bench.json 2> gpurun_out/${T}_default_bench.log
     tail -12 gpurun_out/${T}_default_bench.log
+    # the stem kernel against the implicit GEMM + statistics pass, production library, same box
+    F="--steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-conditioning --no-parity --no-other-configs"
+    for cfg in "" "--config c3" "--config c4"; do for i in 1 2; do for sw in 0 1; do
+      REFACE_STEM_FUSE=$sw python3 bench.py $F $cfg 2>/dev/null | python3 -c "
+import sys,json
+r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('REFACE_STEM_FUSE=$sw %-12s %.1f ms/batch  %.3f img/s' % ('$cfg', r['ms_per_step'], r['value']))"
+    done; done; done | tee gpurun_out/${T}_stem_ab.txt
     python3 tools/clock_probe.py > gpurun_out/${T}_clock_probe.txt 2>&1; tail -2 gpurun_out/${T}_clock_probe.txt
     # host half of the CLI at 8 processes (no GPU used: the device is a sleep of the measured batch time): the reference's PNG level for every file,
     # results/ at the reference's level + the aux files at level 1 (--fast_aux_png), everything at level 1
