@@ -583,7 +583,8 @@ def main():
                             "convs_on_row_extended_a_tiles": plan["eng"].n_hx, "groupnorm_passes_folded_into_proj_in": plan["eng"].n_gn_folded,
                             "transformer_tails_fused_ffn_proj_out": getattr(plan["eng"], "n_tail_fused", 0),
                             "out_head_fused_gn_silu_conv": int(any(getattr(l.fn, "__name__", "") == "rf_gn_silu_conv3x3_small" for l in plan["step"])),
-                            "stem_conv_pixels_on_lanes": getattr(plan["eng"], "n_stem_fused", 0)}
+                            "stem_conv_pixels_on_lanes": getattr(plan["eng"], "n_stem_fused", 0),
+                            "convs_split_by_samples": getattr(plan["eng"], "n_sample_split", 0)}
         sk = [ops.gemm_plan2(l) for l in plan["step"] if getattr(l.fn, "__name__", "") == "rf_conv_gemm"]
         result["fusion"]["splitk_launches"] = sum(1 for q in sk if q["splitk"] > 1)
         timed_l = profiler.time_launches(plan["step"], reps=5)

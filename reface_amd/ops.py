@@ -640,7 +640,7 @@ def fuse_groupnorm_stats(x, producers):
     HW, M = H * W_, B * H * W_
     if Cc % 32 or sum(r * c for _, _, r, _, c in producers) != M * Cc:
         return None
-    plans, slot_of, nslots = [], {}, 0
+    plans, slot_of, need, nslots = [], {}, {}, 0
     for l, row0, rows, col0, cols in producers:
         d = l.keep[0]
         if l.fn.__name__ == "rf_ffn_block":          # the fused transformer tail: 128-token blocks over all C columns
@@ -662,12 +662,13 @@ def fuse_groupnorm_stats(x, producers):
             return None
         per_sample = (HW // bm) * ((cols + bn - 1) // bn)
         key = (col0, cols)
-        if key not in slot_of:                  # batch slices of one column range share the slot numbering
-            slot_of[key] = (nslots, per_sample)
-            nslots += per_sample
-        elif slot_of[key][1] != per_sample:
-            return None
+        # batch slices of one column range share the slot numbering; slices with different tile plans (a launch split by samples) get the larger
+        # count -- the slots a sample does not write stay zero
+        need[key] = max(need.get(key, 0), per_sample)
         plans.append((l, row0, key))
+    for key, n in need.items():
+        slot_of[key] = (nslots, n)
+        nslots += n
     if nslots > GN_FUSED_MAX_SLOTS:
         return None
     partial = torch.zeros((B, nslots, 32, 2), dtype=torch.float64, device=x.device)

@@ -122,6 +122,9 @@ class UNetEngine:
         # the statistics of both its GroupNorm consumers (csrc/smallconv.hip): REFACE_STEM_FUSE=0 keeps the implicit GEMM + the statistics pass
         self.stem_fuse = os.environ.get("REFACE_STEM_FUSE", "1") == "1"
         self.n_stem_fused = 0
+        # 3x3 convolutions whose 256-row tiles overhang whole rounds of the chip by a little are split by samples (_add_conv3): REFACE_SAMPLE_SPLIT=0 off
+        self.sample_split = os.environ.get("REFACE_SAMPLE_SPLIT", "1") == "1"
+        self.n_sample_split = 0
         self.gn_fold_maxc = int(os.environ.get("REFACE_GN_FOLD_MAXC", "640"))
         self.n_gn_folded = 0
         self.n_hx = 0
@@ -308,6 +311,36 @@ class UNetEngine:
         wp = ops.pack_conv_weight(self.sd[wkey], F32, korder=ko)
         return ops.conv2d(x, wp.to(self.dt) if ko else self.gw(wp, cin), out, self.f32(bkey), korder=ko, name=name, **kw)
 
+    def _add_conv3(self, x, wkey, out, bkey, name, rowvec=None, residual=None, **kw):
+        """_conv3 + _add, with the launch split BY SAMPLES when its 256-row tiles overhang a whole number of rounds of the chip by a little
+        (768x768: 8 samples x 36 tiles = 288 = 1.125 rounds of 256 CUs -- the library then falls back to quarter tiles for the whole launch):
+        the first k samples fill whole rounds of big tiles, the rest is a launch of its own (its plan: smaller tiles / split-K).
+        `tools/conv_split_probe.py`: 96x96, 320 / 640 / 960 -> 320: 154 -> 135, 283 -> 236, 405 -> 338 us.  REFACE_SAMPLE_SPLIT=0: off."""
+        B, k = x.shape[0], 0
+        if (self.sample_split and isinstance(x, torch.Tensor) and not isinstance(out, ops.Fp8Act) and self.dt == torch.bfloat16 and not self.x3 and not self.w8
+                and kw.get("stride", 1) == 1):
+            HWo, N = out.shape[1] * out.shape[2], out.shape[3]
+            tn = (N + 319) // 320
+            if HWo % 256 == 0 and B > 1:
+                ps = (HWo // 256) * tn                  # 256 x 320 tiles per sample
+                t = B * ps
+                full, rem = divmod(t, self.n_cu)
+                if full >= 1 and 0 < rem <= self.n_cu // 4:
+                    k = (self.n_cu * full) // ps
+                    if not (0 < k < B and k * ps >= 0.9 * self.n_cu * full):
+                        k = 0
+        if not k:
+            return self._add(self._conv3(x, wkey, out, bkey, name, **dict(kw, **({"rowvec": rowvec} if rowvec is not None else {}),
+                                                                           **({"residual": residual} if residual is not None else {}))), out)
+        self.n_sample_split += 1
+        for a, b in ((0, k), (k, B)):
+            kws = dict(kw)
+            if rowvec is not None:
+                kws["rowvec"] = rowvec[a:b]
+            if residual is not None:
+                kws["residual"] = residual[a:b]
+            self._add(self._conv3(x[a:b], wkey, out[a:b], bkey, f"{name}[{a}:{b}]", **kws), out[a:b])
+
     def _add(self, launch, out=None):
         """Append a launch; GEMM outputs are remembered so that a later GroupNorm can ask their producers for its statistics."""
         self.main.append(launch)
@@ -355,7 +388,7 @@ class UNetEngine:
         rv = self.emb_vec(p)
         if self.uniform_t:
             rv = rv.as_strided((B, cout), (0, 1), rv.storage_offset())      # every sample reads row 0 (B = this input's batch)
-        self._add(self._conv3(t1, f"{p}.in_layers.2.weight", h1, f"{p}.in_layers.2.bias", f"{p}.in_layers.2", rowvec=rv), h1)
+        self._add_conv3(t1, f"{p}.in_layers.2.weight", h1, f"{p}.in_layers.2.bias", f"{p}.in_layers.2", rowvec=rv)
         (self.aput if self.a8 else self.pool.put)(t1)
         t2 = self._gn(h1, f"{p}.out_layers.0", 1e-5, True, fp8=self.a8, split=self.x3_ok(9 * cout, cout))
         self.pool.put(h1)
@@ -375,7 +408,7 @@ class UNetEngine:
         else:
             skip = x
         y = dst if dst is not None else self.pool.get((B, H, W, cout), self.dt)
-        self._add(self._conv3(t2, f"{p}.out_layers.3.weight", y, f"{p}.out_layers.3.bias", f"{p}.out_layers.3", residual=skip), y)
+        self._add_conv3(t2, f"{p}.out_layers.3.weight", y, f"{p}.out_layers.3.bias", f"{p}.out_layers.3", residual=skip)
         (self.aput if self.a8 else self.pool.put)(t2)
         if cin != cout:
             self.pool.put(skip)
@@ -655,7 +688,7 @@ class UNetEngine:
                     self._add(self._conv3(xc, f"{p}.op.weight", y, f"{p}.op.bias", f"{p}.op", stride=2), y)
                 else:
                     y = d if d is not None else self.pool.get((B, 2 * H, 2 * W, l[1]), self.dt)
-                    self._add(self._conv3(xc, f"{p}.conv.weight", y, f"{p}.conv.bias", f"{p}.conv", ups=1), y)
+                    self._add_conv3(xc, f"{p}.conv.weight", y, f"{p}.conv.bias", f"{p}.conv", ups=1)
                 if self.a8:
                     self.aput(xc)
                 elif xc is not x:

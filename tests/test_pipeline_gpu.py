@@ -113,6 +113,52 @@ def test_unet_full_size_structural_reductions(hw):
         assert rel < 0.05, rel
 
 
+@pytest.mark.parametrize("width", [64, 320])
+def test_unet_sample_split_at_96(width):
+    """BASELINE configs[3] (96x96 latent, 8 UNet samples = 4 CFG pairs): the top level's 3x3 convolutions are 8 x 36 = 288 tiles of 256 rows --
+    1.125 rounds of the chip -- and are launched as 7 + 1 samples (UNetEngine._add_conv3).  A scheduling choice: against the unsplit engine the
+    result moves by bf16 rounding noise only (the tail part runs other tiles / split-K: another order of the fp32 additions), and the GroupNorm
+    statistics still come from the GEMM epilogues (two producer launches with different tile plans per tensor)."""
+    import os
+    from reface_amd.unet import UNetEngine
+    from reface_amd.modules import flat_state
+    cfg = dict(in_channels=9, model_channels=width, out_channels=4, num_res_blocks=2, attention_resolutions=(4, 2, 1),
+               channel_mult=(1, 2, 4, 4), num_heads=8, context_dim=768)
+    m = make_unet(cfg, 4321, torch.bfloat16)
+    sd = flat_state(m)
+    hw, B = 96, 8
+    x = torch.zeros((B, hw, hw, 16))
+    x[: B // 2, ..., :9] = rnd((B // 2, hw, hw, 9), 310)
+    x[B // 2:] = x[: B // 2]
+    ctx = rnd((B, 768), 311)
+    t = torch.tensor([481.0])
+
+    def run(split):
+        os.environ["REFACE_SAMPLE_SPLIT"] = "1" if split else "0"
+        try:
+            eng = UNetEngine(sd, m.cfg, B, hw, hw, torch.bfloat16, torch.device(DEV), uniform_t=True, cfg_pair=True)
+        finally:
+            os.environ.pop("REFACE_SAMPLE_SPLIT", None)
+        eng.x_in.copy_(x.to(DEV).to(torch.bfloat16))
+        eng.set_context(ctx.to(DEV))
+        eng.set_timesteps(t)
+        eng.run()
+        torch.cuda.synchronize()
+        out = eng.eps.float().cpu().clone()
+        n, nf, nl = eng.n_sample_split, eng.gn_fused, len(eng.main)
+        del eng
+        torch.cuda.empty_cache()
+        return out, n, nf, nl
+
+    base, n0, nf0, nl0 = run(False)
+    got, n1, nf1, nl1 = run(True)
+    print(f"width {width}: {n1} convolutions split by samples, {nl0} -> {nl1} launches, statistics fused {nf0} -> {nf1}")
+    assert n0 == 0 and n1 >= 8 and nl1 >= nl0 + n1 and nf1 == nf0
+    scale = base.abs().max().item()
+    assert torch.isfinite(got).all() and scale > 1e-3
+    assert (got - base).abs().max().item() < 0.03 * scale, ((got - base).abs().max().item(), scale)
+
+
 def test_unet_small_bf16_close_to_fp32(golden_dir):
     g = G(golden_dir, "unet_small")
     m = make_unet(SMALL_UNET, 7, torch.bfloat16)
