@@ -28,12 +28,15 @@ sys.path.insert(0, ROOT)
 
 F_UNET = {64: 796.94e9, 96: 2137.52e9}   # algorithmic FLOP per sample per UNet evaluation by latent side (SURVEY.md 8d / BASELINE.md 2)
 F_VAE_DEC_512 = 2514.5e9      # fp32 VAE decode per 512x512 image
-PEAK = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0, "fp8w": 2500.0, "fp8c": 5000.0}     # dense MFMA TFLOP/s of the instruction the dominant family issues
+PEAK = {"bf16": 2500.0, "fp16": 2500.0, "f32": 157.3, "fp8": 5000.0, "fp8w": 2500.0, "fp8c": 5000.0}     # dense MFMA TFLOP/s of the instruction the dominant family issues
                                                          # (MI355X_MICROARCH.md): "fp8" = fp8 x fp8 on the MX-scaled fp8 MFMA (5 PF dense);
                                                          # "fp8w" dequantises fp8 weights to bf16 in the LDS read path -> bf16 MFMA rate
 # BASELINE.json configs[i] -> per-GPU workload (configs[2] = configs[1] on every one of the N GPUs)
 CONFIGS = {
     "c1": dict(idx=1, latent=64, batch=8, dtype="bf16"),
+    # configs[1] with the UNet on fp16 storage / v_mfma_f32_32x32x16_f16 instead of bf16: the same kernels, launch list and matrix-core rate; quoted
+    # beside the bf16 line because it is the throughput mode closest to the 1e-3 pixel gate (3 more mantissa bits per operand)
+    "c1h": dict(idx=1, latent=64, batch=8, dtype="fp16"),
     "c2": dict(idx=2, latent=64, batch=8, dtype="bf16"),
     "c3": dict(idx=3, latent=96, batch=4, dtype="bf16"),
     # configs[4] as BASELINE.json states it ("fp8 MFMA UNet weights"): "fp8" = EVERY eligible UNet GEMM weight e4m3fn + fp8 activations into the
@@ -105,7 +108,7 @@ def cpu_baseline(cpu_sd, cores):
     from oracle import unet as ounet, vae as ovae
     from reface_amd import params as P
     # pick the thread count that is actually fastest on this host (all logical CPUs oversubscribe badly)
-    best, best_t = cores, float("inf")
+    best, best_t, probe = cores, float("inf"), {}
     xs, ws = torch.randn(2, 320, 64, 64), torch.randn(320, 320, 3, 3)
     for n in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8), 32, 16, 8}):
         if n > cores:
@@ -116,6 +119,7 @@ def cpu_baseline(cpu_sd, cores):
         for _ in range(3):
             torch.nn.functional.conv2d(xs, ws, padding=1)
         dt = time.time() - t0
+        probe[str(n)] = round(dt / 3 * 1e3, 2)
         if dt < best_t:
             best, best_t = n, dt
     cores = best
@@ -139,6 +143,7 @@ def cpu_baseline(cpu_sd, cores):
         t_dec = time.time() - t0
     ips = 1.0 / (50 * t_step + t_dec)
     return {"value": ips, "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "thread_probe_ms": probe, "thread_probe_note": "ms per 3x3 conv (2 x 320 x 64 x 64 -> 320) by torch thread count; the fastest count is the one used",
             "sample": f"B=1: 2 CFG DDIM steps (UNet batch 2, latent 64x64) = {ts[0]:.2f}s / {ts[1]:.2f}s, the faster scaled x50, + 1 fp32 VAE decode 512x512 = {t_dec:.2f}s"}
 
 
@@ -349,16 +354,18 @@ image_parity.f32_cache = {}
 def family_key(fam, dname):
     """The dominant GEMM family of a mode and the MFMA peak of the instruction THAT family issues (a run whose own family is absent
     falls back to the bf16 family and is then priced against the bf16 peak)."""
-    key = {"bf16": "rf_conv_gemm[bf16]", "f32": "rf_conv_gemm[f32]", "fp8": "rf_conv_gemm[fp8]", "fp8w": "rf_conv_gemm[fp8w]",
+    key = {"bf16": "rf_conv_gemm[bf16]", "fp16": "rf_conv_gemm[f16]", "f32": "rf_conv_gemm[f32]", "fp8": "rf_conv_gemm[fp8]", "fp8w": "rf_conv_gemm[fp8w]",
            "fp8c": "rf_conv_gemm[fp8]", "f32x3": "rf_conv_gemm[bf16x3]"}[dname]
-    peak_of = {"rf_conv_gemm[bf16]": PEAK["bf16"], "rf_conv_gemm[f32]": PEAK["f32"], "rf_conv_gemm[fp8]": PEAK["fp8"],
+    peak_of = {"rf_conv_gemm[bf16]": PEAK["bf16"], "rf_conv_gemm[f16]": PEAK["fp16"], "rf_conv_gemm[f32]": PEAK["f32"], "rf_conv_gemm[fp8]": PEAK["fp8"],
                "rf_conv_gemm[fp8w]": PEAK["fp8w"], "rf_conv_gemm[bf16x3]": PEAK["bf16"] / 3.0}
     if key not in fam:
         key = "rf_conv_gemm[bf16]"
     return key, peak_of[key]
 
 
-def roofline_of(fam, dname, cname, B, h, S, ms_per_step, dec_ms, step_ms, workload, with_traffic=True):
+def roofline_of(fam, dname, cname, B, h, S, ms_per_step, dec_ms, step_ms, workload, with_traffic=True, raw_ms=None):
+    """`frac` = the dominant family's algorithmic FLOP / its event-timed launch time (2.5 us of event cost subtracted per launch, capped: profiler.time_launches)
+    / peak; `frac_raw` = the same with NOTHING subtracted from the event intervals (raw_ms: profiler.time_launches.last_raw_ms of the same pass)."""
     key, peak = family_key(fam, dname)
     dom = fam[key]
     unet_alg = F_UNET[h] * 2 * B if h in F_UNET else None
@@ -368,10 +375,14 @@ def roofline_of(fam, dname, cname, B, h, S, ms_per_step, dec_ms, step_ms, worklo
             "launches_per_ddim_step": dom["calls"], "avg_launch_us": dom["ms"] / dom["calls"] * 1e3,
             "alg_flop_per_ddim_step": dom["flops"], "ddim_step_ms_sum_of_kernels": step_ms,
             "ddim_step_ms_wall": (ms_per_step - dec_ms) / S}
+    if raw_ms and raw_ms.get(key):
+        roof["achieved_raw"] = dom["flops"] / (raw_ms[key] * 1e-3) / 1e12
+        roof["frac_raw"] = roof["achieved_raw"] / peak
+        roof["frac_note"] = "frac: 2.5 us of event-record cost subtracted per launch (capped; an empty event interval measures ~4.7 us); frac_raw: uncorrected event intervals"
     if unet_alg:
         # whole-step utilisation is priced against the FLOP-weighted peak of the matrix instructions the step's GEMM families issue (bf16 2.5 PF;
         # fp8 5 PF; exact fp32 157 TF): a mode that runs 85 % of its FLOPs on the fp8 pipe and 15 % on the bf16 pipe has 1 / (0.85 / 5 + 0.15 / 2.5) PF
-        peak_of = {"rf_conv_gemm[bf16]": PEAK["bf16"], "rf_conv_gemm[f32]": PEAK["f32"], "rf_conv_gemm[fp8]": PEAK["fp8"], "rf_conv_gemm[fp8w]": PEAK["fp8w"],
+        peak_of = {"rf_conv_gemm[bf16]": PEAK["bf16"], "rf_conv_gemm[f16]": PEAK["fp16"], "rf_conv_gemm[f32]": PEAK["f32"], "rf_conv_gemm[fp8]": PEAK["fp8"], "rf_conv_gemm[fp8w]": PEAK["fp8w"],
                    "rf_conv_gemm[bf16x3]": PEAK["bf16"] / 3.0}
         main_peak = PEAK.get(dname, PEAK["bf16"] / 3.0 if dname == "f32x3" else PEAK["bf16"])
         fl = sum(v["flops"] for v in fam.values())
@@ -389,12 +400,12 @@ def other_config_line(oc, unet, vae, ldm, args, device, timed, steps=3, warmup=1
     from reface_amd.ddim import DDIMSampler
     conf = CONFIGS[oc]
     B, h, dname, S = conf["batch"], conf["latent"], conf["dtype"], args.ddim_steps
-    unet.set_compute_dtype({"bf16": torch.bfloat16, "f32": torch.float32, "fp8": "fp8", "fp8w": "fp8w", "fp8c": "fp8c"}[dname])
+    unet.set_compute_dtype({"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32, "fp8": "fp8", "fp8w": "fp8w", "fp8c": "fp8c"}[dname])
     torch.cuda.empty_cache()
     sampler = DDIMSampler(ldm)
     x_T, z_inp, mask, c, uc = synthetic_inputs(B, h, 42, device)
     img_out = torch.empty((B, 3, 8 * h, 8 * h), dtype=torch.float32, device=device)
-    cname = {"c4c": "c4"}.get(oc, oc)          # (the id names the BASELINE config; the dtype field tells the two configs[4] lines apart)
+    cname = {"c4c": "c4", "c1h": "c1"}.get(oc, oc)          # (the id names the BASELINE config; the dtype field tells the two configs[4] lines apart)
 
     def one_batch():
         samples, _ = sampler.sample(S=S, conditioning=c, batch_size=B, shape=[4, h, h], verbose=False, unconditional_guidance_scale=args.scale,
@@ -408,6 +419,7 @@ def other_config_line(oc, unet, vae, ldm, args, device, timed, steps=3, warmup=1
     ms_per_step = elapsed / steps * 1e3
     plan = list(sampler._plans.values())[0]
     timed_l = profiler.time_launches(plan["step"], reps=3)
+    raw_ms = dict(profiler.time_launches.last_raw_ms)
     fam = profiler.summarize(timed_l)
     step_ms = sum(ms for _, ms in timed_l)
     dec_ms = sum(ms for _, ms in profiler.time_launches(vae._engine("dec", B, h, h).launches, reps=2))
@@ -415,14 +427,16 @@ def other_config_line(oc, unet, vae, ldm, args, device, timed, steps=3, warmup=1
     workload = f"{cname}:{px}x{px}:S{S}:B{B}:{dname}"
     line = {"config": f"BASELINE configs[{conf['idx']}]", "id": workload, "value": B * steps / elapsed, "unit": "images/s", "ms_per_step": ms_per_step,
             "steps": steps, "warmup": warmup, "dtype": dname, "vae_decode_mode": vae.decode_mode,
-            "roofline": roofline_of(fam, dname, oc, B, h, S, ms_per_step, dec_ms, step_ms, workload),
+            "roofline": roofline_of(fam, dname, oc, B, h, S, ms_per_step, dec_ms, step_ms, workload, raw_ms=raw_ms),
             "unet_step": {k: {"calls": v["calls"], "ms": round(v["ms"], 4), "tflops_per_s": round(v["tflops_per_s"], 2)} for k, v in fam.items() if v["ms"] > 0.05}}
     del sampler
-    if dname.startswith("fp8") and not args.no_parity:
-        # image distance of this mode from the exact-fp32 mode (S steps, B = 2, same seeds): quoted beside every fp8 rate
+    if (dname.startswith("fp8") or dname == "fp16") and not args.no_parity:
+        # image distance of this mode from the exact-fp32 mode (S steps, B = 2, same seeds): quoted beside every fp8 / fp16 rate
         par = image_parity(unet, vae, ldm, h, S, args.scale, device)
         line["psnr_db_vs_f32"] = par["psnr_db"]
         line["max_abs_vs_f32"] = par["max_abs"]
+        line["mean_abs_vs_f32"] = par["mean_abs"]
+    if dname.startswith("fp8") and not args.no_parity:
         line["psnr_note"] = ("seeded RANDOM-INIT weights (Gaussian): per-32-block scales cannot help there (profiles/r04a_fp8_weight_scale_ablation.json), so the "
                              "fp8 / fp8c gap measured here does not predict a trained checkpoint")
     return line
@@ -438,7 +452,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="image pairs per GPU per step (overrides the config)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--latent", type=int, default=None, help="latent side (64 = 512x512 images; overrides the config)")
-    ap.add_argument("--dtype", default=None, choices=["bf16", "f32", "f32x3", "fp8", "fp8w", "fp8c"], help="UNet compute mode (overrides the config)")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "f32", "f32x3", "fp8", "fp8w", "fp8c"], help="UNet compute mode (overrides the config)")
     ap.add_argument("--scale", type=float, default=3.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -476,7 +490,7 @@ def main():
 
     from reface_amd import ops
     from reface_amd.ddim import DDIMSampler
-    dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "f32x3": "f32x3", "fp8": "fp8", "fp8w": "fp8w", "fp8c": "fp8c"}[dname]
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32, "f32x3": "f32x3", "fp8": "fp8", "fp8w": "fp8w", "fp8c": "fp8c"}[dname]
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     unet, vae, ldm, cpu_sd = build_models(dtype, device, rank, world, want_cpu)
     sampler = DDIMSampler(ldm)
@@ -538,7 +552,7 @@ def main():
     value = world * B * args.steps / elapsed
 
     px = 8 * h
-    wdesc = {"bf16": "bf16 UNet", "f32": "exact-fp32 UNet",
+    wdesc = {"bf16": "bf16 UNet", "fp16": "fp16 UNet (the bf16 mode's kernels on fp16 storage and v_mfma_f32_32x32x16_f16, fp32 accumulate)", "f32": "exact-fp32 UNet",
              "f32x3": "fp32-storage UNet on split-bf16 operand pairs (three bf16 MFMA passes per product, GEMMs and attention; fp32 accumulate / softmax / norms)",
              "fp8": "fp8 (e4m3fn) UNet weights + fp8 activations (E8M0 block scales) into the ResBlock convs / proj_in / qkv / GEGLU on the fp8 MFMA, "
                     "bf16 residual stream, fp32 accumulate",
@@ -590,6 +604,7 @@ def main():
         timed_l = profiler.time_launches(plan["step"], reps=5)
         fam = profiler.summarize(timed_l)
         step_ms = sum(ms for _, ms in timed_l)
+        raw_ms = dict(profiler.time_launches.last_raw_ms)
         audit = {"empty_event_interval_ms": profiler.time_launches.last_gap_ms, "event_gap_ms_subtracted_per_launch": profiler.time_launches.last_sub_ms,
                  "launches_at_half_floor": profiler.time_launches.last_floored,
                  "raw_ms_per_family": {k: round(v, 4) for k, v in profiler.time_launches.last_raw_ms.items()}}
@@ -613,7 +628,7 @@ def main():
             vae._engines = {k: v for k, v in vae._engines.items() if v is not e32}
             del e32, f32_img, fast_img
             torch.cuda.empty_cache()
-        roof = roofline_of(fam, dname, cname, B, h, S, ms_per_step, dec_ms, step_ms, workload)
+        roof = roofline_of(fam, dname, cname, B, h, S, ms_per_step, dec_ms, step_ms, workload, raw_ms=raw_ms)
         if clk and "frac" in clk:
             # `frac` stays priced at the nominal 2.4 GHz peak (guide); this is the same figure at the clock the chip actually held in the loop
             roof["frac_at_measured_clock"] = roof["frac"] / clk["frac"]
@@ -676,7 +691,7 @@ def main():
         # BASELINE configs[3] / configs[4] as short driver-visible lines (inside this run's wall clock): same models, same timed region
         # (barrier + synchronize around `steps` whole batches), their own roofline from the same event-timed launch list
         result["other_configs"] = {}
-        for oc in ("c3", "c4", "c4c"):
+        for oc in ("c1h", "c3", "c4", "c4c"):
             try:
                 result["other_configs"][oc] = other_config_line(oc, unet, vae, ldm, args, device, timed)
                 r = result["other_configs"][oc]
@@ -691,7 +706,7 @@ def main():
         try:
             result["conditioning"] = conditioning_line(vae, B, h, device)
             log(f"[bench] conditioning stage: {result['conditioning']['value']:.1f} images/s ({result['conditioning']['ms_per_batch']:.1f} ms per batch of {B})")
-            if dname != "f32":         # what the CLI's --precision bf16 runs: bf16 towers and VAE encoder (decode stays fp32)
+            if dname not in ("f32", "fp16"):         # what the CLI's --precision bf16 runs: bf16 towers and VAE encoder (decode stays fp32)
                 result["conditioning_bf16"] = conditioning_line(vae, B, h, device, torch.bfloat16)
                 log(f"[bench] conditioning stage, bf16: {result['conditioning_bf16']['value']:.1f} images/s")
         except Exception as e:        # the headline number must not depend on this side line

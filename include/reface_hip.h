@@ -14,7 +14,9 @@
  *   - `stream` is a hipStream_t passed as void* (the caller's current PyTorch HIP stream).
  *   - every function returns 0 on success, non-zero on error; rf_last_error() gives the message.
  *   - activations are channels-last: a tensor [B, H, W, C] is a row-major matrix [B*H*W, C].
- *   - dtype codes: RF_F32 = 0 (fp32 storage, exact-fp32 MFMA), RF_BF16 = 1 (bf16 storage, fp32 accumulate).
+ *   - dtype codes: RF_F32 = 0 (fp32 storage, exact-fp32 MFMA), RF_BF16 = 1 (bf16 storage, fp32 accumulate), RF_F16 = 4 (IEEE fp16 storage on
+ *     v_mfma_f32_32x32x16_f16, fp32 accumulate: the bf16 mode's kernels at the same matrix-core rate with 11 significant bits instead of 8 --
+ *     the "fp16" throughput mode; accepted wherever RF_BF16 is unless an entry point says otherwise, never mixed with bf16 inside one call).
  */
 #ifndef REFACE_HIP_H
 #define REFACE_HIP_H
@@ -26,7 +28,8 @@ extern "C" {
 #endif
 
 enum { RF_F32 = 0, RF_BF16 = 1, RF_FP8_E4M3 = 2 /* OCP e4m3fn weights (rf_conv_gemm_desc.w_dtype only) */,
-       RF_BF16X3 = 3 /* split-bf16 operand pairs, see rf_conv_gemm_desc.dtype and rf_split_bf16 */ };
+       RF_BF16X3 = 3 /* split-bf16 operand pairs, see rf_conv_gemm_desc.dtype and rf_split_bf16 */,
+       RF_F16 = 4 /* IEEE binary16 storage (the "fp16" throughput mode) */ };
 
 /* epilogue activations of rf_conv_gemm */
 enum { RF_ACT_NONE = 0, RF_ACT_GEGLU = 1, RF_ACT_SILU = 2, RF_ACT_QUICK_GELU = 3, RF_ACT_GELU = 4,
@@ -57,7 +60,7 @@ typedef struct rf_conv_gemm_desc {
     /* [C0 hi | C0 lo] (ld0 >= 2 C0), a W row holds per 64-element K tile [64 hi | 64 lo | 64 hi] (3 K bf16; ldw >= 3 K) -- and a product is */
     /* accumulated in fp32 as hi hi + hi lo + lo hi on the bf16 MFMA (relative error 2^-16 per product; out_dtype RF_F32, one source, */
     /* K and C0 multiples of 64, K / C0 / ld0 given in REAL elements): the fast form of the fp32 VAE convolutions (model.py:60-121). */
-    int32_t dtype;        /* RF_F32 | RF_BF16: element type of src0/src1/W; RF_BF16X3: split-bf16 pairs (above) */
+    int32_t dtype;        /* RF_F32 | RF_BF16 | RF_F16: element type of src0/src1/W; RF_BF16X3: split-bf16 pairs (above) */
     int32_t out_dtype;    /* element type of out and residual */
     int32_t M, N, K;      /* GEMM view; K = KH*KW*(C0+C1) (may be padded up to a multiple of 8) */
     const void* src0;
@@ -135,7 +138,8 @@ int rf_conv_gemm(const rf_conv_gemm_desc* d, void* stream);
  * nn.GroupNorm (util.py:214-216) over a tensor this GEMM has just produced. */
 int rf_conv_gemm_plan(const rf_conv_gemm_desc* d, int32_t* bm, int32_t* bn, int32_t* splitk);
 /* The same query with the whole tile plan: info8 = {statistics rows, statistics cols, splitk, BM, BN, wave_cols (columns of one wave's tile),
- * epilogue form (1 = direct register -> global, 0 = staged), split-K through fragment slabs (0 / 1)}. */
+ * epilogue form (1 = direct register -> global, 0 = staged), flags: bit 0 = split-K through fragment slabs, bit 1 = the call runs as TWO GEMM
+ * kernels (a 256-wide launch whose last round of tiles is 20-60 % full is split along N; the query then also validates the second part)}. */
 int rf_conv_gemm_plan2(const rf_conv_gemm_desc* d, int32_t* info8);
 
 /* Fused transformer feed-forward at C = 320 (the 64x64 level):  out = (GEGLU(x W1^T + b1)) W2^T + b2 + residual, bf16 in / out, fp32
@@ -146,6 +150,7 @@ int rf_conv_gemm_plan2(const rf_conv_gemm_desc* d, int32_t* info8);
  *               rf_layernorm stores them; NO affine: the host folds norm3's gamma into w1p's columns and W1 beta into b1p) -- the kernel then
  *               also replaces `self.norm3` (attention.py:231-233, 243) and x is the un-normalised residual stream.
  * Replaces FeedForward.forward (attention.py:40-76) + the residual add of BasicTransformerBlock (attention.py:243). */
+/* (bf16 only: the fp16 mode goes through rf_ffn_block with wpo = NULL and dtype = RF_F16) */
 int rf_ffn_geglu(const void* x, int ldx, const void* w1p, const float* b1p, const void* w2q, const float* b2, const void* residual, int ldr,
                  void* out, int ldo, int M, int C, float ln_eps, void* stream);
 
@@ -172,6 +177,7 @@ typedef struct rf_ffn_desc {
     int32_t gn_cpg0, gn_coff0, gn_slot0, gn_nchunks0;
     double* gn_part1;
     int32_t gn_cpg1, gn_coff1, gn_slot1, gn_nchunks1;
+    int32_t dtype;        /* element type of x / w1p / w2q / residual / out / wpo / res2: RF_BF16 (also 0: the descriptor as it was before the field) or RF_F16 */
 } rf_ffn_desc;
 int rf_ffn_block(const rf_ffn_desc* d, void* stream);
 
@@ -205,13 +211,14 @@ int rf_groupnorm_fold_linear(const float* W, int N, int C, int B, int HW, int nc
                              const float* bias, float eps, int out_dtype, void* w_out, float* rowvec_out, void* stream);
 
 /* GroupNorm(32) + SiLU + 3x3 convolution (stride 1, pad 1) to No <= 4 output channels in one pass over the RAW tensor -- the UNet's `out` head
- * (openaimodel.py:737-741: normalization(ch), nn.SiLU(), conv_nd(dims, model_channels, out_channels, 3, padding=1)): x bf16 [B][H*W][ldx] un-normalised,
- * `partial` its GroupNorm partial sums (the records rf_groupnorm_apply reads), W bf16 [No][9 C] (k = tap * C + c), out [B*H*W][ldo] fp32 / bf16.
+ * (openaimodel.py:737-741: normalization(ch), nn.SiLU(), conv_nd(dims, model_channels, out_channels, 3, padding=1)): x [B][H*W][ldx] un-normalised in
+ * `dtype` (RF_BF16 | RF_F16), `partial` its GroupNorm partial sums (the records rf_groupnorm_apply reads), W [No][9 C] in `dtype` (k = tap * C + c),
+ * out [B*H*W][ldo] fp32 or `dtype`.
  * Kernel 1 normalises + activates every pixel's C values in registers (rounded to bf16 as the apply pass stores them) and multiplies them with
  * all nine taps' weights on the matrix pipe (per-tap partial products, fp32, into `workspace`: B*H*W * 160 bytes); kernel 2 sums, per output pixel,
  * the taps whose source pixel lies inside the image.  Replaces rf_groupnorm_apply + rf_conv_gemm for this layer: one read of the tensor instead of a
  * write + nine tap-shifted reads.  C in {320, 128, 64}. */
-int rf_gn_silu_conv3x3_small(const void* x, int B, int H, int W, int C, int ldx, int nchunks, const double* partial, const float* gamma,
+int rf_gn_silu_conv3x3_small(int dtype, const void* x, int B, int H, int W, int C, int ldx, int nchunks, const double* partial, const float* gamma,
                              const float* beta, float eps, int silu, const void* w, const float* bias, int No, int out_dtype, void* out, int ldo,
                              float* workspace, long long workspace_bytes, void* stream);
 
@@ -235,6 +242,7 @@ typedef struct rf_stem_desc {
     int32_t gn_cpg1, gn_coff1, gn_slot1, gn_nchunks1;
     double* gn_part2;
     int32_t gn_cpg2, gn_coff2, gn_slot2, gn_nchunks2;
+    int32_t dtype;        /* element type of x / w / out: RF_BF16 (also 0) or RF_F16 */
 } rf_stem_desc;
 int rf_conv3x3_stem(const rf_stem_desc* d, void* stream);
 

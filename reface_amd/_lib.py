@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # REFACE_HIP_LIB selects another build of the same library (A/B kernel experiments); there is still no non-HIP fallback.
 LIB_PATH = os.environ.get("REFACE_HIP_LIB") or os.path.join(HERE, "lib", "libreface_hip.so")
 
-RF_F32, RF_BF16, RF_FP8_E4M3, RF_BF16X3 = 0, 1, 2, 3
+RF_F32, RF_BF16, RF_FP8_E4M3, RF_BF16X3, RF_F16 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_PRELU = 0, 1, 2, 3, 4, 5, 6, 7
 
 
@@ -59,6 +59,7 @@ class FfnDesc(C.Structure):
         ("gn_rows", C.c_int32),
         ("gn_part0", C.c_void_p), ("gn_cpg0", C.c_int32), ("gn_coff0", C.c_int32), ("gn_slot0", C.c_int32), ("gn_nchunks0", C.c_int32),
         ("gn_part1", C.c_void_p), ("gn_cpg1", C.c_int32), ("gn_coff1", C.c_int32), ("gn_slot1", C.c_int32), ("gn_nchunks1", C.c_int32),
+        ("dtype", C.c_int32),
     ]
 
 
@@ -73,6 +74,7 @@ class StemDesc(C.Structure):
         ("gn_part0", C.c_void_p), ("gn_cpg0", C.c_int32), ("gn_coff0", C.c_int32), ("gn_slot0", C.c_int32), ("gn_nchunks0", C.c_int32),
         ("gn_part1", C.c_void_p), ("gn_cpg1", C.c_int32), ("gn_coff1", C.c_int32), ("gn_slot1", C.c_int32), ("gn_nchunks1", C.c_int32),
         ("gn_part2", C.c_void_p), ("gn_cpg2", C.c_int32), ("gn_coff2", C.c_int32), ("gn_slot2", C.c_int32), ("gn_nchunks2", C.c_int32),
+        ("dtype", C.c_int32),
     ]
 
 
@@ -92,7 +94,7 @@ _SIGS = {
                                      C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "rf_groupnorm_fold_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "rf_gn_silu_conv3x3_small": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
+    "rf_gn_silu_conv3x3_small": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]),
     "rf_conv3x3_stem": (C.c_int, [C.POINTER(StemDesc), C.c_void_p]),
     "rf_quantize_fp8_act": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

@@ -12,12 +12,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libreface_hip.so")
-SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "encoder.hip", "ffn.hip", "smallconv.hip"]
+SOURCES = ["gemm.hip", "gemm_f16.hip", "norm.hip", "attention.hip", "elementwise.hip", "encoder.hip", "ffn.hip", "smallconv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 # per-file extras.  attention: keep MFMA accumulators in VGPRs -- the online softmax reads every score and rescales O each
 # tile, and with AGPR accumulators hipcc emitted ~160 v_accvgpr_read/write per KV tile (40 % of the loop's VALU work).
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "reface_hip.h")]
+# further files a unit includes (part of its content key): gemm_f16.hip is gemm.hip's templates instantiated for fp16 operands
+UNIT_DEPS = {"gemm_f16.hip": [os.path.join(CSRC, "gemm.hip")]}
 
 
 
@@ -66,7 +68,7 @@ def unit_key(unit, hipcc=None):
 
 def source_key(unit):
     """The compiler-independent part of a unit's key: sha256 of (source, headers, compile flags)."""
-    return _digest([os.path.join(CSRC, unit)] + HEADERS, FLAGS + EXTRA_FLAGS.get(unit, []))
+    return _digest([os.path.join(CSRC, unit)] + UNIT_DEPS.get(unit, []) + HEADERS, FLAGS + EXTRA_FLAGS.get(unit, []))
 
 
 def build(force=False, verbose=True):

@@ -8,7 +8,7 @@
 // P feeds the second MFMA without leaving registers (the K-order permutation this implies is
 // absorbed by the order in which V^T is written to LDS).
 // Same byte geometry for both storage types (16-byte fragments):
-//   bf16: v_mfma_f32_32x32x16_bf16, fp32: 4 x v_mfma_f32_32x32x2_f32 (exact fp32).
+//   bf16: v_mfma_f32_32x32x16_bf16, fp16: v_mfma_f32_32x32x16_f16 (RF_F16: the same kernels for f16_t), fp32: 4 x v_mfma_f32_32x32x2_f32 (exact fp32).
 // Block = 4 waves = 128 queries of one (batch, head); KV tile = 64 keys.
 #include <stdlib.h>
 
@@ -24,6 +24,9 @@ template <> struct AttnMma<bf16_t> {
     __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
     }
+};
+template <> struct AttnMma<f16_t> {
+    __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) { mma16<f16_t>(acc, a, b); }
 };
 template <> struct AttnMma<float> {
     __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
@@ -47,7 +50,28 @@ constexpr int KV_SUB = 64;          // keys per softmax / MFMA pass (the S^T acc
 // reads one contiguous 16-byte fragment holding exactly the keys its P registers cover
 template <typename T> __device__ __forceinline__ int vt_pos(int j);
 template <> __device__ __forceinline__ int vt_pos<bf16_t>(int j) { return (j < 4 || j >= 12) ? j : (j < 8 ? j + 4 : j - 4); }
+template <> __device__ __forceinline__ int vt_pos<f16_t>(int j) { return vt_pos<bf16_t>(j); }
 template <> __device__ __forceinline__ int vt_pos<float>(int j) { return j; }
+
+// Smallest T-representable value >= x (the d = 40 kernel keeps its softmax reference point exactly representable in the operand type: -m rides
+// in a Q element).  bf16: fp32's exponent range, the low 16 pattern bits dropped toward +inf.  fp16: 10 mantissa bits -> the low 13 pattern bits;
+// below fp16's normal range (2^-14) the grid is coarser than that mask assumes -> 0 for the negatives, 2^-14 for the positives; clamped to +-65504
+// (scores of that size in the exp2 domain do not occur: the logits would have to exceed 45 000).
+template <typename T> __device__ __forceinline__ float ceil16(float x);
+template <> __device__ __forceinline__ float ceil16<bf16_t>(float x) {
+    const uint32_t tb = as_u32(x);
+    return as_f32(x >= 0.f ? ((tb + 0xffffu) & 0xffff0000u) : (tb & 0xffff0000u));
+}
+template <> __device__ __forceinline__ float ceil16<f16_t>(float x) {
+    const uint32_t tb = as_u32(x);
+    float r = as_f32(x >= 0.f ? ((tb + 0x1fffu) & 0xffffe000u) : (tb & 0xffffe000u));
+    if (fabsf(r) < 6.103515625e-05f) r = x > 0.f ? 6.103515625e-05f : 0.f;
+    return fminf(fmaxf(r, -65504.f), 65504.f);
+}
+// the 16-bit pattern of a T-representable fp32 value
+template <typename T> __device__ __forceinline__ uint32_t bits16(float x);
+template <> __device__ __forceinline__ uint32_t bits16<bf16_t>(float x) { return as_u32(x) >> 16; }
+template <> __device__ __forceinline__ uint32_t bits16<f16_t>(float x) { return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)x); }
 
 // D = head dim (multiple of 8).  STEPS = 16-byte k-steps over D per lane-half pair.  QB = 32-query blocks per wave
 // (QB = 2: each K / V^T fragment read from LDS feeds two MFMAs and the staging / barrier cost per query halves).
@@ -114,9 +138,8 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 && NW == 4) ? 2 : 1) void attenti
         __syncthreads();
         if (tid < NS * KV_TILE) {
             const int stg = tid / KV_TILE, kcol = tid - stg * KV_TILE;
-            T one;
-            if constexpr (sizeof(T) == 2) one = (T)0x3f80; else one = 1.0f;
-            *(T*)(smem + stg * TILE_BYTES + KV_TILE * KROW + D * VROW + kcol * (int)sizeof(T)) = one;
+            char* const op = smem + stg * TILE_BYTES + KV_TILE * KROW + D * VROW + kcol * (int)sizeof(T);
+            if constexpr (sizeof(T) == 2) *(uint16_t*)op = one16<T>(); else *(float*)op = 1.0f;
         }
     }
 
@@ -281,7 +304,7 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 && NW == 4) ? 2 : 1) void attenti
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) pf[qb][e] = pack_bf2(s[qb][kb][8 * g + 2 * e], s[qb][kb][8 * g + 2 * e + 1]);
+                        for (int e = 0; e < 4; ++e) pf[qb][e] = pack2<T>(s[qb][kb][8 * g + 2 * e], s[qb][kb][8 * g + 2 * e + 1]);
 #pragma unroll
                     for (int i = 0; i < DVB; ++i) {
                         const u32x4_t vf = *(const u32x4_t*)(ldsV + (i * 32 + lq) * VROW + (sub * KV_SUB + kb * 32 + g * 16) * 2 + lh * 16);
@@ -331,8 +354,8 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 && NW == 4) ? 2 : 1) void attenti
                         T* dst = O + (long long)qi * p.ldo + dv;
                         if constexpr (sizeof(T) == 2) {
                             u32x2_t w;
-                            w[0] = pack_bf2(o[qb][i][4 * g] * inv, o[qb][i][4 * g + 1] * inv);
-                            w[1] = pack_bf2(o[qb][i][4 * g + 2] * inv, o[qb][i][4 * g + 3] * inv);
+                            w[0] = pack2<T>(o[qb][i][4 * g] * inv, o[qb][i][4 * g + 1] * inv);
+                            w[1] = pack2<T>(o[qb][i][4 * g + 2] * inv, o[qb][i][4 * g + 3] * inv);
                             *(u32x2_t*)dst = w;
                         } else {
                             f32x4_t w = {o[qb][i][4 * g] * inv, o[qb][i][4 * g + 1] * inv, o[qb][i][4 * g + 2] * inv, o[qb][i][4 * g + 3] * inv};
@@ -609,8 +632,7 @@ static int launch_attn_x3(const AttnParams& p, int B, hipStream_t st) {
     constexpr int tile_bytes = 2 * (KV_TILE * (STEPS * 32 + 16) + DVB * 32 * (KV_TILE * 2 + 16));
     constexpr int smem = (2 * tile_bytes <= 160 * 1024 ? 2 : 1) * tile_bytes;
     auto k = attention_x3_kernel<D, KV_TILE>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+    RF_RAISE_LDS(k, smem, "rf_attention");
     AttnParams pp = p;
     pp.nqb = (p.Nq + 127) / 128;
     hipLaunchKernelGGL(k, dim3(pp.nqb * B * p.heads), dim3(256), smem, st, pp);
@@ -669,9 +691,9 @@ template <int OFF> __device__ __forceinline__ u32x2_t ds_read_tr16(const char* p
 // rows of O^T beyond the head dim multiply whatever follows the row and are never stored -- except rows 48..63, whose lanes read a
 // run of ones, so the MFMA also delivers the softmax denominator.  Every wave issues two or three of a tile's ten one-KiB pieces.
 // The running max moves only when a score exceeds it by 2^8 in the exp2 domain (P <= 256; the O rescale becomes rare).
-template <int D, int KT>
+template <typename T, int D, int KT>
 __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams p) {
-    typedef bf16_t T;
+    static_assert(sizeof(T) == 2, "16-bit operands (bf16 / fp16)");
     static_assert(D > 32 && D < 48 && D % 8 == 0, "three 16-wide k-steps");
     // KT keys per stage and barrier: 64 (ring of 7) or 128 (ring of 3; half the barriers) -- both ~70 KB, two blocks per CU
     constexpr int QB = 2, NU = KT / 32, NSTG = KT == 64 ? 7 : 3;
@@ -723,7 +745,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
         }
     }
 
-    for (int i = tid; i < ONES_BYTES / 4; i += 256) ((uint32_t*)(smem + ONES_OFF))[i] = 0x3f803f80u;
+    for (int i = tid; i < ONES_BYTES / 4; i += 256) ((uint32_t*)(smem + ONES_OFF))[i] = (uint32_t)one16<T>() * 0x10001u;
     // ---- staging: tile X is issued by wave X % 4
     const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, (unsigned)((((long long)p.Nk - 1) * p.ldk + D) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, (unsigned)((((long long)p.Nk - 1) * p.ldv + D) * 2), 0x00020000);
@@ -862,10 +884,9 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
             if (__builtin_expect(__any(moved), 0)) {      // out of line: the common path falls through
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
-                    // new reference: this unit's max (the first unit may also lower it), rounded UP to a bf16 value
+                    // new reference: this unit's max (the first unit may also lower it), rounded UP to a value of the operand type
                     const float target = m_run[qb] + ((t == 0 && uu == 0) ? mx[qb] : fmaxf(mx[qb], 0.f));
-                    const uint32_t tb = as_u32(target);
-                    const float m_new = as_f32(target >= 0.f ? ((tb + 0xffffu) & 0xffff0000u) : (tb & 0xffff0000u));
+                    const float m_new = ceil16<T>(target);
                     const float delta = m_new - m_run[qb];
                     const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
@@ -875,7 +896,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
                     m_run[qb] = m_new;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) cur[qb][r] -= delta;          // this unit's scores were taken against the old reference
-                    if (lh) qf[qb][2][0] = (as_u32(-m_new) >> 16);                // lane half 1 of k-step 2: [-m_run, 0, ...] (exact: bf16 value)
+                    if (lh) qf[qb][2][0] = bits16<T>(-m_new);                     // lane half 1 of k-step 2: [-m_run, 0, ...] (exact: a value of T)
                 }
             }
             // ---- region 2: QK^T of the next unit beside exp2 / pack of this one
@@ -891,7 +912,7 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
                     for (int e = 0; e < 4; ++e) {
                         const int r = 8 * g + 2 * e;
                         const float e0 = __builtin_amdgcn_exp2f(cur[qb][r]), e1 = __builtin_amdgcn_exp2f(cur[qb][r + 1]);
-                        pf[qb][g][e] = pack_bf2(e0, e1);
+                        pf[qb][g][e] = pack2<T>(e0, e1);
                     }
             }
         };
@@ -925,8 +946,8 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
                     const int dv = i * 32 + 8 * g + 4 * lh;
                     if (dv < D) {
                         u32x2_t w;
-                        w[0] = pack_bf2(o[qb][i][4 * g] * inv, o[qb][i][4 * g + 1] * inv);
-                        w[1] = pack_bf2(o[qb][i][4 * g + 2] * inv, o[qb][i][4 * g + 3] * inv);
+                        w[0] = pack2<T>(o[qb][i][4 * g] * inv, o[qb][i][4 * g + 1] * inv);
+                        w[1] = pack2<T>(o[qb][i][4 * g + 2] * inv, o[qb][i][4 * g + 3] * inv);
                         *(u32x2_t*)(O + (long long)qi * p.ldo + dv) = w;
                     }
                 }
@@ -934,12 +955,11 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
     }
 }
 
-template <int D, int KT>
+template <typename T, int D, int KT>
 static int launch_attn_dma(const AttnParams& p, int B, hipStream_t st) {
     constexpr int smem = (KT == 64 ? 7 : 3) * (2 * KT * D * 2) + (KT - 8) * D * 2 + 128;      // stages + the run of ones
-    auto k = attention_dma_kernel<D, KT>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+    auto k = attention_dma_kernel<T, D, KT>;
+    RF_RAISE_LDS(k, smem, "rf_attention");
     AttnParams pp = p;
     pp.nqb = (p.Nq + 255) / 256;
     static const int pad = tune_env("RF_ATTN_SMEM_PAD", 0);      // experiment: one block per CU
@@ -957,8 +977,7 @@ static int launch_attn_qb(const AttnParams& p, int B, hipStream_t st) {
     constexpr int tile_bytes = KV_TILE * KROW + DVB * 32 * VROW;
     constexpr int smem = (2 * tile_bytes <= 160 * 1024 ? 2 : 1) * tile_bytes;
     auto k = attention_kernel<T, D, QB, KV_TILE, NW>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+    RF_RAISE_LDS(k, smem, "rf_attention");
     AttnParams pp = p;
     pp.nqb = (p.Nq + 32 * NW * QB - 1) / (32 * NW * QB);
     dim3 grid(pp.nqb * B * p.heads);
@@ -978,8 +997,8 @@ static int launch_attn(const AttnParams& p, int B, hipStream_t st) {
             static const int pipe = tune_env("RF_ATTN_PIPE", 1);
             if constexpr (D == 40) {
                 static const int kt128 = tune_env("RF_ATTN_KT128", 1);
-                if (pipe && kt128 && p.Nk % 128 == 0 && p.Nk >= 1024) return launch_attn_dma<D, 128>(p, B, st);
-                if (pipe && p.Nk % 64 == 0 && p.Nk >= 1024) return launch_attn_dma<D, 64>(p, B, st);
+                if (pipe && kt128 && p.Nk % 128 == 0 && p.Nk >= 1024) return launch_attn_dma<T, D, 128>(p, B, st);
+                if (pipe && p.Nk % 64 == 0 && p.Nk >= 1024) return launch_attn_dma<T, D, 64>(p, B, st);
             }
             // 8-wave blocks (both waves of a SIMD on one staged tile) measured 608 vs 586 us at N = 4096: opt-in only (RF_ATTN_NW=8)
             static const int nw = tune_env("RF_ATTN_NW", 4);
@@ -990,7 +1009,7 @@ static int launch_attn(const AttnParams& p, int B, hipStream_t st) {
         }
     }
     // d = 80 (the 32x32 / 48x48 levels): 128 keys per stage and 8 waves per block -- both waves of a SIMD share one staged K / V tile, half the barriers;
-    // 73 us against 85 at N = 1024 (tools/run_r04x.sh: 64-key stages with 8 waves 85, 128-key stages with 4 waves 105, two query blocks per wave 81-99).
+    // 73 us against 85 at N = 1024 (tools/archive/run_r04x.sh: 64-key stages with 8 waves 85, 128-key stages with 4 waves 105, two query blocks per wave 81-99).
     // d = 160 keeps the 4-wave / 64-key form (N = 256: four stages of 64 keys already cover the sequence).
     if constexpr (sizeof(T) == 2 && D == 80) {
         if (p.Nk >= 512 && (long long)((p.Nq + 255) / 256) * B * p.heads >= 256) return launch_attn_qb<T, D, 1, 128, 8>(p, B, st);
@@ -1019,9 +1038,9 @@ static int dispatch_attn(const AttnParams& p, int B, hipStream_t st) {
 extern "C" int rf_attention(int dtype, const void* q, const void* k, const void* v, void* out, int B, int heads, int d, int Nq, int Nk,
                             int ldq, int ldk, int ldv, int ldo, int64_t sq, int64_t sk, int64_t sv, int64_t so, float scale, void* stream) {
     using namespace rf;
-    RF_CHECK(dtype == RF_F32 || dtype == RF_BF16 || dtype == RF_BF16X3, "rf_attention: bad dtype %d", dtype);
+    RF_CHECK(dtype == RF_F32 || dtype == RF_BF16 || dtype == RF_F16 || dtype == RF_BF16X3, "rf_attention: bad dtype %d", dtype);
     RF_CHECK(q && k && v && out && B > 0 && heads > 0 && Nq > 0 && Nk > 0, "rf_attention: bad arguments");
-    const int vec = dtype == RF_BF16 ? 8 : 4;
+    const int vec = (dtype == RF_BF16 || dtype == RF_F16) ? 8 : 4;
     RF_CHECK(d % 8 == 0 && ldq % vec == 0 && ldk % vec == 0 && ldv % vec == 0 && ldo % 4 == 0, "rf_attention: d/ld alignment (d=%d)", d);
     RF_CHECK(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16 == 0, "rf_attention: operands must be 16-byte aligned");
     RF_CHECK((long long)B * heads * ((Nq + 127) / 128) < (1LL << 31), "rf_attention: grid too large");
@@ -1033,5 +1052,6 @@ extern "C" int rf_attention(int dtype, const void* q, const void* k, const void*
     if (fabsf(p.scale_log2e - 1.0f) < 1e-6f) p.scale_log2e = 1.0f;       // scale = ln 2: the caller's scores are already in the exp2 domain
     if (dtype == RF_BF16X3) return dispatch_attn_x3(p, B, (hipStream_t)stream);          // fp32 in memory, split-bf16 operand pairs on the bf16 MFMA
     if (dtype == RF_F32) return dispatch_attn<float>(p, B, (hipStream_t)stream);
+    if (dtype == RF_F16) return dispatch_attn<f16_t>(p, B, (hipStream_t)stream);
     return dispatch_attn<bf16_t>(p, B, (hipStream_t)stream);
 }

@@ -6,6 +6,7 @@ namespace rf {
 template <typename TO> __device__ __forceinline__ void st(TO* p, float v);
 template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+template <> __device__ __forceinline__ void st<f16_t>(f16_t* p, float v) { *p = (f16_t)v; }
 
 // x_in[(dup*B), hw, Cpad] = [img(4) | z_inpaint(4) | mask(1) | 0...]   (ddim.py:330, 338)
 template <typename TO>
@@ -267,6 +268,7 @@ extern "C" int rf_ddim_pack_input(const float* img, const float* z_inpaint, cons
     hipStream_t st_ = (hipStream_t)stream;
     if (out_dtype == RF_F32) hipLaunchKernelGGL(ddim_pack_kernel<float>, grid1d((long long)B * hw), dim3(256), 0, st_, img, z_inpaint, mask, B, hw, dup, (float*)x_in, Cpad);
     else if (out_dtype == RF_BF16) hipLaunchKernelGGL(ddim_pack_kernel<bf16_t>, grid1d((long long)B * hw), dim3(256), 0, st_, img, z_inpaint, mask, B, hw, dup, (bf16_t*)x_in, Cpad);
+    else if (out_dtype == RF_F16) hipLaunchKernelGGL(ddim_pack_kernel<f16_t>, grid1d((long long)B * hw), dim3(256), 0, st_, img, z_inpaint, mask, B, hw, dup, (f16_t*)x_in, Cpad);
     else RF_CHECK(false, "rf_ddim_pack_input: bad out_dtype %d", out_dtype);
     RF_LAUNCH_CHECK("rf_ddim_pack_input");
     return 0;
@@ -286,6 +288,7 @@ extern "C" int rf_nchw_to_nhwc(const float* x, int B, int C, int HW, int out_dty
     const long long n = (long long)B * HW * Cpad;
     if (out_dtype == RF_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid1d(n), dim3(256), 0, (hipStream_t)stream, x, B, C, HW, (float*)out, Cpad);
     else if (out_dtype == RF_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid1d(n), dim3(256), 0, (hipStream_t)stream, x, B, C, HW, (bf16_t*)out, Cpad);
+    else if (out_dtype == RF_F16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16_t>, grid1d(n), dim3(256), 0, (hipStream_t)stream, x, B, C, HW, (f16_t*)out, Cpad);
     else RF_CHECK(false, "rf_nchw_to_nhwc: bad out_dtype %d", out_dtype);
     RF_LAUNCH_CHECK("rf_nchw_to_nhwc");
     return 0;
@@ -296,6 +299,7 @@ extern "C" int rf_nhwc_to_nchw(int dtype, const void* x, int B, int C, int HW, i
     const long long n = (long long)B * C * HW;
     if (dtype == RF_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid1d(n), dim3(256), 0, (hipStream_t)stream, (const float*)x, B, C, HW, ldx, out);
     else if (dtype == RF_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid1d(n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, B, C, HW, ldx, out);
+    else if (dtype == RF_F16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16_t>, grid1d(n), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, B, C, HW, ldx, out);
     else RF_CHECK(false, "rf_nhwc_to_nchw: bad dtype %d", dtype);
     RF_LAUNCH_CHECK("rf_nhwc_to_nchw");
     return 0;
@@ -308,6 +312,8 @@ extern "C" int rf_cast(int in_dtype, const void* x, int out_dtype, void* out, in
     else if (in_dtype == RF_BF16 && out_dtype == RF_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid1d(n), dim3(256), 0, s, (const bf16_t*)x, (float*)out, (long long)n);
     else if (in_dtype == RF_F32 && out_dtype == RF_F32) hipLaunchKernelGGL((cast_kernel<float, float>), grid1d(n), dim3(256), 0, s, (const float*)x, (float*)out, (long long)n);
     else if (in_dtype == RF_BF16 && out_dtype == RF_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), grid1d(n), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, (long long)n);
+    else if (in_dtype == RF_F32 && out_dtype == RF_F16) hipLaunchKernelGGL((cast_kernel<float, f16_t>), grid1d(n), dim3(256), 0, s, (const float*)x, (f16_t*)out, (long long)n);
+    else if (in_dtype == RF_F16 && out_dtype == RF_F32) hipLaunchKernelGGL((cast_kernel<f16_t, float>), grid1d(n), dim3(256), 0, s, (const f16_t*)x, (float*)out, (long long)n);
     else RF_CHECK(false, "rf_cast: bad dtypes %d -> %d", in_dtype, out_dtype);
     RF_LAUNCH_CHECK("rf_cast");
     return 0;

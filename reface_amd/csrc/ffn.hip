@@ -21,6 +21,7 @@
 
 namespace rf {
 
+// (the 16-bit operands are addressed as uint16_t: the kernel's element type T -- bf16_t or f16_t -- only selects conversions and the MFMA)
 struct FfnParams {
     const bf16_t* x; int ldx;
     const bf16_t* w1; const float* b1;       // [8C][C] GEGLU-packed rows (32 value | 32 gate), [8C]
@@ -42,8 +43,9 @@ struct FfnParams {
 
 __device__ __forceinline__ int ffn_lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
-template <int C, bool PROJ>
+template <int C, bool PROJ, typename T = bf16_t>
 __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
+    static_assert(sizeof(T) == 2, "16-bit operands (bf16 / fp16)");
     constexpr int CK = C / 64;               // K tiles of GEMM 1
     constexpr int NB = C / 32;               // 32-row blocks of the output (transposed)
     constexpr int F = 4 * C;                 // hidden width
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
 #pragma unroll
         for (int s_ = 0; s_ < CK * 4; ++s_) {
             float f[8];
-            unpack16<bf16_t>(xq[s_], f);
+            unpack16<T>(xq[s_], f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) sum += f[e];
         }
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
 #pragma unroll
         for (int s_ = 0; s_ < CK * 4; ++s_) {
             float f[8];
-            unpack16<bf16_t>(xq[s_], f);
+            unpack16<T>(xq[s_], f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float d = f[e] - mu; sq += d * d; }
         }
@@ -111,10 +113,10 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
 #pragma unroll
         for (int s_ = 0; s_ < CK * 4; ++s_) {
             float f[8];
-            unpack16<bf16_t>(xq[s_], f);
+            unpack16<T>(xq[s_], f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = (f[e] - mu) * rstd;
-            xq[s_] = pack16<bf16_t>(f);
+            xq[s_] = pack16<T>(f);
         }
     }
 
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
                 }
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
-                    acc1[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[cur][b]), __builtin_bit_cast(bf16x8_t, xq[kt * 4 + kk]), acc1[b], 0, 0, 0);
+                    mma16<T>(acc1[b], wf[cur][b], xq[kt * 4 + kk]);
 #if RF_FFN_SPREAD == 2
                 // one LDS-DMA piece behind every k-step's MFMAs (their issue slots hide under the matrix pipe): W1 tile g + 3 into the stage tile g - 1
                 // left at the last barrier, the next chunk's W2 pieces behind k-steps 1 and 3, its bias behind the last k-step of K tile 0
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) hb[2 * pr + s2][e] = pack_bf2(h[8 * s2 + 2 * e], h[8 * s2 + 2 * e + 1]);
+                    for (int e = 0; e < 4; ++e) hb[2 * pr + s2][e] = pack2<T>(h[8 * s2 + 2 * e], h[8 * s2 + 2 * e + 1]);
             }
         }
         // ---- GEMM 2: O^T += W2c . H^T  (the W2 chunk was issued a whole chunk ago; the waits of K tiles 0 and 4 covered it)
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
                         const int nkk = (it + 1) / NB, nnb = (it + 1) % NB;
                         af[cur ^ 1] = *(const u32x4_t*)(w2base + nnb * 4096 + (((nkk * 2 + lhalf) ^ bsw) << 4));
                     }
-                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[cur]), __builtin_bit_cast(bf16x8_t, hb[kk]), acc2[nb], 0, 0, 0);
+                    mma16<T>(acc2[nb], af[cur], hb[kk]);
                 }
             }
         }
@@ -363,10 +365,10 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
                 for (int h = 0; h < 2; ++h) {
                     float f[8], v[8];
                     const f32x4_t c0 = *(const f32x4_t*)(b2l + col + 8 * h), c1 = *(const f32x4_t*)(b2l + col + 8 * h + 4);
-                    if (p.res) unpack16<bf16_t>(rq[nb % PFD][h], f);
+                    if (p.res) unpack16<T>(rq[nb % PFD][h], f);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = acc2[nb][8 * h + e] + (e < 4 ? c0[e] : c1[e - 4]) + (p.res ? f[e] : 0.f);
-                    ((u32x4_t*)dst)[h] = pack16<bf16_t>(v);
+                    ((u32x4_t*)dst)[h] = pack16<T>(v);
                 }
             }
             if (nb + PFD < NB) load_res(nb + PFD, rq[nb % PFD]);
@@ -390,10 +392,10 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
         for (int h = 0; h < 2; ++h) {
             float f[8], v[8];
             const f32x4_t c0 = *(const f32x4_t*)(b2l + col + 8 * h), c1 = *(const f32x4_t*)(b2l + col + 8 * h + 4);
-            if (p.res) unpack16<bf16_t>(rq[nb % PFD][h], f);
+            if (p.res) unpack16<T>(rq[nb % PFD][h], f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (row < p.M) ? acc2[nb][8 * h + e] + (e < 4 ? c0[e] : c1[e - 4]) + (p.res ? f[e] : 0.f) : 0.f;
-            pk[h] = pack16<bf16_t>(v);
+            pk[h] = pack16<T>(v);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
                         const int nkk = (it + 1) / NB, nnb = (it + 1) % NB;
                         af[cur ^ 1] = *(const u32x4_t*)(w2base + nnb * 4096 + (((nkk * 2 + lhalf) ^ bsw) << 4));
                     }
-                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[cur]), __builtin_bit_cast(bf16x8_t, hb3[kt * 4 + kk]), acc2[nb], 0, 0, 0);
+                    mma16<T>(acc2[nb], af[cur], hb3[kt * 4 + kk]);
                 }
 #if RF_FFN_SPREAD == 2
                 if (kt + 2 < CK) issue_wp_part(kt + 2, kk * 3, kk * 3 + 3 < NPW2 ? kk * 3 + 3 : NPW2);
@@ -491,13 +493,13 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
             for (int h = 0; h < 2; ++h) {
                 float f[8], v[8];
                 const f32x4_t c0 = *(const f32x4_t*)(bpl + col + 8 * h), c1 = *(const f32x4_t*)(bpl + col + 8 * h + 4);
-                if (p.res2) unpack16<bf16_t>(rq[nb % PFD][h], f);
+                if (p.res2) unpack16<T>(rq[nb % PFD][h], f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = acc2[nb][8 * h + e] + (e < 4 ? c0[e] : c1[e - 4]) + (p.res2 ? f[e] : 0.f);
-                const u32x4_t wv = pack16<bf16_t>(v);
+                const u32x4_t wv = pack16<T>(v);
                 ((u32x4_t*)dst)[h] = wv;
                 if (gn_on) {
-                    unpack16<bf16_t>(wv, f);
+                    unpack16<T>(wv, f);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) y[8 * h + e] = f[e];
                 }
@@ -537,10 +539,11 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
 
 }  // namespace rf
 
-static int ffn_launch(const rf::FfnParams& p, int C, void* stream) {
+static int ffn_launch(const rf::FfnParams& p, int C, void* stream, int dtype = RF_BF16) {
     using namespace rf;
     RF_CHECK(p.x && p.w1 && p.b1 && p.w2 && p.b2 && p.out && p.M > 0, "rf_ffn_geglu: bad arguments");
     RF_CHECK(C == 320, "rf_ffn_geglu: built for C = 320 (the 64x64 level), got %d", C);
+    RF_CHECK(dtype == RF_BF16 || dtype == RF_F16, "rf_ffn_block: dtype %d (RF_BF16 or RF_F16)", dtype);
     RF_CHECK(p.ldx % 8 == 0 && p.ldo % 8 == 0 && (!p.res || p.ldr % 8 == 0) && (!p.res2 || p.ldr2 % 8 == 0), "rf_ffn_geglu: row pitches must be multiples of 8");
     RF_CHECK(((uintptr_t)p.x | (uintptr_t)p.w1 | (uintptr_t)p.w2 | (uintptr_t)p.out | (uintptr_t)p.res | (uintptr_t)p.b1 | (uintptr_t)p.b2 | (uintptr_t)p.wpo | (uintptr_t)p.bpo |
               (uintptr_t)p.res2) % 16 == 0, "rf_ffn_geglu: operands must be 16-byte aligned");
@@ -554,17 +557,15 @@ static int ffn_launch(const rf::FfnParams& p, int C, void* stream) {
                      "rf_ffn_block: GroupNorm consumer %d: cpg=%d slot=%d needs %d slots of %d", c, p.gn_cpg[c], p.gn_slot[c], p.gn_rows / 128, p.gn_nch[c]);
     }
     constexpr int smem = 4 * 16384 + 2 * 320 * 128 + 2 * 4 * 512;
-    if (p.wpo) {
-        auto k = ffn_geglu_kernel<320, true>;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
-        hipLaunchKernelGGL(k, dim3((p.M + 127) / 128), dim3(256), smem, (hipStream_t)stream, p);
-    } else {
-        auto k = ffn_geglu_kernel<320, false>;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
-        hipLaunchKernelGGL(k, dim3((p.M + 127) / 128), dim3(256), smem, (hipStream_t)stream, p);
+#define RF_FFN_LAUNCH(PROJ_, T_)                                                                       \
+    {                                                                                                  \
+        auto k = ffn_geglu_kernel<320, PROJ_, T_>;                                                     \
+        RF_RAISE_LDS(k, smem, "rf_ffn_geglu");                                                         \
+        hipLaunchKernelGGL(k, dim3((p.M + 127) / 128), dim3(256), smem, (hipStream_t)stream, p);       \
     }
+    if (dtype == RF_F16) { if (p.wpo) RF_FFN_LAUNCH(true, f16_t) else RF_FFN_LAUNCH(false, f16_t) }
+    else { if (p.wpo) RF_FFN_LAUNCH(true, bf16_t) else RF_FFN_LAUNCH(false, bf16_t) }
+#undef RF_FFN_LAUNCH
     RF_LAUNCH_CHECK("rf_ffn_geglu");
     return 0;
 }
@@ -590,5 +591,5 @@ extern "C" int rf_ffn_block(const rf_ffn_desc* d, void* stream) {
     p.gn_rows = (d->gn_part0 || d->gn_part1) ? d->gn_rows : 0;
     p.gn_part[0] = d->gn_part0; p.gn_cpg[0] = d->gn_cpg0; p.gn_coff[0] = d->gn_coff0; p.gn_slot[0] = d->gn_slot0; p.gn_nch[0] = d->gn_nchunks0;
     p.gn_part[1] = d->gn_part1; p.gn_cpg[1] = d->gn_cpg1; p.gn_coff[1] = d->gn_coff1; p.gn_slot[1] = d->gn_slot1; p.gn_nch[1] = d->gn_nchunks1;
-    return ffn_launch(p, d->C, stream);
+    return ffn_launch(p, d->C, stream, d->dtype == 0 ? RF_BF16 : d->dtype);
 }

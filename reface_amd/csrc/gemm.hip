@@ -6,6 +6,8 @@
 // 128 bytes of K per row (64 bf16 or 32 fp32), LDS rows are 128 B with a 16-B-slot XOR swizzle,
 // every lane feeds the MFMA from one 16-B fragment (lane l: row l&31, slot 2*kk + (l>>5)):
 //   bf16 : 1 x v_mfma_f32_32x32x16_bf16 per fragment pair (8 k per lane-half)
+//   fp16 : 1 x v_mfma_f32_32x32x16_f16  -- the same kernels instantiated for f16_t (RF_F16, the "fp16" throughput mode): identical geometry and
+//          matrix-core rate, 11 significant bits per operand instead of 8; no fp8-weight (W8) and no split-operand (x3) variants
 //   fp32 : 4 x v_mfma_f32_32x32x2_f32   per fragment pair (exact fp32 FMA chain, 157 TF peak)
 // The A operand is gathered on the fly from channels-last source tensors (3x3 / 1x1, stride, asymmetric padding, nearest x2
 // upsample folded into the addressing, 2-source channel concat).  Hot path (GLDS): both operands go global -> LDS directly
@@ -125,6 +127,9 @@ template <> struct MmaFrag<bf16_t> {
 #endif
     }
 };
+template <> struct MmaFrag<f16_t> {
+    __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) { mma16<f16_t>(acc, a, b); }
+};
 template <> struct MmaFrag<fp8_t> {      // (the fp8 x fp8 path has its own main loop with block scales; this keeps the shared lambdas well-formed)
     __device__ static __forceinline__ void mma(f32x16_t&, const u32x4_t&, const u32x4_t&) {}
 };
@@ -165,9 +170,13 @@ template <bool W8> __device__ __forceinline__ int w_soff(int t) { return (W8 ? (
 template <typename TO> __device__ __forceinline__ void store_out(TO* p, float v);
 template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+template <> __device__ __forceinline__ void store_out<f16_t>(f16_t* p, float v) { *p = (f16_t)v; }
 template <typename TO> __device__ __forceinline__ float load_out(const TO* p);
 template <> __device__ __forceinline__ float load_out<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float load_out<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <> __device__ __forceinline__ float load_out<f16_t>(const f16_t* p) { return (float)*p; }
+// 16-bit storage element (bf16 or fp16): the forms that differ only in their conversions share one code path
+template <typename X> struct is16 { static constexpr bool value = std::is_same<X, bf16_t>::value || std::is_same<X, f16_t>::value; };
 
 // EPI = 1: "direct" epilogue.  The MFMA operands are swapped (W fragment as the row operand, A fragment as the column operand)
 // and the W rows of each 32-row block are read in the order  row(i') = 16*((i'>>2)&1) + 4*(i'>>3) + (i'&3), so that lane
@@ -191,8 +200,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
     static_assert(LNF == 0 || (EPI == 1 && !CONV && !W8 && sizeof(T) == 2 && sizeof(TO) == 2), "LayerNorm folding: bf16 linear layers on the direct epilogue");
     static_assert(!HX || (CONV && GLDS && NST == 2 && sizeof(T) == 2 && !W8 && EPI != 2), "row-extended A tiles: bf16 3x3 convolutions on the two-stage direct-to-LDS loop");
     static_assert(EPI == 0 || GLDS, "the direct / packed epilogues are built on the direct-to-LDS main loop");
-    static_assert(EPI != 2 || sizeof(TO) == 2, "the packed staged epilogue writes bf16");
-    static_assert(!W8 || (GLDS && sizeof(T) == 2), "fp8 weights: bf16 activations on the direct-to-LDS main loop");
+    static_assert(EPI != 2 || std::is_same<TO, bf16_t>::value, "the packed staged epilogue writes bf16");
+    static_assert(!W8 || (GLDS && std::is_same<T, bf16_t>::value), "fp8 weights: bf16 activations on the direct-to-LDS main loop");
     // A8: fp8 (e4m3fn) activations with one E8M0 scale per 32 channels x fp8 weights with one power-of-two scale per output channel on
     // v_mfma_scale_f32_32x32x64_f8f6f4: a K tile (128-byte rows) holds 128 K elements, two k-steps of 64
     constexpr bool A8 = std::is_same<T, fp8_t>::value;
@@ -1172,7 +1181,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 for (int h = 0; h < 2; ++h) {
                     u32x4_t w;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) w[e] = pack_bf2(v[8 * h + 2 * e], v[8 * h + 2 * e + 1]);
+                    for (int e = 0; e < 4; ++e) w[e] = pack2<TO>(v[8 * h + 2 * e], v[8 * h + 2 * e + 1]);
                     st16_out((u32x4_t*)dst + h, w);
                 }
             } else {
@@ -1507,7 +1516,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                     float rr[4];
                     if constexpr (sizeof(TO) == 2) {
                         const u32x2_t q = *(const u32x2_t*)(resp + (long long)row * p.ldr + ocol);
-                        rr[0] = as_f32(q[0] << 16); rr[1] = as_f32(q[0] & 0xffff0000u); rr[2] = as_f32(q[1] << 16); rr[3] = as_f32(q[1] & 0xffff0000u);
+                        const uint32_t q0 = q[0], q1 = q[1];
+                        rr[0] = lo16<TO>(q0); rr[1] = hi16<TO>(q0); rr[2] = lo16<TO>(q1); rr[3] = hi16<TO>(q1);
                     } else {
                         const f32x4_t q = *(const f32x4_t*)(resp + (long long)row * p.ldr + ocol);
                         rr[0] = q[0]; rr[1] = q[1]; rr[2] = q[2]; rr[3] = q[3];
@@ -1516,7 +1526,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                     for (int e = 0; e < 4; ++e) v[e] += rr[e];
                 }
                 if constexpr (sizeof(TO) == 2) {
-                    u32x2_t w; w[0] = pack_bf2(v[0], v[1]); w[1] = pack_bf2(v[2], v[3]);
+                    u32x2_t w; w[0] = pack2<TO>(v[0], v[1]); w[1] = pack2<TO>(v[2], v[3]);
                     *(u32x2_t*)dst = w;
                 } else {
                     *(f32x4_t*)dst = f32x4_t{v[0], v[1], v[2], v[3]};
@@ -1594,16 +1604,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                 if (full) {
                     if (resp) {
                         if constexpr (sizeof(TO) == 2) {
-                            v[0] += as_f32(rq[u][0] << 16); v[1] += as_f32(rq[u][0] & 0xffff0000u); v[2] += as_f32(rq[u][1] << 16); v[3] += as_f32(rq[u][1] & 0xffff0000u);
+                            const uint32_t q0 = rq[u][0], q1 = rq[u][1];
+                            v[0] += lo16<TO>(q0); v[1] += hi16<TO>(q0); v[2] += lo16<TO>(q1); v[3] += hi16<TO>(q1);
                         } else {
                             v[0] += rq[u][0]; v[1] += rq[u][1]; v[2] += rq[u][2]; v[3] += rq[u][3];
                         }
                     }
                     if constexpr (sizeof(TO) == 2) {
-                        u32x2_t w; w[0] = pack_bf2(v[0], v[1]); w[1] = pack_bf2(v[2], v[3]);
+                        u32x2_t w; w[0] = pack2<TO>(v[0], v[1]); w[1] = pack2<TO>(v[2], v[3]);
                         *(u32x2_t*)dst = w;
                         if (gn_on) {      // statistics of the values AS STORED (what the apply pass and the unfused statistics pass read)
-                            v[0] = as_f32(w[0] << 16); v[1] = as_f32(w[0] & 0xffff0000u); v[2] = as_f32(w[1] << 16); v[3] = as_f32(w[1] & 0xffff0000u);
+                            const uint32_t w0 = w[0], w1 = w[1];
+                            v[0] = lo16<TO>(w0); v[1] = hi16<TO>(w0); v[2] = lo16<TO>(w1); v[3] = hi16<TO>(w1);
                         }
                     }
                     if (gn_on) {
@@ -1623,7 +1635,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const GemmParams
                             store_out<TO>(dst + e, y);
                             if (gn_on) {
                                 float ys = y;
-                                if constexpr (sizeof(TO) == 2) ys = bf2f(f2bf(y));
+                                if constexpr (sizeof(TO) == 2) ys = round16<TO>(y);
                                 gsum[e] += ys; gsq[e] += ys * ys;
                             }
                         }
@@ -1739,7 +1751,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
                 float y4[4] = {0.f, 0.f, 0.f, 0.f}, r4[4] = {0.f, 0.f, 0.f, 0.f};
                 if (resp && full) {
                     if constexpr (sizeof(TO) == 2) {
-                        r4[0] = as_f32(rq[u][0] << 16); r4[1] = as_f32(rq[u][0] & 0xffff0000u); r4[2] = as_f32(rq[u][1] << 16); r4[3] = as_f32(rq[u][1] & 0xffff0000u);
+                        const uint32_t q0 = rq[u][0], q1 = rq[u][1];
+                        r4[0] = lo16<TO>(q0); r4[1] = hi16<TO>(q0); r4[2] = lo16<TO>(q1); r4[3] = hi16<TO>(q1);
                     } else {
                         r4[0] = rq[u][0]; r4[1] = rq[u][1]; r4[2] = rq[u][2]; r4[3] = rq[u][3];
                     }
@@ -1759,7 +1772,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
                     if (resp) y += full ? r4[e] : load_out<TO>(resp + (long long)row * p.ldr + c);
                     if (gn_on) {          // statistics of the value as stored
                         float ys = y;
-                        if constexpr (sizeof(TO) == 2) ys = bf2f(f2bf(y));
+                        if constexpr (sizeof(TO) == 2) ys = round16<TO>(y);
                         gsum[e] += ys; gsq[e] += ys * ys;
                     }
                     y4[e] = y;
@@ -1768,7 +1781,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
                 if (full) {
                     TO* dst = outp + (long long)row * p.ldo + col;
                     if constexpr (sizeof(TO) == 2) {
-                        u32x2_t w; w[0] = pack_bf2(y4[0], y4[1]); w[1] = pack_bf2(y4[2], y4[3]);
+                        u32x2_t w; w[0] = pack2<TO>(y4[0], y4[1]); w[1] = pack2<TO>(y4[2], y4[3]);
                         *(u32x2_t*)dst = w;
                     } else {
                         *(f32x4_t*)dst = f32x4_t{y4[0], y4[1], y4[2], y4[3]};
@@ -1930,7 +1943,7 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     // HX (row-extended A tiles for 3x3 stride-1 convolutions, korder 2): bf16 -> bf16 only; the stage of BM + BM / 4 rows must fit the 160 KB of LDS
     constexpr int RPP_ = WM * WN * 8, AXR_ = ((BM * 5 / 4 + RPP_ - 1) / RPP_) * RPP_;
     constexpr int smem_hx_ml = NST * (AXR_ + BN) * 128, smem_hx = smem_hx_ml > smem_ep ? smem_hx_ml : smem_ep;
-    constexpr bool HX_OK = std::is_same<T, bf16_t>::value && std::is_same<TO, bf16_t>::value && !W8 && !A8 && smem_hx <= 160 * 1024 && AXR_ / RPP_ <= 8;
+    constexpr bool HX_OK = is16<T>::value && std::is_same<TO, T>::value && !W8 && !A8 && smem_hx <= 160 * 1024 && AXR_ / RPP_ <= 8;
     const bool hx = p.korder == 2;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
@@ -2005,7 +2018,7 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     }
     // epilogue form (needed by the plan query too): see the selection notes below
     static const int epi_env = tune_env("RF_EPI", -1);
-    constexpr bool PACKED_OK = sizeof(TO) == 2 && !A8;
+    constexpr bool PACKED_OK = std::is_same<TO, bf16_t>::value && !A8;
     constexpr bool DIRECT_OK = (WM * WN == 8) || (TM * TN == 5) || (TM * TN >= 16) || std::is_same<T, fp8_t>::value;      // (fp8 x fp8: every tile --
                                                                                           // the GEGLU epilogue with fp8 output exists only in this form)
     const bool ep_common = p.glds && p.epi2_ok && p.splitk == 1 && (!p.rowvec || p.rows_per_sample % BM == 0) &&
@@ -2059,14 +2072,12 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
         constexpr int E_ = (EPI_ == 2 && PACKED_OK) ? 2 : ((EPI_ == 1 && DIRECT_OK) ? 1 : 0);                                   \
         if (GLDS_ && deep) {                                                                                                     \
             auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NSTD : 2), E_, (W8 && GLDS_), LNF_, false>; \
-            static bool attr = false;                                                                                            \
-            if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem_deep); attr = true; } \
+            RF_RAISE_LDS(k, smem_deep, "rf_conv_gemm");                                                                          \
             hipLaunchKernelGGL(k, grid, block, smem_deep, st, p);                                                                \
         } else {                                                                                                                 \
             auto k = conv_gemm_kernel<T, TO, WM, WN, TM, TN, CONV_, GLDS_, (GLDS_ ? NST : 2), E_, (W8 && GLDS_), LNF_, HX_>;    \
             constexpr int SM_ = HX_ ? smem_hx : (smem_pk > smem ? smem_pk : smem);                                               \
-            static bool attr = false;                                                                                            \
-            if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SM_); attr = true; } \
+            RF_RAISE_LDS(k, SM_, "rf_conv_gemm");                                                                                \
             hipLaunchKernelGGL(k, grid, block, HX_ ? smem_hx : smem_l, st, p);                                                   \
         }                                                                                                                        \
     }
@@ -2076,7 +2087,7 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
     // The ring of four stages for 128x160 launches of at most one block per CU (4096 x 1280 x K <= 6000: the projections, ff.net.2 and 1x1 skips
     // of the 16x16 level, 25 launches per step): nothing else covers the single tile of look-ahead there.  Alone (warm weights) it is neutral
     // (4096x1280x5120 68.3 -> 66.7 us); in situ, where every launch streams weights the previous ones pushed out of the caches, -0.9 % per batch
-    // (tools/exp_r03_10.sh: 921.7 -> 913.5 ms, same box, two runs each).  Forcing the 8x8 level (M = 1024) onto this tile + ring: neutral for the
+    // (tools/archive/exp_r03_10.sh: 921.7 -> 913.5 ms, same box, two runs each).  Forcing the 8x8 level (M = 1024) onto this tile + ring: neutral for the
     // 3x3 convs, +0.9 % for its small projections.
     static const int deep_env = tune_env("RF_GEMM_DEEP", 256);        // largest grid (blocks) that takes the ring
     constexpr int smem_deep = NSTD * (BM + BN) * 128 > smem ? NSTD * (BM + BN) * 128 : smem;
@@ -2199,7 +2210,7 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
                 // (also 1.5 rounds: qkv of the 32x32 level, 384 tiles -> 1536 quarter tiles = three full rounds at two blocks per CU; and the
                 //  K = C projections with a residual at the 64x64 level -- 107 FLOP per byte of compulsory traffic, bandwidth-bound: two
                 //  co-resident blocks keep loads, residual reads and stores of different tiles in flight together, 61 -> 48 us with cold
-                //  operands; together -0.7 % per batch, tools/exp_r03_14.sh)
+                //  operands; together -0.7 % per batch, tools/archive/exp_r03_14.sh)
                 const double rounds = (double)(mt256 * nt) / 256.0, rfill = rounds / (double)((mt256 * nt + 255) / 256);
                 // 256-wide tiles (GEGLU, N not a multiple of 320) whose last round is 20-60 % full -- 4096 x 10240 x 1280, the GEGLU projection of
                 // the 16x16 level: 640 tiles = 2.5 rounds, three round times -- are split along N: the whole rounds on 256-row tiles, the columns of
@@ -2231,8 +2242,18 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
                     };
                     GemmParams q1 = part(0, n1);
                     const int rc = launch_cfg<T, TO, 4, 2, 2, 4, W8>(d, q1, conv, st);
-                    if (rc != 0 || p.plan) return rc;                                        // (a plan query reports the whole-round tiling)
+                    if (rc != 0) return rc;
                     GemmParams q2 = part(n1, N - n1);
+                    if (p.plan) {
+                        // a plan query reports the whole-round tiling of the first part -- but BOTH parts must be launchable (a LayerNorm consumer
+                        // needs the direct epilogue in the tail too): the tail's plan is validated here, not at the first replay.  Bit 1 of the
+                        // eighth plan word says that the call runs as two GEMM kernels.
+                        int tail_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                        q2.plan = tail_plan;
+                        const int rc2 = launch_typed<T, TO, W8>(d, q2, conv, st);
+                        if (rc2 == 0) p.plan[7] |= 2;
+                        return rc2;
+                    }
                     return launch_typed<T, TO, W8>(d, q2, conv, st);
                 }
                 if (n320 && (rfill < 0.6 || (rfill < 0.8 && rounds > 1.0) || (d->residual && p.K <= 320))) return launch_cfg<T, TO, 4, 1, 1, 5, W8>(d, p, conv, st);
@@ -2265,6 +2286,16 @@ static int launch_typed(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hi
     }
 }
 
+#ifdef RF_GEMM_F16_UNIT
+// gemm_f16.hip: the fp16 (RF_F16) instantiations of the templates above as a compile unit of their own -- built beside gemm.hip instead of
+// lengthening its four minutes of compile time by another two.  rf_conv_gemm's argument checks and GemmParams set-up stay in gemm.hip.
+int launch_f16(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipStream_t st) {
+    if (d->out_dtype == RF_F32) return launch_typed<f16_t, float>(d, p, conv, st);
+    return launch_typed<f16_t, f16_t>(d, p, conv, st);
+}
+}  // namespace rf
+#else
+int launch_f16(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipStream_t st);          // gemm_f16.hip
 }  // namespace rf
 
 static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
@@ -2272,14 +2303,18 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
     RF_CHECK(d != nullptr, "rf_conv_gemm: null descriptor");
     const bool oq = d->out_dtype == RF_FP8_E4M3;       // fp8 output + block scales (GEGLU of the fp8 x fp8 path)
     const bool x3 = d->dtype == RF_BF16X3;
-    RF_CHECK(d->dtype == RF_F32 || d->dtype == RF_BF16 || x3 || d->dtype == RF_FP8_E4M3, "rf_conv_gemm: bad dtype %d", d->dtype);
+    const bool h16 = d->dtype == RF_F16;             // fp16 operands: the bf16 kernels' geometry on v_mfma_f32_32x32x16_f16
+    RF_CHECK(d->dtype == RF_F32 || d->dtype == RF_BF16 || h16 || x3 || d->dtype == RF_FP8_E4M3, "rf_conv_gemm: bad dtype %d", d->dtype);
+    RF_CHECK(!h16 || ((d->out_dtype == RF_F16 || d->out_dtype == RF_F32) && d->w_dtype == 0),
+             "rf_conv_gemm: fp16 operands write fp16 or fp32 and take fp16 weights (out_dtype %d, w_dtype %d)", d->out_dtype, d->w_dtype);
+    RF_CHECK(d->out_dtype != RF_F16 || h16, "rf_conv_gemm: fp16 output needs fp16 operands (dtype %d)", d->dtype);
     RF_CHECK(d->dtype != RF_FP8_E4M3 || (d->w_dtype == RF_FP8_E4M3 && d->wscale && d->ascale && d->as_ld > 0 && d->as_ld % 4 == 0 && (d->out_dtype == RF_BF16 || oq) &&
                                          d->C1 == 0 && d->batch == 1 && d->korder == 0 && d->K % 128 == 0 && (d->C0 % 128 == 0 || (d->KH == 1 && d->KW == 1))),
              "rf_conv_gemm: fp8 activations need fp8 weights + wscale, ascale with a pitch that is a multiple of 4, bf16 output, one source, batch 1, "
              "K a multiple of 128 (zero-padded weights) and, for k x k windows, C0 a multiple of 128");
     RF_CHECK(!x3 || (d->out_dtype == RF_F32 && d->w_dtype == 0 && d->korder == 0 && d->C1 == 0 && d->batch == 1 && d->ld0 >= 2 * d->C0),
              "rf_conv_gemm: split-bf16 operands need fp32 output, one source with pixel pitch >= 2*C0, batch 1, tap-major K");
-    RF_CHECK(d->out_dtype == RF_F32 || d->out_dtype == RF_BF16 || oq, "rf_conv_gemm: bad out_dtype %d", d->out_dtype);
+    RF_CHECK(d->out_dtype == RF_F32 || d->out_dtype == RF_BF16 || d->out_dtype == RF_F16 || oq, "rf_conv_gemm: bad out_dtype %d", d->out_dtype);
     RF_CHECK(!oq || (d->dtype == RF_FP8_E4M3 && d->act == RF_ACT_GEGLU && d->oscale && d->os_ld >= d->N / 64 && !d->residual && d->N % 64 == 0),
              "rf_conv_gemm: fp8 output is the GEGLU epilogue of the fp8 x fp8 path (oscale, no residual, N a multiple of 64)");
     const bool a8 = d->dtype == RF_FP8_E4M3;           // fp8 activations + E8M0 block scales x fp8 weights (MX-scaled MFMA)
@@ -2304,8 +2339,8 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
     RF_CHECK(!d->rowvec || d->rows_per_sample > 0, "rf_conv_gemm: rowvec needs rows_per_sample");
     RF_CHECK(d->korder == 0 || ((d->korder == 1 || d->korder == 2) && ctot % (8 * vec) == 0 && d->K == d->KH * d->KW * ctot),
              "rf_conv_gemm: korder=%d needs (C0+C1) to be a multiple of %d", d->korder, 8 * vec);
-    RF_CHECK(d->korder != 2 || (d->dtype == RF_BF16 && d->out_dtype == RF_BF16 && d->w_dtype == 0 && d->C1 == 0 && d->batch == 1),
-             "rf_conv_gemm: korder=2 (row-extended A tiles) is built for bf16 -> bf16 convolutions of one source");
+    RF_CHECK(d->korder != 2 || ((d->dtype == RF_BF16 || h16) && d->out_dtype == d->dtype && d->w_dtype == 0 && d->C1 == 0 && d->batch == 1),
+             "rf_conv_gemm: korder=2 (row-extended A tiles) is built for bf16 -> bf16 / fp16 -> fp16 convolutions of one source");
     RF_CHECK(d->act != RF_ACT_PRELU || d->act_vec, "rf_conv_gemm: PReLU needs act_vec (per-column slopes)");
     const bool conv = !(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->ups == 0 &&
                         d->C1 == 0 && d->Hin == d->Hout && d->Win == d->Wout);
@@ -2326,8 +2361,8 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
     p.plan = plan;
     p.ln_out = (float*)d->ln_stats_out; p.ln_out_parts = d->ln_out_parts;
     p.ln_in = (const float*)d->ln_stats_in; p.ln_in_parts = d->ln_in_parts; p.ln_in_cols = d->ln_in_cols; p.ln_eps = d->ln_eps; p.ln_u = d->ln_u;
-    RF_CHECK(!(p.ln_out || p.ln_in) || (d->out_dtype == RF_BF16 && d->dtype == RF_BF16 && d->batch == 1 && !(p.ln_out && p.ln_in)),
-             "rf_conv_gemm: LayerNorm folding is built for bf16 GEMMs (batch 1, one role per launch)");
+    RF_CHECK(!(p.ln_out || p.ln_in) || ((d->dtype == RF_BF16 || h16) && d->out_dtype == d->dtype && d->batch == 1 && !(p.ln_out && p.ln_in)),
+             "rf_conv_gemm: LayerNorm folding is built for bf16 / fp16 GEMMs (batch 1, one role per launch)");
     {
         static const int dbg = tune_env("RF_GEMM_DBG", 0);
         p.dbg = dbg;
@@ -2386,7 +2421,9 @@ static int conv_gemm_impl(const rf_conv_gemm_desc* d, void* stream, int* plan) {
         return launch_typed<bf16_t, bf16_t, true>(d, p, conv, st);
     }
     if (x3) return launch_typed<bf16_t, float>(d, p, conv, st);
+    if (h16) return launch_f16(d, p, conv, st);
     if (a8) return launch_typed<fp8_t, bf16_t>(d, p, conv, st);
+    RF_CHECK(d->out_dtype != RF_F16, "rf_conv_gemm: fp16 output needs fp16 operands");
     if (d->dtype == RF_F32) {
         if (d->out_dtype == RF_F32) return launch_typed<float, float>(d, p, conv, st);
         return launch_typed<float, bf16_t>(d, p, conv, st);
@@ -2459,4 +2496,5 @@ extern "C" int rf_conv_gemm_plan2(const rf_conv_gemm_desc* d, int32_t* info8) {
     return rc;
 }
 
+#endif          // RF_GEMM_F16_UNIT
 #endif          // RF_KERNEL_ONLY

@@ -351,11 +351,11 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x
 using namespace rf;
 
 extern "C" const char* rf_last_error(void) { return rf::g_err; }
-extern "C" int rf_version(void) { return 100; }
+extern "C" int rf_version(void) { return 101; }          // 101: RF_F16 (the fp16 throughput mode), `dtype` in rf_ffn_desc / rf_stem_desc / rf_gn_silu_conv3x3_small
 
 static int gn_check(const char* name, int dtype, int C, int ldx, int nchunks) {
     const int vec = dtype == RF_F32 ? 4 : 8;
-    RF_CHECK(dtype == RF_F32 || dtype == RF_BF16, "%s: bad dtype %d", name, dtype);
+    RF_CHECK(dtype == RF_F32 || dtype == RF_BF16 || dtype == RF_F16, "%s: bad dtype %d", name, dtype);
     RF_CHECK(C % 32 == 0 && C % vec == 0 && ldx % vec == 0, "%s: C=%d ld=%d must be multiples of 32 and %d", name, C, ldx, vec);
     RF_CHECK(C / vec <= GN_SLOTS * GN_THREADS, "%s: C=%d too large", name, C);
     RF_CHECK(nchunks >= 1, "%s: nchunks=%d", name, nchunks);
@@ -371,6 +371,7 @@ extern "C" int rf_groupnorm_stats(int dtype, const void* x, int B, int HW, int C
     const size_t smem = (size_t)2 * PL * C * sizeof(double);
     RF_CHECK(smem <= 64 * 1024, "rf_groupnorm_stats: C=%d needs %zu B of LDS", C, smem);
     if (dtype == RF_F32) hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(GN_THREADS), smem, (hipStream_t)stream, (const float*)x, HW, C, ldx, nchunks, partial);
+    else if (dtype == RF_F16) hipLaunchKernelGGL(gn_stats_kernel<f16_t>, grid, dim3(GN_THREADS), smem, (hipStream_t)stream, (const f16_t*)x, HW, C, ldx, nchunks, partial);
     else hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(GN_THREADS), smem, (hipStream_t)stream, (const bf16_t*)x, HW, C, ldx, nchunks, partial);
     RF_LAUNCH_CHECK("rf_groupnorm_stats");
     return 0;
@@ -410,7 +411,8 @@ extern "C" int rf_groupnorm_apply(int dtype, const void* x, int B, int HW, int C
     RF_CHECK(x && partial && gamma && beta && out && B > 0 && HW > 0, "rf_groupnorm_apply: bad arguments");
     RF_CHECK((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "rf_groupnorm_apply: gamma / beta must be 16-byte aligned");
     const int split = out_dtype == RF_BF16X3 ? 1 : 0;      // [C hi | C lo] bf16 pairs per pixel (ldo >= 2C), fp32 input
-    RF_CHECK(out_dtype == RF_F32 || out_dtype == RF_BF16 || split, "rf_groupnorm_apply: bad out_dtype");
+    RF_CHECK(out_dtype == RF_F32 || out_dtype == RF_BF16 || out_dtype == RF_F16 || split, "rf_groupnorm_apply: bad out_dtype");
+    RF_CHECK((dtype == RF_F16) == (out_dtype == RF_F16) || (dtype == RF_F16 && out_dtype == RF_F32), "rf_groupnorm_apply: fp16 goes to fp16 or fp32 (dtype %d, out_dtype %d)", dtype, out_dtype);
     RF_CHECK(!split || (dtype == RF_F32 && ldo >= 2 * C), "rf_groupnorm_apply: split-bf16 output needs fp32 input and ldo >= 2C");
     RF_CHECK(ldo % 8 == 0, "rf_groupnorm_apply: ldo=%d must be a multiple of 8", ldo);
     // about 4 blocks per CU in total, down to 2 pixels per block: the launches of the 16x16 / 8x8 levels are latency chains (statistics -> scale / shift -> pixels
@@ -425,6 +427,8 @@ extern "C" int rf_groupnorm_apply(int dtype, const void* x, int B, int HW, int C
 #define GN_APPLY_(T, TO, NS_) hipLaunchKernelGGL((gn_apply_kernel<T, TO, NS_>), grid, dim3(GN_THREADS), 0, st, (const T*)x, HW, C, ldx, nchunks, partial, gamma, beta, eps, silu, (TO*)out, ldo, achunks, split)
 #define GN_APPLY(T, TO) { if (ns <= 1) GN_APPLY_(T, TO, 1); else if (ns <= 2) GN_APPLY_(T, TO, 2); else GN_APPLY_(T, TO, GN_SLOTS); }
     if (dtype == RF_F32 && out_dtype == RF_F32) GN_APPLY(float, float)
+    else if (dtype == RF_F16 && out_dtype == RF_F32) GN_APPLY(f16_t, float)
+    else if (dtype == RF_F16) GN_APPLY(f16_t, f16_t)
     else if (dtype == RF_F32) GN_APPLY(float, bf16_t)
     else if (out_dtype == RF_F32) GN_APPLY(bf16_t, float)
     else GN_APPLY(bf16_t, bf16_t)
@@ -539,14 +543,14 @@ extern "C" int rf_groupnorm_fold_linear(const float* W, int N, int C, int B, int
                                         const float* beta, const float* bias, float eps, int out_dtype, void* w_out, float* rowvec_out, void* stream) {
     RF_CHECK(W && partial && gamma && beta && w_out && rowvec_out && N > 0 && B > 0 && HW > 0 && nchunks >= 1, "rf_groupnorm_fold_linear: bad arguments");
     RF_CHECK(C > 0 && C % 32 == 0 && C <= 1536, "rf_groupnorm_fold_linear: C=%d must be a multiple of 32, at most 1536", C);
-    RF_CHECK(out_dtype == RF_BF16 || out_dtype == RF_F32, "rf_groupnorm_fold_linear: bad out_dtype %d", out_dtype);
+    RF_CHECK(out_dtype == RF_BF16 || out_dtype == RF_F16 || out_dtype == RF_F32, "rf_groupnorm_fold_linear: bad out_dtype %d", out_dtype);
     RF_CHECK((((uintptr_t)W | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)w_out) & 15) == 0, "rf_groupnorm_fold_linear: W / gamma / beta / w_out must be 16-byte aligned");
     constexpr int RPB = (GN_THREADS / 64) * GN_FOLD_RPW;
     dim3 grid((N + RPB - 1) / RPB, B);
     hipStream_t st = (hipStream_t)stream;
 #define GN_FOLD_(TO, NIT) hipLaunchKernelGGL((gn_fold_linear_kernel<TO, NIT>), grid, dim3(GN_THREADS), 0, st, W, N, C, HW, nchunks, partial, gamma, beta, bias, eps, (TO*)w_out, rowvec_out)
 #define GN_FOLD(TO) { if (C <= 512) GN_FOLD_(TO, 1); else if (C <= 1024) GN_FOLD_(TO, 2); else GN_FOLD_(TO, 3); }
-    if (out_dtype == RF_BF16) GN_FOLD(bf16_t) else GN_FOLD(float)
+    if (out_dtype == RF_BF16) GN_FOLD(bf16_t) else if (out_dtype == RF_F16) GN_FOLD(f16_t) else GN_FOLD(float)
 #undef GN_FOLD
 #undef GN_FOLD_
     RF_LAUNCH_CHECK("rf_groupnorm_fold_linear");
@@ -615,9 +619,10 @@ extern "C" int rf_quantize_fp8_act(const void* x, int64_t M, int C, int ldx, voi
 extern "C" int rf_layernorm(int dtype, const void* x, int M, int C, int ldx, const float* gamma, const float* beta, float eps,
                             int out_dtype, void* out, int ldo, void* stream) {
     const int vec = dtype == RF_F32 ? 4 : 8;
-    RF_CHECK(dtype == RF_F32 || dtype == RF_BF16, "rf_layernorm: bad dtype %d", dtype);
+    RF_CHECK(dtype == RF_F32 || dtype == RF_BF16 || dtype == RF_F16, "rf_layernorm: bad dtype %d", dtype);
     const int split = out_dtype == RF_BF16X3 ? 1 : 0;          // split-bf16 pairs [C hi | C lo] per row (ldo >= 2C), fp32 input
-    RF_CHECK(out_dtype == RF_F32 || out_dtype == RF_BF16 || split, "rf_layernorm: bad out_dtype");
+    RF_CHECK(out_dtype == RF_F32 || out_dtype == RF_BF16 || out_dtype == RF_F16 || split, "rf_layernorm: bad out_dtype");
+    RF_CHECK((dtype == RF_F16) == (out_dtype == RF_F16) || (dtype == RF_F16 && out_dtype == RF_F32), "rf_layernorm: fp16 goes to fp16 or fp32 (dtype %d, out_dtype %d)", dtype, out_dtype);
     RF_CHECK(!split || (dtype == RF_F32 && ldo >= 2 * C), "rf_layernorm: split-bf16 output needs fp32 input and ldo >= 2C");
     RF_CHECK(x && gamma && beta && out && M > 0, "rf_layernorm: bad arguments");
     RF_CHECK((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "rf_layernorm: gamma / beta must be 16-byte aligned");
@@ -628,6 +633,8 @@ extern "C" int rf_layernorm(int dtype, const void* x, int M, int C, int ldx, con
 #define LN_(T, TO, NV) hipLaunchKernelGGL((layernorm_kernel<T, TO, NV>), grid, dim3(256), 0, st, (const T*)x, M, C, ldx, gamma, beta, eps, (TO*)out, ldo, (fp8_t*)nullptr, 0, split)
 #define LN(T, TO) { if (nv <= 1) LN_(T, TO, 1); else if (nv <= 2) LN_(T, TO, 2); else if (nv <= 3) LN_(T, TO, 3); else LN_(T, TO, LN_MAXV); }
     if (dtype == RF_F32 && out_dtype == RF_F32) LN(float, float)
+    else if (dtype == RF_F16 && out_dtype == RF_F32) LN(f16_t, float)
+    else if (dtype == RF_F16) LN(f16_t, f16_t)
     else if (dtype == RF_F32) LN(float, bf16_t)
     else if (out_dtype == RF_F32) LN(bf16_t, float)
     else LN(bf16_t, bf16_t)

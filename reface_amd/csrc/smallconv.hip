@@ -24,7 +24,8 @@ struct SmallConvParams {
 constexpr int SC_YP = 40;              // floats per pixel in y (9 No <= 36 used; 160-byte rows keep the 16-byte vectors aligned)
 
 // kernel 1: block = 4 waves = 128 pixels of one sample
-template <int C>
+// (T = bf16_t or f16_t: the 16-bit operands are addressed as uint16_t, T selects the conversions and the MFMA)
+template <int C, typename T = bf16_t>
 __global__ __launch_bounds__(256) void gn_silu_taps_kernel(const SmallConvParams p) {
     constexpr int KS = C / 16;                                   // k-steps of 16 channels
     constexpr int WP = C * 2 + 16;                               // row pitch of the weight table in LDS (bytes): 16-byte skew against bank conflicts
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void gn_silu_taps_kernel(const SmallConvParams
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         float f[8];
-        unpack16<bf16_t>(xq[s], f);
+        unpack16<T>(xq[s], f);
         const int c0 = s * 16 + lhalf * 8;
         const f32x4_t a0 = *(const f32x4_t*)(scl + c0), a1 = *(const f32x4_t*)(scl + c0 + 4), h0 = *(const f32x4_t*)(shl + c0), h1 = *(const f32x4_t*)(shl + c0 + 4);
 #pragma unroll
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void gn_silu_taps_kernel(const SmallConvParams
             if (p.silu) v = silu_exact(v);
             f[e] = v;
         }
-        xq[s] = pack16<bf16_t>(f);
+        xq[s] = pack16<T>(f);
     }
     // ---- Y^T = Wt . act(X)^T : two 32-row blocks (rows >= 9 No read a clamped row: their results are never used)
     f32x16_t acc[2];
@@ -127,8 +128,8 @@ __global__ __launch_bounds__(256) void gn_silu_taps_kernel(const SmallConvParams
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const u32x4_t w0 = *(const u32x4_t*)(wl + r0 * WP + (s * 16 + lhalf * 8) * 2), w1 = *(const u32x4_t*)(wl + r1 * WP + (s * 16 + lhalf * 8) * 2);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w0), __builtin_bit_cast(bf16x8_t, xq[s]), acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w1), __builtin_bit_cast(bf16x8_t, xq[s]), acc[1], 0, 0, 0);
+        mma16<T>(acc[0], w0, xq[s]);
+        mma16<T>(acc[1], w1, xq[s]);
     }
     // accumulator register r of block k = row 32 k + (r & 3) + 8 (r >> 2) + 4 half of this lane's pixel: four 16-byte row runs per block
     if (live) {
@@ -191,7 +192,7 @@ struct StemParams {
     double* gn_part[3]; int gn_cpg[3], gn_coff[3], gn_slot[3], gn_nch[3];
 };
 
-template <int NB>
+template <int NB, typename T = bf16_t>
 __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const StemParams p) {
     constexpr int C = 32 * NB;
     constexpr int WP = 144 * 2 + 16;                             // row pitch of the weight table in LDS (bytes), 16-byte skew
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const StemParams p) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const u32x4_t af = *(const u32x4_t*)(wb + nb * 32 * WP + t * 32);
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, xq[t]), acc[nb], 0, 0, 0);
+            mma16<T>(acc[nb], af, xq[t]);
         }
 
     const bool gn_on = p.gn_part[0] || p.gn_part[1] || p.gn_part[2];
@@ -267,10 +268,10 @@ __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const StemParams p) {
             const f32x4_t c0 = *(const f32x4_t*)(bl + col + 8 * h), c1 = *(const f32x4_t*)(bl + col + 8 * h + 4);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = acc[nb][8 * h + e] + (e < 4 ? c0[e] : c1[e - 4]);
-            const u32x4_t wv = pack16<bf16_t>(v);
+            const u32x4_t wv = pack16<T>(v);
             *(u32x4_t*)(orow + col + 8 * h) = wv;
             if (p.dup_off) *(u32x4_t*)(orow + p.dup_off + col + 8 * h) = wv;
-            unpack16<bf16_t>(wv, f);
+            unpack16<T>(wv, f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) y[8 * h + e] = f[e];
         }
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const StemParams p) {
 
 }  // namespace rf
 
-extern "C" int rf_gn_silu_conv3x3_small(const void* x, int B, int H, int W, int C, int ldx, int nchunks, const double* partial, const float* gamma,
+extern "C" int rf_gn_silu_conv3x3_small(int dtype, const void* x, int B, int H, int W, int C, int ldx, int nchunks, const double* partial, const float* gamma,
                                         const float* beta, float eps, int silu, const void* w, const float* bias, int No, int out_dtype, void* out, int ldo,
                                         float* workspace, long long workspace_bytes, void* stream) {
     using namespace rf;
@@ -311,7 +312,8 @@ extern "C" int rf_gn_silu_conv3x3_small(const void* x, int B, int H, int W, int 
     RF_CHECK(B > 0 && H > 0 && W > 0 && nchunks > 0 && No >= 1 && No <= 4, "rf_gn_silu_conv3x3_small: bad sizes (1 <= No <= 4: 9 No rows fit SC_YP), got No=%d", No);
     RF_CHECK(C == 320 || C == 128 || C == 64, "rf_gn_silu_conv3x3_small: built for C = 320 (REFace), 128, 64 (reduced-width tests), got %d", C);
     RF_CHECK(ldx % 8 == 0 && ((uintptr_t)x | (uintptr_t)w) % 16 == 0 && (uintptr_t)workspace % 16 == 0, "rf_gn_silu_conv3x3_small: operands must be 16-byte aligned, ldx a multiple of 8");
-    RF_CHECK(out_dtype == RF_F32 || out_dtype == RF_BF16, "rf_gn_silu_conv3x3_small: bad out_dtype %d", out_dtype);
+    RF_CHECK(dtype == RF_BF16 || dtype == RF_F16, "rf_gn_silu_conv3x3_small: dtype %d (RF_BF16 or RF_F16)", dtype);
+    RF_CHECK(out_dtype == RF_F32 || out_dtype == dtype, "rf_gn_silu_conv3x3_small: out_dtype %d (fp32 or the input's type)", out_dtype);
     const long long M = (long long)B * H * W;
     RF_CHECK(workspace_bytes >= M * SC_YP * 4, "rf_gn_silu_conv3x3_small: workspace of %lld bytes needed", M * SC_YP * 4);
     SmallConvParams p;
@@ -319,11 +321,14 @@ extern "C" int rf_gn_silu_conv3x3_small(const void* x, int B, int H, int W, int 
     p.gamma = gamma; p.beta = beta; p.eps = eps; p.silu = silu; p.w = (const bf16_t*)w; p.y = workspace;
     hipStream_t st = (hipStream_t)stream;
     const int nb = B * ((H * W + 127) / 128);
-#define RF_SC(C_) { const int smem = 36 * (C_ * 2 + 16) + 2 * C_ * 4; hipLaunchKernelGGL(gn_silu_taps_kernel<C_>, dim3(nb), dim3(256), smem, st, p); }
+#define RF_SC(C_) { const int smem = 36 * (C_ * 2 + 16) + 2 * C_ * 4;                                                                      \
+        if (dtype == RF_F16) hipLaunchKernelGGL((gn_silu_taps_kernel<C_, f16_t>), dim3(nb), dim3(256), smem, st, p);                          \
+        else hipLaunchKernelGGL((gn_silu_taps_kernel<C_, bf16_t>), dim3(nb), dim3(256), smem, st, p); }
     if (C == 320) RF_SC(320) else if (C == 128) RF_SC(128) else RF_SC(64)
 #undef RF_SC
     const int gb = (int)((M + 255) / 256);
     if (out_dtype == RF_F32) hipLaunchKernelGGL(gather_taps_kernel<float>, dim3(gb), dim3(256), 0, st, workspace, B, H, W, No, bias, (float*)out, ldo);
+    else if (out_dtype == RF_F16) hipLaunchKernelGGL(gather_taps_kernel<f16_t>, dim3(gb), dim3(256), 0, st, workspace, B, H, W, No, bias, (f16_t*)out, ldo);
     else hipLaunchKernelGGL(gather_taps_kernel<bf16_t>, dim3(gb), dim3(256), 0, st, workspace, B, H, W, No, bias, (bf16_t*)out, ldo);
     RF_LAUNCH_CHECK("rf_gn_silu_conv3x3_small");
     return 0;
@@ -334,6 +339,8 @@ extern "C" int rf_conv3x3_stem(const rf_stem_desc* d, void* stream) {
     RF_CHECK(d && d->x && d->w && d->out, "rf_conv3x3_stem: null argument");
     RF_CHECK(d->B > 0 && d->H > 0 && d->W > 0 && (d->H * d->W) % 128 == 0, "rf_conv3x3_stem: H*W = %d must be a multiple of the 128-pixel block", d->H * d->W);
     RF_CHECK(d->C == 320 || d->C == 128 || d->C == 64, "rf_conv3x3_stem: built for C = 320 (REFace), 128, 64 (reduced-width tests), got %d", d->C);
+    const int dtype = d->dtype == 0 ? RF_BF16 : d->dtype;
+    RF_CHECK(dtype == RF_BF16 || dtype == RF_F16, "rf_conv3x3_stem: dtype %d (RF_BF16 or RF_F16)", d->dtype);
     RF_CHECK(d->ldx >= 16 && d->ldx % 8 == 0 && d->ldo >= d->C && d->ldo % 8 == 0 && d->dup_off % 8 == 0, "rf_conv3x3_stem: ldx=%d (>= 16 stored channels) / ldo=%d / dup_off must be multiples of 8", d->ldx, d->ldo);
     RF_CHECK(((uintptr_t)d->x | (uintptr_t)d->w | (uintptr_t)d->out) % 16 == 0, "rf_conv3x3_stem: operands must be 16-byte aligned");
     StemParams p;
@@ -348,10 +355,12 @@ extern "C" int rf_conv3x3_stem(const rf_stem_desc* d, void* stream) {
         p.gn_part[c] = parts[c]; p.gn_cpg[c] = cpg[c]; p.gn_coff[c] = coff[c]; p.gn_slot[c] = slot[c]; p.gn_nch[c] = nch[c];
     }
     const int nb = d->B * (d->H * d->W / 128);
-#define RF_STEM(NB_) { constexpr int smem = 32 * NB_ * (144 * 2 + 16) + 32 * NB_ * 4 * 9; auto k = stem_conv3x3_kernel<NB_>; \
-        static bool attr = false; if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; } \
+#define RF_STEM_(NB_, T_) { constexpr int smem = 32 * NB_ * (144 * 2 + 16) + 32 * NB_ * 4 * 9; auto k = stem_conv3x3_kernel<NB_, T_>; \
+        RF_RAISE_LDS(k, smem, "rf_conv3x3_stem"); \
         hipLaunchKernelGGL(k, dim3(nb), dim3(256), smem, (hipStream_t)stream, p); }
+#define RF_STEM(NB_) { if (dtype == RF_F16) RF_STEM_(NB_, f16_t) else RF_STEM_(NB_, bf16_t) }
     if (d->C == 320) RF_STEM(10) else if (d->C == 128) RF_STEM(4) else RF_STEM(2)
+#undef RF_STEM_
 #undef RF_STEM
     RF_LAUNCH_CHECK("rf_conv3x3_stem");
     return 0;

@@ -216,7 +216,8 @@ class LatentDiffusion(nn.Module, _DeviceMixin):
         yield None                                   # use_ema is False on this path (ddpm.py:309-322)
 
     def set_compute_dtype(self, dtype, encoders=False):
-        """Storage/MFMA dtype of the UNet (torch.float32 = exact-fp32 parity mode, torch.bfloat16 = throughput mode).
+        """Storage/MFMA dtype of the UNet (torch.float32 = exact-fp32 parity mode, torch.bfloat16 = throughput mode, torch.float16 = the throughput
+        mode's kernels on fp16 operands).
         ``encoders=True`` also switches the CLIP ViT-L/14 / ArcFace towers and the VAE *encoder* (conditioning stage 4x faster; the
         conditioning vector and the inpaint latent then deviate ~1 % from fp32 -- throughput mode only; the VAE decode stays fp32)."""
         self.model.diffusion_model.set_compute_dtype(dtype)
@@ -225,6 +226,8 @@ class LatentDiffusion(nn.Module, _DeviceMixin):
             dtype = torch.bfloat16
         elif dtype == "f32x3":             # split-bf16 UNet operands (fast parity mode): everything around it stays fp32
             dtype = torch.float32
+        elif dtype == torch.float16:       # fp16 is a UNet mode (csrc/encoder.hip is bf16 / fp32): 16-bit towers / VAE encoder, if asked for, are bf16
+            dtype = torch.bfloat16
         if encoders:
             for m in (getattr(self, "cond_stage_model", None), getattr(getattr(self, "face_ID_model", None), "facenet", None)):
                 if m is not None and hasattr(m, "compute_dtype"):

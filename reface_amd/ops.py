@@ -2,7 +2,7 @@
 
 PyTorch is used for device memory and the current HIP stream only; every arithmetic op of the
 hot path is a HIP kernel from libreface_hip.so.  Activations are channels-last torch tensors
-([B, H, W, C] or [M, C]) in fp32 or bf16; biases / norm affine parameters stay fp32.
+([B, H, W, C] or [M, C]) in fp32, bf16 or fp16 (H16: the two 16-bit storage types run the same kernels); biases / norm affine parameters stay fp32.
 """
 import ctypes as C
 import threading
@@ -10,7 +10,7 @@ import threading
 import torch
 
 from . import _lib
-from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_PRELU, ACT_QUICK_GELU, ACT_RELU, ACT_SIGMOID, ACT_SILU, RF_BF16, RF_BF16X3, RF_F32,
+from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_PRELU, ACT_QUICK_GELU, ACT_RELU, ACT_SIGMOID, ACT_SILU, RF_BF16, RF_BF16X3, RF_F16, RF_F32,
                    RF_FP8_E4M3, ConvGemmDesc, FfnDesc, StemDesc)
 
 # Attention scores in the exp2 domain: the UNet folds d^-0.5 * log2(e) into the to_q weights and calls rf_attention with scale = ln 2
@@ -24,7 +24,12 @@ def code(dt):
         return RF_F32
     if dt == torch.bfloat16:
         return RF_BF16
+    if dt == torch.float16:
+        return RF_F16
     raise TypeError(f"unsupported dtype {dt}")
+
+
+H16 = (torch.bfloat16, torch.float16)
 
 
 def vec(dt):
@@ -137,9 +142,11 @@ def ffn_geglu(x, w1p, b1p, w2q, b2, out, *, residual=None, ln_eps=0.0, name="ffn
     lib = _lib.load()
     _require_gpu(x, w1p, b1p, w2q, b2, out, residual)
     M, Cc = x.shape
-    assert x.dtype == w1p.dtype == w2q.dtype == out.dtype == torch.bfloat16 and b1p.dtype == b2.dtype == torch.float32
+    assert x.dtype == w1p.dtype == w2q.dtype == out.dtype and x.dtype in H16 and b1p.dtype == b2.dtype == torch.float32
     assert w1p.shape == (8 * Cc, Cc) and w2q.shape == (Cc, 4 * Cc) and w1p.is_contiguous() and w2q.is_contiguous()
     assert x.stride(1) == 1 and out.stride(1) == 1 and (residual is None or (residual.stride(1) == 1 and residual.dtype == out.dtype))
+    if x.dtype == torch.float16:          # the positional entry point is bf16; fp16 goes through the descriptor form with no projection behind it
+        return ffn_block(x, w1p, b1p, w2q, b2, out, residual=residual, wpo=None, bpo=None, res2=None, ln_eps=ln_eps, name=name)
     return Launch(lib.rf_ffn_geglu, (_p(x), x.stride(0), _p(w1p), _p(b1p), _p(w2q), _p(b2), _p(residual),
                                      residual.stride(0) if residual is not None else 0, _p(out), out.stride(0), M, Cc, float(ln_eps)),
                   (x, w1p, b1p, w2q, b2, out, residual), name)
@@ -152,8 +159,9 @@ def ffn_block(x, w1p, b1p, w2q, b2, out, *, residual, wpo, bpo, res2, res2_rows=
     lib = _lib.load()
     _require_gpu(x, w1p, b1p, w2q, b2, out, residual, wpo, bpo, res2)
     M, Cc = x.shape
-    assert x.dtype == w1p.dtype == w2q.dtype == out.dtype == wpo.dtype == torch.bfloat16 and b1p.dtype == b2.dtype == bpo.dtype == torch.float32
-    assert w1p.shape == (8 * Cc, Cc) and w2q.shape == (Cc, 4 * Cc) and wpo.shape == (Cc, Cc) and w1p.is_contiguous() and w2q.is_contiguous() and wpo.is_contiguous()
+    assert x.dtype == w1p.dtype == w2q.dtype == out.dtype and x.dtype in H16 and b1p.dtype == b2.dtype == torch.float32
+    assert wpo is None or (wpo.dtype == x.dtype and bpo.dtype == torch.float32 and wpo.shape == (Cc, Cc) and wpo.is_contiguous())
+    assert w1p.shape == (8 * Cc, Cc) and w2q.shape == (Cc, 4 * Cc) and w1p.is_contiguous() and w2q.is_contiguous()
     assert x.stride(1) == 1 and out.stride(1) == 1 and out.shape == (M, Cc)
     assert residual is None or (residual.stride(1) == 1 and residual.dtype == out.dtype and residual.shape == (M, Cc))
     assert res2 is None or (res2.stride(1) == 1 and res2.dtype == out.dtype and res2.shape == ((res2_rows or M), Cc))
@@ -163,6 +171,7 @@ def ffn_block(x, w1p, b1p, w2q, b2, out, *, residual, wpo, bpo, res2, res2_rows=
     d.out, d.ldo, d.M, d.C, d.ln_eps = _p(out), out.stride(0), M, Cc, float(ln_eps)
     d.wpo, d.bpo = _p(wpo), _p(bpo)
     d.res2, d.ldr2, d.res2_rows = _p(res2), (res2.stride(0) if res2 is not None else 0), int(res2_rows)
+    d.dtype = code(x.dtype)
     return Launch(lib.rf_ffn_block, (C.byref(d),), (d, x, w1p, b1p, w2q, b2, out, residual, wpo, bpo, res2), name)
 
 
@@ -447,13 +456,13 @@ def gn_silu_conv3x3_small(x, gamma, beta, partial, nchunks, W, bias, out, *, eps
     B, H, W_, Cc = x.shape
     No = W.shape[0]
     _require_gpu(x, gamma, beta, partial, W, bias, out)
-    assert x.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and W.shape[1] == 9 * Cc and x.stride(3) == 1 and out.stride(3) == 1 and out.shape[:3] == x.shape[:3]
+    assert x.dtype in H16 and W.dtype == x.dtype and out.dtype in (torch.float32, x.dtype) and W.shape[1] == 9 * Cc and x.stride(3) == 1 and out.stride(3) == 1 and out.shape[:3] == x.shape[:3]
     assert Cc in SMALLCONV_CHANNELS and 1 <= No <= 4 and partial.dtype == torch.float64
     assert x.stride(0) == H * W_ * x.stride(2) and x.stride(1) == W_ * x.stride(2) and out.stride(0) == H * W_ * out.stride(2) and out.stride(1) == W_ * out.stride(2)
     if workspace is None:
         workspace = torch.empty((B * H * W_ * 40,), dtype=torch.float32, device=x.device)
     assert workspace.dtype == torch.float32 and workspace.numel() >= B * H * W_ * 40
-    return Launch(lib.rf_gn_silu_conv3x3_small, (_p(x), B, H, W_, Cc, x.stride(2), nchunks, _p(partial), _p(gamma), _p(beta), float(eps), int(bool(silu)), _p(W), _p(bias),
+    return Launch(lib.rf_gn_silu_conv3x3_small, (code(x.dtype), _p(x), B, H, W_, Cc, x.stride(2), nchunks, _p(partial), _p(gamma), _p(beta), float(eps), int(bool(silu)), _p(W), _p(bias),
                                                  No, code(out.dtype), _p(out), out.stride(2), _p(workspace), workspace.numel() * 4),
                   (x, gamma, beta, partial, W, bias, out, workspace), name)
 
@@ -467,7 +476,7 @@ def conv3x3_stem(x, W, bias, out, *, dup=None, name="conv_in"):
     _require_gpu(x, W, bias, out, dup)
     B, H, W_, Ci = x.shape
     Cc = W.shape[0]
-    assert x.dtype == W.dtype == out.dtype == torch.bfloat16 and (bias is None or bias.dtype == torch.float32)
+    assert x.dtype == W.dtype == out.dtype and x.dtype in H16 and (bias is None or bias.dtype == torch.float32)
     assert Ci >= 16 and W.shape == (Cc, 144) and W.is_contiguous() and Cc in SMALLCONV_CHANNELS and (H * W_) % 128 == 0 and out.shape == (B, H, W_, Cc)
     for t in (x, out) + ((dup,) if dup is not None else ()):
         assert t.stride(3) == 1 and t.stride(1) == W_ * t.stride(2) and t.stride(0) == H * W_ * t.stride(2)
@@ -480,6 +489,7 @@ def conv3x3_stem(x, W, bias, out, *, dup=None, name="conv_in"):
         off = dup.data_ptr() - out.data_ptr()
         assert off > 0 and off % 16 == 0
         d.dup_off = off // 2
+    d.dtype = code(x.dtype)
     return Launch(lib.rf_conv3x3_stem, (C.byref(d),), (d, x, W, bias, out, dup), name)
 
 
@@ -566,12 +576,16 @@ def gemm_plan(launch):
 
 
 def gemm_plan2(launch):
-    """The whole tile plan of a prepared rf_conv_gemm launch: dict(stat_rows, stat_cols, splitk, bm, bn, wave_cols, direct, frag); raises
+    """The whole tile plan of a prepared rf_conv_gemm launch: dict(stat_rows, stat_cols, splitk, bm, bn, wave_cols, direct, frag, gemm_kernels); raises
     RefaceHipError when the library rejects the descriptor (e.g. LayerNorm folding asked of a launch that cannot carry it)."""
     lib = _lib.load()
     info = (C.c_int32 * 8)()
     _lib.check(lib.rf_conv_gemm_plan2(C.byref(launch.keep[0]), info), launch.name + ".plan2")
-    return dict(zip(("stat_rows", "stat_cols", "splitk", "bm", "bn", "wave_cols", "direct", "frag"), (int(v) for v in info)))
+    pl = dict(zip(("stat_rows", "stat_cols", "splitk", "bm", "bn", "wave_cols", "direct", "frag"), (int(v) for v in info)))
+    # eighth word: bit 0 = split-K through fragment-ordered slabs, bit 1 = the call runs as TWO GEMM kernels (tail-round split along N)
+    pl["gemm_kernels"] = 2 if pl["frag"] & 2 else 1
+    pl["frag"] &= 1
+    return pl
 
 
 def fold_layernorm_linear(w, gamma, beta, bias, dtype):

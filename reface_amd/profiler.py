@@ -20,6 +20,8 @@ def launch_family(l):
             return "rf_conv_gemm[fp8w]"          # fp8 (e4m3fn) weights x bf16 activations on the bf16 MFMA
         if d.dtype == 3:
             return "rf_conv_gemm[bf16x3]"        # split-bf16 operand pairs, three bf16 MFMA passes per product, fp32 accumulate / output
+        if d.dtype == 4:
+            return "rf_conv_gemm[f16]"           # fp16 operands on v_mfma_f32_32x32x16_f16 (the bf16 kernels' geometry and rate)
         return f"rf_conv_gemm[{'bf16' if d.dtype == 1 else 'f32'}]"
     if n == "rf_ffn_block":
         return "rf_ffn_geglu"          # (one family with the plain fused feed-forward: the same kernel)

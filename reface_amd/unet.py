@@ -33,6 +33,7 @@ from .modules import ParamTree, flat_state, weights_version
 from .params import UNetConfig, unet_param_specs, unet_plan
 
 F32 = torch.float32
+H16 = (torch.bfloat16, torch.float16)          # the 16-bit storage modes: the same kernels (element type bf16_t / f16_t) and the same fused paths
 
 
 class _Pool:
@@ -103,7 +104,7 @@ class UNetEngine:
         # GroupNorm statistics come out of the epilogue of the GEMM that produced the tensor wherever its tile plan allows
         self.gn_fuse = os.environ.get("REFACE_GN_FUSE", "1") == "1"
         # GEGLU + ff.net.2 of the C = 320 blocks as ONE kernel (csrc/ffn.hip): 213 us against 150 + 80 for the pair inside the step -- the pair's
-        # epilogues are store-bound and ff.net.2's residual segments cost ~20 us; -0.4 % per batch, same box (tools/exp_r03_17.sh).  =0: the pair
+        # epilogues are store-bound and ff.net.2's residual segments cost ~20 us; -0.4 % per batch, same box (tools/archive/exp_r03_17.sh).  =0: the pair
         self.ffn_fuse = os.environ.get("REFACE_FFN_FUSE", "1") == "1"
         self.ffn_whole = float(os.environ.get("REFACE_FFN_WHOLE", "0.9"))          # least fill of the fused kernel's last round of 128-token blocks
         # norm3 inside the fused feed-forward kernel (C = 320 blocks): REFACE_LN_FOLD=0 keeps the separate LayerNorm pass
@@ -117,6 +118,10 @@ class UNetEngine:
         # proj_out fused behind the feed-forward kernel of the C = 320 blocks (rf_ffn_block): REFACE_TAIL_FUSE=0 keeps the separate proj_out launches
         self.tail_fuse = os.environ.get("REFACE_TAIL_FUSE", "1") == "1"
         self.n_tail_fused = 0
+        # proj_out folded into ff.net.2 where the token-resident kernel does not reach (C = 640 / 1280, and C = 320 at sizes that kernel declines; 16-bit
+        # modes): one GEMM over K = 5 C on premultiplied weights instead of two launches and a round trip of [M, C] (_st): REFACE_PO_FOLD=0 keeps the pair
+        self.po_fold = os.environ.get("REFACE_PO_FOLD", "1") == "1"
+        self.n_po_folded = 0
         self.out_fuse = os.environ.get("REFACE_OUT_FUSE", "1") == "1"          # `out` head (GroupNorm + SiLU + 3x3 conv to 4 channels) as one pass (csrc/smallconv.hip)
         # the stem (3x3 conv from the 9 stored-in-16 input channels) as a pixels-on-lanes kernel that computes the CFG-duplicated half once and emits
         # the statistics of both its GroupNorm consumers (csrc/smallconv.hip): REFACE_STEM_FUSE=0 keeps the implicit GEMM + the statistics pass
@@ -132,6 +137,7 @@ class UNetEngine:
         self.n_cu = torch.cuda.get_device_properties(device).multi_processor_count if torch.cuda.is_available() else 256
         self.gn_fused = 0
         self.pool = _Pool(device)
+        self._wpack = {}
         self.tracker = ProducerTracker()
         self.pool.on_put = self.tracker.forget
         self.sd = {k: v.detach().to(device=device, dtype=F32) for k, v in sd.items()}
@@ -149,6 +155,7 @@ class UNetEngine:
             self.main = []
             self._build_main()
         self.sd = None      # packed copies are held by the launches
+        self._wpack = None
 
     # ------------------------------------------------------------------ weights
     def w(self, key, dtype=None):
@@ -296,20 +303,29 @@ class UNetEngine:
             self.n_x3 += 1
             return ops.conv2d(x, ops.pack_x3(ops.pack_conv_weight(self.sd[wkey], F32)), out, self.f32(bkey), x3=True, name=name, **kw)
         ko = ops.conv_korder(cin, self.dt) if self.korder_on else 0
-        if (self.hx_on and self.dt == torch.bfloat16 and not self.w8 and not ko and cin % 64 == 0 and kw.get("stride", 1) == 1 and not kw.get("ups", 0)
+        if (self.hx_on and self.dt in H16 and not self.w8 and not ko and cin % 64 == 0 and kw.get("stride", 1) == 1 and not kw.get("ups", 0)
                 and x.shape[1:3] == out.shape[1:3]):
             # 3x3 stride-1 convolution: K order (filter row, channel chunk, filter column) -- one row-extended A tile serves the three horizontal
             # taps (a third of the A-operand fill, gemm.hip HX).  Whether the launch's tile can take it (whole image rows per tile) is the
             # library's answer: ask for the plan, fall back to the tap-major order otherwise.
-            cand = ops.conv2d(x, ops.pack_conv_weight(self.sd[wkey], self.dt, korder=2), out, self.f32(bkey), korder=2, name=name, **kw)
+            cand = ops.conv2d(x, self._packed(wkey, "hx", lambda: ops.pack_conv_weight(self.sd[wkey], self.dt, korder=2)), out, self.f32(bkey), korder=2, name=name, **kw)
             try:
                 ops.gemm_plan2(cand)
                 self.n_hx += 1
                 return cand
             except Exception:
                 pass
-        wp = ops.pack_conv_weight(self.sd[wkey], F32, korder=ko)
-        return ops.conv2d(x, wp.to(self.dt) if ko else self.gw(wp, cin), out, self.f32(bkey), korder=ko, name=name, **kw)
+        def pack():
+            wp = ops.pack_conv_weight(self.sd[wkey], F32, korder=ko)
+            return wp.to(self.dt) if ko else self.gw(wp, cin)
+        return ops.conv2d(x, self._packed(wkey, ("tap", ko), pack), out, self.f32(bkey), korder=ko, name=name, **kw)
+
+    def _packed(self, wkey, kind, make):
+        """One packed device copy per (weight, packing): a convolution launched in two sample slices (_add_conv3) shares it."""
+        w = self._wpack.get((wkey, kind))
+        if w is None:
+            w = self._wpack[(wkey, kind)] = make()
+        return w
 
     def _add_conv3(self, x, wkey, out, bkey, name, rowvec=None, residual=None, **kw):
         """_conv3 + _add, with the launch split BY SAMPLES when its 256-row tiles overhang a whole number of rounds of the chip by a little
@@ -317,7 +333,7 @@ class UNetEngine:
         the first k samples fill whole rounds of big tiles, the rest is a launch of its own (its plan: smaller tiles / split-K).
         `tools/conv_split_probe.py`: 96x96, 320 / 640 / 960 -> 320: 154 -> 135, 283 -> 236, 405 -> 338 us.  REFACE_SAMPLE_SPLIT=0: off."""
         B, k = x.shape[0], 0
-        if (self.sample_split and isinstance(x, torch.Tensor) and not isinstance(out, ops.Fp8Act) and self.dt == torch.bfloat16 and not self.x3 and not self.w8
+        if (self.sample_split and isinstance(x, torch.Tensor) and not isinstance(out, ops.Fp8Act) and self.dt in H16 and not self.x3 and not self.w8
                 and kw.get("stride", 1) == 1):
             HWo, N = out.shape[1] * out.shape[2], out.shape[3]
             tn = (N + 319) // 320
@@ -431,7 +447,7 @@ class UNetEngine:
         tok = self.pool.get((M, c), self.dt)
         w_pi = self.sd[f"{p}.proj_in.weight"].reshape(c, c)
         l_pi = None
-        if self.gn_fold_lin and self.dt == torch.bfloat16 and not a8 and not self.w8 and c <= self.gn_fold_maxc and x.is_contiguous() and (H * W) % 256 == 0:
+        if self.gn_fold_lin and self.dt in H16 and not a8 and not self.w8 and c <= self.gn_fold_maxc and x.is_contiguous() and (H * W) % 256 == 0:
             # `norm` folded into proj_in (bf16 mode, C <= 640: B x C x C folded weights cost less than the pass they replace): the statistics of x
             # scale W's columns per sample, proj_in multiplies the UN-normalised x, the mean / beta terms ride in its per-sample vector
             part, nch = self._gn_stats(x)
@@ -457,7 +473,7 @@ class UNetEngine:
         # UN-normalised tokens and applies  rstd (acc - mean u) + W beta  in its epilogue; gamma rides in the weights' columns -- the
         # rf_layernorm pass (one read + one write of [M, C]) and its launch are gone
         l_qkv = None
-        if self.ln_fold_gemm and self.dt == torch.bfloat16 and not self.w8:
+        if self.ln_fold_gemm and self.dt in H16 and not self.w8:
             w2, u2, b2 = ops.fold_layernorm_linear(wqkv, self.sd[f"{t}.norm1.weight"], self.sd[f"{t}.norm1.bias"], None, self.dt)
             cand = ops.linear(tok, w2, qkv, b2, ln_u=u2, name=f"{t}.attn1.qkv")
             if ops.layernorm_fold([(l_pi, 0, M)], cand, eps=1e-5, C_=c) is not None:
@@ -474,7 +490,20 @@ class UNetEngine:
         q3 = qkv.view(B, H * W, 3 * c)
         self.main.append(ops.attention(q3[..., :c], q3[..., c:2 * c], q3[..., 2 * c:], att.view(B, H * W, c), heads=heads,
                                        scale=ops.LN2, name=f"{t}.attn1"))
-        x1 = self.pool.get((nb * M, c), self.dt)
+        # (one block of the fused feed-forward kernel per 128 tokens and CU: only where those blocks come in nearly whole rounds -- 576 blocks at configs[3]
+        #  are 2.25 rounds of 256 CUs and lose 0.5 % per batch against the pair, tools/archive/exp_r03_20.sh)
+        nblk = (nb * M + 127) // 128
+        whole = nblk / (self.n_cu * ((nblk + self.n_cu - 1) // self.n_cu))
+        fused_ffn = self.ffn_fuse and c == 320 and self.dt in H16 and not self.w8 and whole >= self.ffn_whole
+        # proj_out folded into ff.net.2 (attention.py:243, 268-272, 288-289; exact in real arithmetic):
+        #     y = Wpo (W2 h + b2 + x1) + bpo + x_in  =  [h | x1] [Wpo W2 | Wpo]^T + (Wpo b2 + bpo) + x_in
+        # one GEMM over K = 5 C whose A operand is ONE buffer [M, 5 C]: the GEGLU projection writes h into columns [0, 4 C), the attention's out-projection
+        # writes x1 into columns [4 C, 5 C) (strided outputs, as the decoder's [h | skip] concat) -- a single source keeps the direct-to-LDS main loop.  The
+        # product Wpo W2 is formed in fp32 and rounded ONCE to the operand type; x2 = ff(x1) + x1 is never rounded to 16 bits, never written, never re-read:
+        # a launch and a round trip of [M, C] per block fewer (11 blocks at 512x512).
+        po_fold = self.po_fold and nb == 1 and self.dt in H16 and not self.w8 and not a8 and not fused_ffn and c % 64 == 0
+        cat5 = self.pool.get((M, 5 * c), self.dt) if po_fold else None
+        x1 = cat5[:, 4 * c:] if po_fold else self.pool.get((nb * M, c), self.dt)
         # attn1 out-projection + residual + the (token-independent) cross-attention output; with pair=True one launch per CFG
         # half: same A and residual, that half's context vectors
         w_out, b_out, cv = self.gw(self.sd[f"{t}.attn1.to_out.0.weight"]), self.f32(f"{t}.attn1.to_out.0.bias"), self.ctx_vec(p)
@@ -488,11 +517,6 @@ class UNetEngine:
         if pair or a8:
             self.pool.put(ln)
             ln = self.aget((nb * M, c)) if a8 else self.pool.get((nb * M, c), self.dt)
-        # (one block of the fused kernel per 128 tokens and CU: only where those blocks come in nearly whole rounds -- 576 blocks at configs[3]
-        #  are 2.25 rounds of 256 CUs and lose 0.5 % per batch against the pair, tools/exp_r03_20.sh)
-        nblk = (nb * M + 127) // 128
-        whole = nblk / (self.n_cu * ((nblk + self.n_cu - 1) // self.n_cu))
-        fused_ffn = self.ffn_fuse and c == 320 and self.dt == torch.bfloat16 and not self.w8 and whole >= self.ffn_whole
         fold = fused_ffn and self.ln_fold
         w1s, b1s = self.sd[f"{t}.ff.net.0.proj.weight"], self.sd[f"{t}.ff.net.0.proj.bias"]
         if fold:
@@ -502,22 +526,36 @@ class UNetEngine:
             w1s, b1s = ops.fold_layernorm_geglu(w1s, b1s, self.sd[f"{t}.norm3.weight"], self.sd[f"{t}.norm3.bias"])
             self.n_ln_folded += 1
         l_geglu_f = None
-        if not fold and self.ln_fold_gemm and self.dt == torch.bfloat16 and not self.w8:
+        if not fold and self.ln_fold_gemm and self.dt in H16 and not self.w8:
             # norm3 of the unfused feed-forward (C = 640 / 1280, and C = 320 where the fused kernel is not taken): the statistics come from the
             # to_out launch(es) that wrote x1, the GEGLU GEMM reads x1 itself and normalises in its epilogue
             wgp, bgp = ops.pack_geglu(w1s, b1s, F32)          # (the fold is per input column: it commutes with the row packing)
             w2, u2, b2 = ops.fold_layernorm_linear(wgp, self.sd[f"{t}.norm3.weight"], self.sd[f"{t}.norm3.bias"], None, self.dt)
             b2 = (b2 + bgp).contiguous()
-            ggc = self.pool.get((nb * M, 4 * c), self.dt)
+            ggc = cat5[:, :4 * c] if po_fold else self.pool.get((nb * M, 4 * c), self.dt)
             cand = ops.linear(x1, w2, ggc, b2, act=ops.ACT_GEGLU, ln_u=u2, name=f"{t}.ff.net.0")
             if ops.layernorm_fold([(l, hf * M, M) for hf, l in enumerate(l_out)], cand, eps=1e-5, C_=c) is not None:
                 l_geglu_f = (cand, ggc)
                 self.n_ln_folded += 1
-            else:
+            elif not po_fold:
                 self.pool.put(ggc)
         if not fold and l_geglu_f is None:
             self.main.append(ops.layernorm(x1, self.f32(f"{t}.norm3.weight"), self.f32(f"{t}.norm3.bias"), ln, name=f"{t}.norm3"))
         wg, bg = ops.pack_geglu(w1s, b1s, F32)
+        if po_fold:
+            if l_geglu_f is not None:
+                self.main.append(l_geglu_f[0])
+            else:          # (norm3 ran as its own pass into `ln`)
+                self.main.append(ops.linear(ln, self.gw(wg), cat5[:, :4 * c], bg, act=ops.ACT_GEGLU, name=f"{t}.ff.net.0"))
+            wpo32, w232 = self.sd[f"{p}.proj_out.weight"].reshape(c, c).float(), self.sd[f"{t}.ff.net.2.weight"].float()
+            wf = torch.cat([wpo32 @ w232, wpo32], dim=1).contiguous()
+            bf = (wpo32 @ self.sd[f"{t}.ff.net.2.bias"].float() + self.sd[f"{p}.proj_out.bias"].float()).contiguous()
+            y = dst if dst is not None else self.pool.get((B, H, W, c), self.dt)
+            self._add(ops.conv2d(cat5.view(B, H, W, 5 * c), self.gw(wf), y, bf, ksize=1, pad=(0, 0), residual=x, name=f"{t}.ff.net.2+proj_out"), y)
+            self.pool.put(ln)
+            self.pool.put(cat5)
+            self.n_po_folded += 1
+            return y
         if l_geglu_f is not None:
             l_g, gg = l_geglu_f
             self.main.append(l_g)
@@ -639,7 +677,7 @@ class UNetEngine:
         """input_blocks.0.0 (openaimodel.py:666-671) as rf_conv3x3_stem when the shapes allow; with cfg_pair the second batch half of x is a copy of
         the first (the same latent under both conditionings): it is computed once and stored twice.  -> True when the launch was appended."""
         B, H, W, ci = x.shape
-        if not (self.stem_fuse and self.dt == torch.bfloat16 and not self.x3 and dst is not None and ci == self.CPAD == 16 and
+        if not (self.stem_fuse and self.dt in H16 and not self.x3 and dst is not None and ci == self.CPAD == 16 and
                 cout in ops.SMALLCONV_CHANNELS and (H * W) % 128 == 0 and p == "input_blocks.0.0"):
             return False
         w = ops.pack_conv_weight(self.sd[f"{p}.weight"], self.dt, cin_pad=self.CPAD)
@@ -748,7 +786,7 @@ class UNetEngine:
                 dst = None
             final = self._block(f"output_blocks.{i}", layers, cats[i], dst)
         c_fin = final.shape[3]
-        if (self.out_fuse and self.dt == torch.bfloat16 and not self.x3 and final.dtype == torch.bfloat16 and c_fin in ops.SMALLCONV_CHANNELS and
+        if (self.out_fuse and self.dt in H16 and not self.x3 and final.dtype == self.dt and c_fin in ops.SMALLCONV_CHANNELS and
                 self.sd["out.2.weight"].shape[0] <= 4 and final.is_contiguous()):
             # `out` = GroupNorm + SiLU + 3x3 conv to 4 channels: one pass over the raw tensor (csrc/smallconv.hip) instead of the normalisation pass
             # (a write + a read of the tensor) and an implicit GEMM that stages it nine times for a tile that is 94 % padding
@@ -821,10 +859,12 @@ class UNetModel(nn.Module):
         self._engines = {}
 
     def set_compute_dtype(self, dtype):
-        """torch.float32 (exact-fp32 parity mode) | torch.bfloat16 (throughput mode) | "fp8" (BASELINE configs[4]: fp8 e4m3fn GEMM weights
+        """torch.float32 (exact-fp32 parity mode) | torch.bfloat16 (throughput mode) | torch.float16 (the throughput mode's kernels on fp16 storage and
+        v_mfma_f32_32x32x16_f16: same rate, 11 significant bits instead of 8 -- the mode that brings the 50-step image closest to the exact-fp32 one at
+        full speed; activations of a checkpoint must stay inside fp16's range, tools/act_range.py) | "fp8" (BASELINE configs[4]: fp8 e4m3fn GEMM weights
         everywhere + fp8 activations with E8M0 block scales into the ResBlock convs / proj_in / qkv / GEGLU on the fp8 MFMA) | "fp8w" (fp8
         weights, bf16 activations, bf16 MFMA)."""
-        if dtype not in (torch.float32, torch.bfloat16, "fp8", "fp8w", "fp8c", "f32x3"):
+        if dtype not in (torch.float32, torch.bfloat16, torch.float16, "fp8", "fp8w", "fp8c", "f32x3"):
             raise ValueError(f"unsupported UNet compute dtype {dtype!r}")
         self.compute_dtype = dtype
         self._engines.clear()

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r04d
-bash tools/exp_r04_1.sh > gpurun_out/r04d/exp1_afill.log 2>&1
+bash tools/archive/exp_r04_1.sh > gpurun_out/r04d/exp1_afill.log 2>&1
 cat gpurun_out/r04d/exp1_afill.log
 timeout 600 python -m pytest tests/test_ops_gpu.py -q -k "layernorm_folded" -rA 2>&1 | tail -40 > gpurun_out/r04d/pytest_ln.log
 tail -5 gpurun_out/r04d/pytest_ln.log

@@ -1,5 +1,5 @@
 #!/bin/bash
-# r05m: the round's evidence on the FINAL library, one call per part (tools/run_r05m.sh a|b|c)
+# r05m: the round's evidence on the FINAL library, one call per part (tools/archive/run_r05m.sh a|b|c)
 part=$1
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 T=${T:-r05m}

@@ -41,14 +41,8 @@ def collect(args):
             d = l.keep[0]
             pl = ops.gemm_plan2(l)
             r.update(M=d.M, N=d.N, K=d.K, KH=d.KH, C0=d.C0, act=d.act, splitk=pl["splitk"], bm=pl["bm"], bn=pl["bn"], res=bool(d.residual))
-            r["kernels"] = 2 if pl["splitk"] > 1 else 1
-            # the tail-round split of gemm.hip's dispatcher (256-wide tiles, last round 20-60 % full): two GEMM kernels behind one call
-            if d.act == 1 and pl["splitk"] == 1 and pl["bn"] == 256 and d.N % 256 == 0 and not d.gn_part0 and not d.ln_stats_out:
-                mt256, mt128, nt = (d.M + 255) // 256, (d.M + 127) // 128, d.N // 256
-                tiles = mt256 * nt
-                full, rem = tiles // 256, tiles % 256
-                if full >= 1 and 256 <= rem * 5 <= 768 and (full * 256) % mt256 == 0 and mt128 * (nt - full * 256 // mt256) >= 192:
-                    r["kernels"] = 2
+            # (split-K: GEMM + reduce pass; tail-round split along N: two GEMM kernels behind one call -- the library's plan says which)
+            r["kernels"] = (2 if pl["splitk"] > 1 else 1) + (pl["gemm_kernels"] - 1)
         elif l.fn.__name__ == "rf_gn_silu_conv3x3_small":
             r["kernels"] = 2
         rows.append(r)
