@@ -649,10 +649,13 @@ def main():
             log(f"   dec {k:24s} calls {v['calls']:4d}  {v['ms']:9.3f} ms  {v['tflops_per_s']:8.1f} TFLOP/s")
         if args.profile_json:
             def row(l, ms):
-                r = {"name": l.name, "family": profiler.launch_family(l), "ms": ms, "flop": profiler.gemm_flops(l) + profiler.attention_flops(l) + profiler.ffn_flops(l)}
+                r = {"name": l.name, "family": profiler.launch_family(l), "ms": ms, "flop": profiler.gemm_flops(l) + profiler.attention_flops(l) + profiler.ffn_flops(l),
+                     "bytes": profiler.launch_bytes(l)}
                 if l.fn.__name__ == "rf_conv_gemm":
                     d = l.keep[0]
-                    r.update(M=d.M, N=d.N, K=d.K, act=d.act, batch=d.batch)
+                    pl = ops.gemm_plan2(l)
+                    r.update(M=d.M, N=d.N, K=d.K, act=d.act, batch=d.batch, KH=d.KH, residual=bool(d.residual), splitk=pl["splitk"], bm=pl["bm"], bn=pl["bn"],
+                             gemm_kernels=pl["gemm_kernels"])
                 return r
             with open(args.profile_json, "w") as f:
                 json.dump({"families": fam, "vae_families": dfam, "step_launches": [row(l, ms) for l, ms in timed_l],

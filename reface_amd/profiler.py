@@ -58,6 +58,28 @@ def attention_flops(l):
     return 4.0 * B * heads * Nq * Nk * d
 
 
+def launch_bytes(l):
+    """Compulsory bytes of one launch: every distinct operand / output tensor it points at, counted once (a view counts its own elements -- a column slice
+    of a concat buffer, a batch half).  Not counted: the split-K scratch, the fp64 GroupNorm slots and LayerNorm records (tiny), anything a kernel re-reads
+    (filter taps, K slices): this is the floor a perfect kernel of the same operation would move through HBM."""
+    import torch
+    keep = list(l.keep)
+    if l.fn.__name__ == "rf_conv_gemm" and len(keep) > 9:
+        keep = keep[:9] + keep[10:]          # (index 9 = the engine's split-K workspace)
+    seen, total = set(), 0
+    for k in keep:
+        parts = [k]
+        if type(k).__name__ in ("Fp8Weight", "Fp8Act"):
+            parts = [k.q, k.scale]
+        for t in parts:
+            if isinstance(t, torch.Tensor) and t.is_cuda and t.dtype != torch.float64:
+                key = (t.data_ptr(), t.numel(), t.element_size())
+                if key not in seen:
+                    seen.add(key)
+                    total += t.numel() * t.element_size()
+    return total
+
+
 def time_launches(launches, reps=5, warmup=1):
     """Time every launch of a launch list (HIP events on the current torch stream, which is the stream the launches run on).
 

@@ -180,7 +180,7 @@ def test_unet_bf16_batch16_cfg_matches_oracle_rows(full_unet, dt, lim):
     print(f"c1 engine (CFG batch 16 @64x64, {dt}) vs oracle pair: rel L2 {rel:.5f}")
     assert torch.isfinite(out).all() and rel < lim, rel          # bf16: 1.0 % measured
     # fp16 runs the SAME launch list as bf16 (every fused path is open to both 16-bit types)
-    assert eng.n_tail_fused == 5 and eng.n_stem_fused == 1 and eng.n_hx >= 40 and eng.n_gn_folded == 10, (eng.n_tail_fused, eng.n_stem_fused, eng.n_hx, eng.n_gn_folded)
+    assert eng.n_tail_fused == 5 and eng.n_stem_fused == 1 and eng.n_hx >= 25 and eng.n_gn_folded == 10, (eng.n_tail_fused, eng.n_stem_fused, eng.n_hx, eng.n_gn_folded)
     # the plan really is the big-tile one
     tiles = set()
     for l in eng.main:
