@@ -651,6 +651,9 @@ def main():
             def row(l, ms):
                 r = {"name": l.name, "family": profiler.launch_family(l), "ms": ms, "flop": profiler.gemm_flops(l) + profiler.attention_flops(l) + profiler.ffn_flops(l),
                      "bytes": profiler.launch_bytes(l)}
+                if l.fn.__name__ == "rf_attention":
+                    a = l.args          # (dtype, q, k, v, out, B, heads, d, Nq, Nk, ...)
+                    r.update(heads_x_batch=a[5] * a[6], d=a[7], Nq=a[8], Nk=a[9], exps=float(a[5]) * a[6] * a[8] * a[9])
                 if l.fn.__name__ == "rf_conv_gemm":
                     d = l.keep[0]
                     pl = ops.gemm_plan2(l)

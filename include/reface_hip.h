@@ -143,7 +143,7 @@ int rf_conv_gemm_plan(const rf_conv_gemm_desc* d, int32_t* bm, int32_t* bn, int3
 int rf_conv_gemm_plan2(const rf_conv_gemm_desc* d, int32_t* info8);
 
 /* Fused transformer feed-forward at C = 320 (the 64x64 level):  out = (GEGLU(x W1^T + b1)) W2^T + b2 + residual, bf16 in / out, fp32
- * accumulate, GELU on the tanh form (the bf16 mode's).  The [M, 4C] hidden tensor stays in registers (tokens on lanes, see ffn.hip).
+ * accumulate, GELU on the 16-bit modes' sigmoid form (degree-5 argument, <= 2.6e-5 from the erf form: csrc/common.h).  The [M, 4C] hidden tensor stays in registers (tokens on lanes, see ffn.hip).
  *   w1p / b1p : ff.net.0.proj [8C, C] / [8C] with rows interleaved in blocks of 32 (value | gate), as rf_conv_gemm's GEGLU takes them
  *   w2q       : ff.net.2 [C, 4C] with the columns of every 16-group in the order 0-3, 8-11, 4-7, 12-15
  *   ln_eps > 0: every row of x is LayerNorm-ed first, in registers (two-pass fp32 statistics, normalised values rounded to bf16 as

@@ -266,14 +266,14 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // to <= 2.6e-5 over the reals (round 6; tools-free check: tests/test_ops_gpu.py::test_geglu_negative_gates pins the bound), a twentieth of an fp16 ulp.
 // The polynomial's x^4 term is negative: its argument is clamped to |x| <= 7, beyond which sigmoid(g) is 0 or 1 to eleven digits.  9 VALU operations
 // (two of them transcendental) against ~25 for the erf form, which the exact-fp32 mode keeps.
-__device__ __forceinline__ float gelu_tanh_fast(float x) {
+__device__ __forceinline__ float gelu_sigmoid5(float x) {
     const float xc = __builtin_fminf(__builtin_fmaxf(x, -7.0f), 7.0f);
     const float x2 = xc * xc;
     const float u = xc * __builtin_fmaf(__builtin_fmaf(-0.0010142630f, x2, 0.10677572f), x2, 2.3011212f);          // g(x) * log2(e)
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u));
 }
 template <typename T> __device__ __forceinline__ float gelu_for(float x) {
-    if constexpr (sizeof(T) == 2) return gelu_tanh_fast(x);
+    if constexpr (sizeof(T) == 2) return gelu_sigmoid5(x);
     else return gelu_erf(x);
 }
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + expf(-1.702f * x)); }

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * q4 + e;
-                        h[r] = (acc1[2 * pr][r] + bv[e]) * gelu_tanh_fast(acc1[2 * pr + 1][r] + bg[e]);
+                        h[r] = (acc1[2 * pr][r] + bv[e]) * gelu_sigmoid5(acc1[2 * pr + 1][r] + bg[e]);
                     }
                 }
 #pragma unroll

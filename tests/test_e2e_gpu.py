@@ -225,6 +225,28 @@ def test_cli_plms_start_from_target(tmp_path):
     assert sorted(os.listdir(out / "results")) == ["000000000000.png", "000000000001.png"]
 
 
+def test_cli_precision_fp16_close_to_full(tmp_path):
+    """--precision fp16 (round 6): the drop-in CLI with the UNet on fp16 operands (fp32 towers / VAE encoder, split-bf16 decode) against --precision full on
+    the same synthetic pairs: the saved results/<id>.png agree to a couple of grey levels (the bf16 mode is an order of magnitude further away)."""
+    import json
+    import numpy as np
+    from PIL import Image
+    imgs = {}
+    for prec in ("full", "fp16"):
+        out = tmp_path / prec
+        cmd = [sys.executable, os.path.join(ROOT, "scripts", "inference_test_bench.py"), "--outdir", str(out), "--config",
+               os.path.join(ROOT, "tests", "configs", "reface_small.yaml"), "--ckpt", "none", "--dataset", "synthetic", "--n_items", "2",
+               "--n_samples", "2", "--ddim_steps", "5", "--scale", "3.5", "--H", "256", "--W", "256", "--precision", prec,
+               "--clip_vision_config", json.dumps(SMALL_CLIP)]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        imgs[prec] = [np.asarray(Image.open(out / "results" / f)).astype(np.int32) for f in sorted(os.listdir(out / "results"))]
+    assert len(imgs["full"]) == len(imgs["fp16"]) == 2
+    d = max(int(np.abs(a - b).max()) for a, b in zip(imgs["full"], imgs["fp16"]))
+    print(f"--precision fp16 vs full, saved PNGs: max |d| = {d} grey levels")
+    assert d <= 3, d
+
+
 def test_cli_swap_selected(tmp_path):
     """the selected-swap caller (inference_swap_selected.py:516-762) on a prepared <Base_dir> tree: every source onto every
     target, the reference's per-source output folders."""

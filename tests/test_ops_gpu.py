@@ -1084,7 +1084,7 @@ def test_groupnorm_apply_split_output():
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_geglu_negative_gates(dt):
-    """The 16-bit GEGLU epilogues use the sigmoid-form GELU with a degree-5 argument (csrc/common.h gelu_tanh_fast: |form - gelu_erf| <= 2.6e-5
+    """The 16-bit GEGLU epilogues use the sigmoid-form GELU with a degree-5 argument (csrc/common.h gelu_sigmoid5: |form - gelu_erf| <= 2.6e-5
     absolute; the tanh form it replaced was 4.8e-4).  For negative gates gelu(g) is small, so the bound on the PRODUCT is absolute:
     |out - value * gelu_erf(gate)| <= 2.6e-5 * |value| + one ulp of the stored product.  Gates swept over [-8, 8] (beyond |7| the argument is clamped)."""
     M, Cc, Fh = 512, 64, 64

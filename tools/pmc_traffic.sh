@@ -11,6 +11,7 @@ python3 - <<PY
 import csv, glob, collections, json, re
 def fam(n):
     if "conv_gemm_kernel<unsigned char" in n: return "rf_conv_gemm[fp8]"          # fp8 activations x fp8 weights (MX-scaled MFMA)
+    if "conv_gemm_kernel<_Float16" in n: return "rf_conv_gemm[f16]"               # fp16 operands (the fp16 throughput mode)
     m = re.search(r"conv_gemm_kernel<(unsigned short|float), (unsigned short|float)", n)
     if m:
         if m.group(1) == "unsigned short" and m.group(2) == "float": return "rf_conv_gemm[bf16x3]"      # bf16 operands, fp32 out: the split-bf16 VAE convs (+ the UNet's 4-channel out conv)
