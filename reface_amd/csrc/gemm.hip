@@ -1977,7 +1977,10 @@ static int launch_cfg(const rf_conv_gemm_desc* d, GemmParams& p, bool conv, hipS
         // along N -- the pm A panels stay resident if they fit beside the patch's pn W panels, the W panels are streamed once per super-row.
         // (bf16 / fp32 operands only: the fp8 x fp8 and fp8-weight kernels of configs[4] LOSE 3 % per batch on the same rule -- half the operand bytes per tile, other
         //  tile shapes; profiles/r05r_r04_vs_r05_same_box.txt)
-        constexpr bool PATCH_T = !W8 && !std::is_same<T, fp8_t>::value;
+#ifndef RF_PATCH_FP8
+#define RF_PATCH_FP8 0          // (experiment builds: 1 applies the patch order to the fp8 / fp8-weight kernels too -- the A/B of profiles/r06f)
+#endif
+        constexpr bool PATCH_T = RF_PATCH_FP8 || (!W8 && !std::is_same<T, fp8_t>::value);
         if (PATCH_T && patch_on && p.splitk == 1 && WM * WN == 8 && tiles >= 2 * 256 && mf_env < 0) {
             const double conc = 32.0, cap = 3.0 * 1024 * 1024;          // tiles in flight per XCD; L2 bytes the operands may take (4 MB minus output lines)
             auto cost_of = [&](int h, int w) {
