@@ -211,6 +211,40 @@ def test_cli_flags_match_reference_surface():
     assert (d.ddim_steps, d.H, d.W, d.C, d.f, d.ddim_eta, d.seed, d.precision) == (50, 512, 512, 4, 8, 0.0, 42, "full")
 
 
+def test_fp16_mode_surface():
+    """The fp16 throughput mode end to end on the host side (no GPU): the C-ABI dtype code, the ctypes descriptors' `dtype` fields, the library's argument
+    checks (fp16 operands write fp16 or fp32, never mix with bf16), the UNet's compute-dtype switch and the CLI's --precision choice."""
+    import ctypes
+    from reface_amd import _lib, ops
+    from reface_amd.unet import UNetModel
+    hdr = open(os.path.join(ROOT, "include", "reface_hip.h")).read()
+    assert re.search(r"RF_F16\s*=\s*4", hdr) and _lib.RF_F16 == 4 and ops.code(torch.float16) == 4
+    assert [f for f, _ in _lib.FfnDesc._fields_][-1] == "dtype" and [f for f, _ in _lib.StemDesc._fields_][-1] == "dtype"
+    if os.path.exists(_lib.LIB_PATH):
+        lib = _lib.load()
+        assert lib.rf_version() >= 101
+        d = _lib.ConvGemmDesc()
+        d.dtype, d.out_dtype, d.M, d.N, d.K = _lib.RF_F16, _lib.RF_BF16, 128, 128, 64
+        assert lib.rf_conv_gemm(ctypes.byref(d), None) != 0 and b"fp16 operands write fp16 or fp32" in lib.rf_last_error()
+        d.dtype, d.out_dtype = _lib.RF_BF16, _lib.RF_F16
+        assert lib.rf_conv_gemm(ctypes.byref(d), None) != 0 and b"fp16 output needs fp16 operands" in lib.rf_last_error()
+        fd = _lib.FfnDesc()
+        fd.dtype = 7
+        assert lib.rf_ffn_block(ctypes.byref(fd), None) != 0
+        assert lib.rf_gn_silu_conv3x3_small(0, None, 1, 8, 8, 64, 64, 1, None, None, None, 1e-5, 1, None, None, 4, 0, None, 4, None, 0, None) != 0
+    m = UNetModel(in_channels=9, model_channels=64, out_channels=4, num_res_blocks=2, attention_resolutions=(4, 2, 1), channel_mult=(1, 2, 4, 4), num_heads=8,
+                  use_spatial_transformer=True, context_dim=768, legacy=False)
+    m.set_compute_dtype(torch.float16)
+    assert m.compute_dtype == torch.float16
+    with pytest.raises(ValueError):
+        m.set_compute_dtype(torch.float64)
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import importlib
+    for mod in ("inference_test_bench", "inference_swap_selected", "inference_swap_video"):
+        cli = importlib.import_module(mod)
+        assert cli.build_parser().parse_args(["--precision", "fp16"]).precision == "fp16"
+
+
 def test_synthetic_dataset_contract_and_sharding():
     from reface_amd.data import SyntheticPairs, shard_indices
     ds = SyntheticPairs(n=5, image_size=64, seed=3)

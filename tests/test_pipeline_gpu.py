@@ -168,6 +168,17 @@ def test_unet_small_bf16_close_to_fp32(golden_dir):
     assert rel < 0.08, rel          # bf16 storage + bf16 MFMA through ~60 layers: percent-level agreement
 
 
+def test_unet_small_fp16_close_to_fp32(golden_dir):
+    """The fp16 mode on the reduced-width UNet against the REFERENCE's output (golden): an eighth of the bf16 mode's bound (11 significant bits against 8)."""
+    g = G(golden_dir, "unet_small")
+    m = make_unet(SMALL_UNET, 7, torch.float16)
+    y = m(rnd((2, 9, 16, 16), 10).to(DEV), torch.from_numpy(g["t"]).to(DEV), context=rnd((2, 1, 768), 11).to(DEV))
+    ref = g["y"]
+    rel = maxerr(y, ref) / np.abs(ref).max()
+    print(f"small UNet fp16 vs the reference's golden output: max |d| / max |y| = {rel:.2e}")
+    assert rel < 0.01, rel
+
+
 class _LDMStub:
     """What DDIMSampler reads from the pipeline model (ddim.py:100,113-119,207,345)."""
 
