@@ -598,7 +598,9 @@ def main():
                             "transformer_tails_fused_ffn_proj_out": getattr(plan["eng"], "n_tail_fused", 0),
                             "out_head_fused_gn_silu_conv": int(any(getattr(l.fn, "__name__", "") == "rf_gn_silu_conv3x3_small" for l in plan["step"])),
                             "stem_conv_pixels_on_lanes": getattr(plan["eng"], "n_stem_fused", 0),
-                            "convs_split_by_samples": getattr(plan["eng"], "n_sample_split", 0)}
+                            "convs_split_by_samples": getattr(plan["eng"], "n_sample_split", 0),
+                            "proj_out_folded_into_ff_net_2": getattr(plan["eng"], "n_po_folded", 0),
+                            "transformer_fronts_fused_proj_in_norm1_qkv": getattr(plan["eng"], "n_front_fused", 0)}
         sk = [ops.gemm_plan2(l) for l in plan["step"] if getattr(l.fn, "__name__", "") == "rf_conv_gemm"]
         result["fusion"]["splitk_launches"] = sum(1 for q in sk if q["splitk"] > 1)
         timed_l = profiler.time_launches(plan["step"], reps=5)
@@ -649,7 +651,7 @@ def main():
             log(f"   dec {k:24s} calls {v['calls']:4d}  {v['ms']:9.3f} ms  {v['tflops_per_s']:8.1f} TFLOP/s")
         if args.profile_json:
             def row(l, ms):
-                r = {"name": l.name, "family": profiler.launch_family(l), "ms": ms, "flop": profiler.gemm_flops(l) + profiler.attention_flops(l) + profiler.ffn_flops(l),
+                r = {"name": l.name, "family": profiler.launch_family(l), "ms": ms, "flop": profiler.gemm_flops(l) + profiler.attention_flops(l) + profiler.ffn_flops(l) + profiler.attn_in_flops(l),
                      "bytes": profiler.launch_bytes(l)}
                 if l.fn.__name__ == "rf_attention":
                     a = l.args          # (dtype, q, k, v, out, B, heads, d, Nq, Nk, ...)

@@ -181,6 +181,28 @@ typedef struct rf_ffn_desc {
 } rf_ffn_desc;
 int rf_ffn_block(const rf_ffn_desc* d, void* stream);
 
+/* The token-resident FRONT of a SpatialTransformer block at C = 320 (attention.py:262-266 `norm`, 276-279 `proj_in`, 231-233 `norm1`, 239 + 159-170 to_q / to_k / to_v)
+ * in one kernel (round 6):
+ *   tok = x W'_s^T + r_s                 W'_s / r_s: proj_in with the GroupNorm folded in per sample (rf_groupnorm_fold_linear's w_out / rowvec_out)
+ *   qkv = LayerNorm(tok) Wqkv'^T + b'    LayerNorm without affine in registers (two-pass fp32 statistics of the STORED tok row, normalised values rounded to `dtype`);
+ *                                        the host folds norm1's gamma into wqkv's columns and Wqkv beta into bqkv
+ * x [M][ldx] un-normalised, tok [M][ldt] (written: the attention's out-projection reads it back as its residual), qkv [M][ldq] columns [0, 3C), all in `dtype`
+ * (RF_BF16, also 0, or RF_F16); wpi [S][C][C] with w_sample_stride elements between samples (0: one matrix), rowvec fp32 [S][ldv], rows_per_sample a multiple of 128
+ * dividing M; wqkv [3C][C], bqkv fp32 [3C].  Replaces two rf_conv_gemm launches whose K = 320 main loops are a quarter of their time, the re-read of tok and the
+ * LayerNorm statistics exchange between them. */
+typedef struct rf_attn_in_desc {
+    const void* x; int32_t ldx;
+    const void* wpi; int64_t w_sample_stride;
+    const float* rowvec; int32_t ldv, rows_per_sample;
+    void* tok; int32_t ldt;
+    const void* wqkv; const float* bqkv;
+    void* qkv; int32_t ldq;
+    int32_t M, C;
+    float ln_eps;
+    int32_t dtype;
+} rf_attn_in_desc;
+int rf_attn_in(const rf_attn_in_desc* d, void* stream);
+
 /* Per-row fp8 quantisation of a weight matrix for the w_dtype = RF_FP8_E4M3 path: w [N][K] fp32 (row pitch K) ->
  * q [N][ldq] e4m3fn bytes (ldq >= K, a multiple of 128; the pad bytes are written as zero) and scale [N] = the smallest power of
  * two with max|w[n,:]| / scale <= 448 (e4m3fn's largest finite value); q = round-to-nearest-even(w / scale), saturating.

@@ -63,6 +63,21 @@ class FfnDesc(C.Structure):
     ]
 
 
+class AttnInDesc(C.Structure):
+    """Mirror of ``rf_attn_in_desc`` (include/reface_hip.h)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int32),
+        ("wpi", C.c_void_p), ("w_sample_stride", C.c_int64),
+        ("rowvec", C.c_void_p), ("ldv", C.c_int32), ("rows_per_sample", C.c_int32),
+        ("tok", C.c_void_p), ("ldt", C.c_int32),
+        ("wqkv", C.c_void_p), ("bqkv", C.c_void_p),
+        ("qkv", C.c_void_p), ("ldq", C.c_int32),
+        ("M", C.c_int32), ("C", C.c_int32),
+        ("ln_eps", C.c_float),
+        ("dtype", C.c_int32),
+    ]
+
+
 class StemDesc(C.Structure):
     """Mirror of ``rf_stem_desc`` (include/reface_hip.h)."""
     _fields_ = [
@@ -87,6 +102,7 @@ _SIGS = {
     "rf_ffn_geglu": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "rf_ffn_block": (C.c_int, [C.POINTER(FfnDesc), C.c_void_p]),
+    "rf_attn_in": (C.c_int, [C.POINTER(AttnInDesc), C.c_void_p]),
     "rf_quantize_fp8_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rf_groupnorm_stats": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "rf_groupnorm_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libreface_hip.so")
-SOURCES = ["gemm.hip", "gemm_f16.hip", "norm.hip", "attention.hip", "elementwise.hip", "encoder.hip", "ffn.hip", "smallconv.hip"]
+SOURCES = ["gemm.hip", "gemm_f16.hip", "norm.hip", "attention.hip", "elementwise.hip", "encoder.hip", "ffn.hip", "smallconv.hip", "attnin.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 # per-file extras.  attention: keep MFMA accumulators in VGPRs -- the online softmax reads every score and rescales O each
 # tile, and with AGPR accumulators hipcc emitted ~160 v_accvgpr_read/write per KV tile (40 % of the loop's VALU work).

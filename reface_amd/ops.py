@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_PRELU, ACT_QUICK_GELU, ACT_RELU, ACT_SIGMOID, ACT_SILU, RF_BF16, RF_BF16X3, RF_F16, RF_F32,
-                   RF_FP8_E4M3, ConvGemmDesc, FfnDesc, StemDesc)
+                   RF_FP8_E4M3, AttnInDesc, ConvGemmDesc, FfnDesc, StemDesc)
 
 # Attention scores in the exp2 domain: the UNet folds d^-0.5 * log2(e) into the to_q weights and calls rf_attention with scale = ln 2
 # (the kernels then multiply by exactly 1: no second rounding of q * scale to bf16 in the pipelined d = 40 kernel).
@@ -173,6 +173,26 @@ def ffn_block(x, w1p, b1p, w2q, b2, out, *, residual, wpo, bpo, res2, res2_rows=
     d.res2, d.ldr2, d.res2_rows = _p(res2), (res2.stride(0) if res2 is not None else 0), int(res2_rows)
     d.dtype = code(x.dtype)
     return Launch(lib.rf_ffn_block, (C.byref(d),), (d, x, w1p, b1p, w2q, b2, out, residual, wpo, bpo, res2), name)
+
+
+def attn_in(x, wps, rv, tok, wqkv, bqkv, qkv, *, rows_per_sample, ln_eps=1e-5, name="attn_in"):
+    """The token-resident front of a SpatialTransformer block at C = 320 (rf_attn_in): tok[M, C] = x W'_s^T + r_s (proj_in with the GroupNorm folded in per sample:
+    wps [S, C, C] / rv [S, C] from groupnorm_fold_linear), qkv[M, 3C] = LayerNorm(tok) wqkv^T + bqkv (norm1 without affine in registers: fold gamma / beta with
+    fold_layernorm_geglu's scheme).  x / tok / qkv: row-strided 2-D views in one 16-bit type."""
+    lib = _lib.load()
+    _require_gpu(x, wps, rv, tok, wqkv, bqkv, qkv)
+    M, Cc = x.shape
+    S = wps.shape[0]
+    assert x.dtype in H16 and x.dtype == wps.dtype == tok.dtype == wqkv.dtype == qkv.dtype and rv.dtype == bqkv.dtype == torch.float32
+    assert wps.shape == (S, Cc, Cc) and wps.is_contiguous() and rv.shape == (S, Cc) and rv.stride(1) == 1 and M == S * rows_per_sample
+    assert wqkv.shape == (3 * Cc, Cc) and wqkv.is_contiguous() and bqkv.shape == (3 * Cc,) and bqkv.is_contiguous()
+    assert tok.shape == (M, Cc) and qkv.shape == (M, 3 * Cc) and x.stride(1) == tok.stride(1) == qkv.stride(1) == 1
+    d = AttnInDesc()
+    d.x, d.ldx, d.wpi, d.w_sample_stride = _p(x), x.stride(0), _p(wps), (Cc * Cc if S > 1 else 0)
+    d.rowvec, d.ldv, d.rows_per_sample = _p(rv), rv.stride(0), int(rows_per_sample)
+    d.tok, d.ldt, d.wqkv, d.bqkv, d.qkv, d.ldq = _p(tok), tok.stride(0), _p(wqkv), _p(bqkv), _p(qkv), qkv.stride(0)
+    d.M, d.C, d.ln_eps, d.dtype = M, Cc, float(ln_eps), code(x.dtype)
+    return Launch(lib.rf_attn_in, (C.byref(d),), (d, x, wps, rv, tok, wqkv, bqkv, qkv), name)
 
 
 class Fp8Weight:

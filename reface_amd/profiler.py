@@ -50,6 +50,14 @@ def ffn_flops(l):
     return 2.0 * M * C_ * 8 * C_ + 2.0 * M * 4 * C_ * C_
 
 
+def attn_in_flops(l):
+    """rf_attn_in: proj_in (2*M*C*C) + the fused q / k / v projection (2*M*3C*C)."""
+    if l.fn.__name__ != "rf_attn_in":
+        return 0.0
+    d = l.keep[0]
+    return 2.0 * d.M * d.C * d.C + 2.0 * d.M * 3 * d.C * d.C
+
+
 def attention_flops(l):
     if l.fn.__name__ != "rf_attention":
         return 0.0
@@ -135,7 +143,7 @@ def summarize(timed):
         f = fam.setdefault(launch_family(l), dict(calls=0, ms=0.0, flops=0.0))
         f["calls"] += 1
         f["ms"] += ms
-        f["flops"] += gemm_flops(l) + attention_flops(l) + ffn_flops(l)
+        f["flops"] += gemm_flops(l) + attention_flops(l) + ffn_flops(l) + attn_in_flops(l)
     for f in fam.values():
         f["tflops_per_s"] = (f["flops"] / (f["ms"] * 1e-3) / 1e12) if f["ms"] > 0 else 0.0
     return fam

@@ -122,6 +122,10 @@ class UNetEngine:
         # modes): one GEMM over K = 5 C on premultiplied weights instead of two launches and a round trip of [M, C] (_st): REFACE_PO_FOLD=0 keeps the pair
         self.po_fold = os.environ.get("REFACE_PO_FOLD", "1") == "1"
         self.n_po_folded = 0
+        # the token-resident FRONT of the C = 320 blocks: norm (folded) + proj_in + norm1 + qkv in one kernel (rf_attn_in, csrc/attnin.hip): REFACE_FRONT_FUSE=0 keeps the
+        # two K = 320 GEMM launches
+        self.front_fuse = os.environ.get("REFACE_FRONT_FUSE", "1") == "1"
+        self.n_front_fused = 0
         self.out_fuse = os.environ.get("REFACE_OUT_FUSE", "1") == "1"          # `out` head (GroupNorm + SiLU + 3x3 conv to 4 channels) as one pass (csrc/smallconv.hip)
         # the stem (3x3 conv from the 9 stored-in-16 input channels) as a pixels-on-lanes kernel that computes the CFG-duplicated half once and emits
         # the statistics of both its GroupNorm consumers (csrc/smallconv.hip): REFACE_STEM_FUSE=0 keeps the implicit GEMM + the statistics pass
@@ -447,6 +451,27 @@ class UNetEngine:
         tok = self.pool.get((M, c), self.dt)
         w_pi = self.sd[f"{p}.proj_in.weight"].reshape(c, c)
         l_pi = None
+        # C = 320: GroupNorm (folded into per-sample weights) + proj_in + norm1 + to_q / to_k / to_v as ONE token-resident kernel (rf_attn_in) where its 128-token blocks come in
+        # nearly whole rounds of the chip: tok is written once (to_out's residual) and never re-read, the LayerNorm statistics never leave the registers that hold the row
+        fblk = (M + 127) // 128
+        front = (self.front_fuse and c == 320 and self.dt in H16 and not a8 and not self.w8 and self.gn_fold_lin and x.is_contiguous() and (H * W) % 128 == 0 and
+                 fblk / (self.n_cu * ((fblk + self.n_cu - 1) // self.n_cu)) >= self.ffn_whole)
+        if front:
+            part, nch = self._gn_stats(x)
+            fl, wps, rv = ops.groupnorm_fold_linear(w_pi.float().contiguous(), self.f32(f"{p}.norm.weight"), self.f32(f"{p}.norm.bias"),
+                                                    self.f32(f"{p}.proj_in.bias"), part, nch, B=B, HW=H * W, eps=1e-6, dtype=self.dt, name=f"{p}.norm.fold")
+            wq = torch.cat([self.sd[f"{t}.attn1.to_q.weight"].float() * (d ** -0.5 * ops.LOG2E), self.sd[f"{t}.attn1.to_k.weight"].float(),
+                            self.sd[f"{t}.attn1.to_v.weight"].float()], 0)
+            wqf, bqf = ops.fold_layernorm_geglu(wq, torch.zeros(3 * c, device=self.dev), self.sd[f"{t}.norm1.weight"], self.sd[f"{t}.norm1.bias"])
+            qkv = self.pool.get((M, 3 * c), self.dt)
+            self.main.append(fl)
+            self.main.append(ops.attn_in(x.view(M, c), wps, rv, tok, wqf.to(self.dt).contiguous(), bqf.contiguous(), qkv, rows_per_sample=H * W, ln_eps=1e-5,
+                                         name=f"{p}.proj_in+norm1+qkv"))
+            self.n_gn_folded += 1
+            self.n_ln_folded += 1
+            self.n_front_fused += 1
+            ln = self.pool.get((M, c), self.dt)
+            return self._st_after_qkv(p, x, c, heads, dst, pair, tok, qkv, ln, a8)
         if self.gn_fold_lin and self.dt in H16 and not a8 and not self.w8 and c <= self.gn_fold_maxc and x.is_contiguous() and (H * W) % 256 == 0:
             # `norm` folded into proj_in (bf16 mode, C <= 640: B x C x C folded weights cost less than the pass they replace): the statistics of x
             # scale W's columns per sample, proj_in multiplies the UN-normalised x, the mean / beta terms ride in its per-sample vector
@@ -486,6 +511,15 @@ class UNetEngine:
         if a8:
             self.aput(ln)
             ln = self.pool.get((M, c), self.dt)
+        return self._st_after_qkv(p, x, c, heads, dst, pair, tok, qkv, ln, a8)
+
+    def _st_after_qkv(self, p, x, c, heads, dst, pair, tok, qkv, ln, a8):
+        """The SpatialTransformer block from the self-attention on (attention.py:239-243, 268-289): `tok` = proj_in's output (the residual), `qkv` the fused projection,
+        `ln` a free [M, C] buffer."""
+        B, H, W, _ = x.shape
+        M, d = B * H * W, c // heads
+        t = f"{p}.transformer_blocks.0"
+        nb = 2 if pair else 1
         att = ln    # reuse the LayerNorm buffer for the attention output
         q3 = qkv.view(B, H * W, 3 * c)
         self.main.append(ops.attention(q3[..., :c], q3[..., c:2 * c], q3[..., 2 * c:], att.view(B, H * W, c), heads=heads,

@@ -148,6 +148,22 @@ def test_cabi_exports_match_header():
     for f, t in _lib.StemDesc._fields_:
         if f in ssz:
             assert ctypes.sizeof(t) == ssz[f], f
+    # ... and of rf_attn_in_desc
+    m4 = re.search(r"typedef struct rf_attn_in_desc \{(.*?)\} rf_attn_in_desc;", hdr, re.S)
+    afields = []
+    for decl in re.sub(r"/\*.*?\*/", "", m4.group(1), flags=re.S).split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split("*", 1)[1] if "*" in decl else decl.split(None, 1)[1]
+        afields += [n.strip().lstrip("*") for n in names.split(",") if n.strip()]
+    assert [f[0] for f in _lib.AttnInDesc._fields_] == afields, afields
+    asz = {"x": 8, "w_sample_stride": 8, "rows_per_sample": 4, "ln_eps": 4, "dtype": 4}
+    for f, t in _lib.AttnInDesc._fields_:
+        if f in asz:
+            assert ctypes.sizeof(t) == asz[f], f
+    ad = _lib.AttnInDesc()
+    assert lib.rf_attn_in(ctypes.byref(ad), None) != 0 and b"rf_attn_in" in lib.rf_last_error()
     sd = _lib.StemDesc()
     assert lib.rf_conv3x3_stem(ctypes.byref(sd), None) != 0 and b"rf_conv3x3_stem" in lib.rf_last_error()
     # argument validation happens before any launch, so it is testable without a GPU

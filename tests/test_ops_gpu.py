@@ -911,6 +911,53 @@ def test_groupnorm_folded_into_linear(B, hw, c, dt):
     assert not torch.equal(wps[0], wps[1])
 
 
+@pytest.mark.parametrize("dt", H16)
+@pytest.mark.parametrize("B,hw", [(2, 16), (3, 32), (8, 64)])
+def test_attn_in_fused_front(B, hw, dt):
+    """rf_attn_in: the token-resident front of a SpatialTransformer block at C = 320 -- GroupNorm `norm` (folded into per-sample proj_in weights) + proj_in + norm1 +
+    to_q / to_k / to_v (attention.py:262-266, 276-279, 231-233, 239, 159-170) in ONE kernel.  Against the chain it replaces on the GPU (rf_groupnorm_fold_linear ->
+    rf_conv_gemm with per-sample weights -> rf_layernorm -> rf_conv_gemm: the same roundings of tok and of the normalised row), and against an fp32 reference
+    Linear(LayerNorm(Linear(GroupNorm(x)))) on the rounded x."""
+    c = 320
+    HW, M = hw * hw, B * hw * hw
+    x, xr = q(rnd((B, hw, hw, c), 1200) * 1.5 + rnd((B, 1, 1, c), 1201) * 0.5, dt)
+    g0, b0 = rnd((c,), 1202) * 0.3 + 1, rnd((c,), 1203) * 0.2
+    wpi, bpi = rnd((c, c), 1204) / math.sqrt(c), rnd((c,), 1205) * 0.3
+    g1, b1 = rnd((c,), 1206) * 0.3 + 1, rnd((c,), 1207) * 0.2
+    wqkv = rnd((3 * c, c), 1208) / math.sqrt(c)
+    part = torch.empty(B * ops.GN_MAX_CHUNKS * 64, dtype=torch.float64, device=DEV)
+    ls, n = ops.groupnorm_stats(x, part)
+    fl, wps, rv = ops.groupnorm_fold_linear(wpi.to(DEV), g0.to(DEV), b0.to(DEV), bpi.to(DEV), part, n, B=B, HW=HW, eps=1e-6, dtype=dt)
+    wqf, bqf = ops.fold_layernorm_geglu(wqkv, torch.zeros(3 * c), g1, b1)
+    tok = torch.empty((M, c), dtype=dt, device=DEV)
+    qkv = torch.full((M, 3 * c), 9.0, dtype=dt, device=DEV)
+    la = ops.attn_in(x.view(M, c), wps, rv, tok, wqf.to(dt).to(DEV), bqf.to(DEV), qkv, rows_per_sample=HW, ln_eps=1e-5)
+    ls(); fl(); la()
+    # the chain it replaces
+    tok2 = torch.empty_like(tok)
+    ops.linear(x.view(M, c), wps[0], tok2, None, rowvec=rv, rows_per_sample=HW, w_per_sample=wps)()
+    lnb = torch.empty_like(tok)
+    ops.layernorm(tok2, g1.to(DEV), b1.to(DEV), lnb, eps=1e-5)()
+    qkv2 = torch.empty_like(qkv)
+    ops.linear(lnb, wqkv.to(dt).to(DEV), qkv2, None)()
+    torch.cuda.synchronize()
+    # fp32 reference on the rounded x
+    gn = F.group_norm(xr.permute(0, 3, 1, 2), 32, g0, b0, 1e-6).permute(0, 2, 3, 1).reshape(M, c)
+    tok_ref = F.linear(gn, wpi, bpi)
+    qkv_ref = F.linear(F.layer_norm(tok_ref, (c,), g1, b1, 1e-5), wqkv)
+    d_tok = (tok.float() - tok2.float()).abs().max().item()
+    d_qkv = (qkv.float() - qkv2.float()).abs().max().item()
+    e_tok = ((tok.float().cpu() - tok_ref).norm() / tok_ref.norm()).item()
+    e_qkv = ((qkv.float().cpu() - qkv_ref).norm() / qkv_ref.norm()).item()
+    e_qkv2 = ((qkv2.float().cpu() - qkv_ref).norm() / qkv_ref.norm()).item()
+    print(f"fused front (B {B}, {hw}x{hw}, {dt}): tok vs chain max |d| {d_tok:.2e}, qkv vs chain {d_qkv:.2e}; rel L2 vs fp32 reference tok {e_tok:.2e}, qkv {e_qkv:.2e} (chain {e_qkv2:.2e})")
+    assert torch.isfinite(qkv.float()).all()
+    assert d_tok <= 4 * STEP[dt] * max(1.0, tok_ref.abs().max().item())          # same products, another order of the fp32 additions
+    assert d_qkv <= 16 * STEP[dt] * max(1.0, qkv_ref.abs().max().item())         # (a tok value on a rounding boundary moves one normalised operand by a step)
+    lim = 6e-3 * (STEP[dt] / STEP[torch.bfloat16]) ** 0.5
+    assert e_tok < lim and e_qkv < 1.5 * e_qkv2 + 1e-3 and e_qkv < 2 * lim, (e_tok, e_qkv, e_qkv2)
+
+
 @pytest.mark.parametrize("B,H,W_,c,No,odt", [(2, 64, 64, 320, 4, torch.float32), (3, 24, 40, 320, 4, torch.float32), (2, 16, 16, 64, 4, torch.float32),
                                              (1, 9, 7, 128, 3, None), (2, 96, 96, 320, 4, torch.float32)])          # (odt None: the input's 16-bit type)
 @pytest.mark.parametrize("dt", H16)

@@ -10,7 +10,7 @@ mkdir -p $ROOT/reface_amd/lib/alt
 flags=$(cd $ROOT && python -m reface_amd.build --print-flags $unit)
 /opt/rocm/bin/hipcc $flags -DRF_EXPERIMENT $VARIANT_DEFS -I$ROOT/reface_amd/csrc -I$ROOT/include -c $src -o $ROOT/reface_amd/lib/alt/$tag.$unit.o
 objs=""
-for u in gemm gemm_f16 norm attention elementwise encoder ffn smallconv; do
+for u in gemm gemm_f16 norm attention elementwise encoder ffn smallconv attnin; do
   if [ $u = $unit ]; then objs="$objs $ROOT/reface_amd/lib/alt/$tag.$unit.o"; else objs="$objs $ROOT/reface_amd/lib/$u.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/reface_amd/lib/alt/$tag.so $objs

@@ -53,7 +53,7 @@ for k, c in sorted(cls.items(), key=lambda kv: -kv[1]["ms"]):
           f"{bound:>6s} {c['flop'] / (c['ms'] * 1e-3) / 1e12 if c['ms'] else 0:6.0f}")
 def group_of(k):
     if not k.startswith("gemm "):
-        return {"rf_attention": "self-attention (d = 40 / 80 / 160)", "rf_ffn_geglu": "token-resident feed-forward + proj_out (C = 320)", "rf_groupnorm_apply": "GroupNorm + SiLU apply passes"}.get(k, "other passes (fold, finalize, stem, out head, LayerNorm, DDIM glue)")
+        return {"rf_attention": "self-attention (d = 40 / 80 / 160)", "rf_ffn_geglu": "token-resident feed-forward + proj_out (C = 320)", "rf_attn_in": "token-resident proj_in + norm1 + qkv (C = 320)", "rf_groupnorm_apply": "GroupNorm + SiLU apply passes"}.get(k, "other passes (fold, finalize, stem, out head, LayerNorm, DDIM glue)")
     M, N, K = (int(v) for v in k.split()[1].split("x"))
     if "geglu" in k:
         return "GEGLU projections (C = 640 / 1280)"
