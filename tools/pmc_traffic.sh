@@ -12,6 +12,8 @@ import csv, glob, collections, json, re
 def fam(n):
     if "conv_gemm_kernel<unsigned char" in n: return "rf_conv_gemm[fp8]"          # fp8 activations x fp8 weights (MX-scaled MFMA)
     if "conv_gemm_kernel<_Float16" in n: return "rf_conv_gemm[f16]"               # fp16 operands (the fp16 throughput mode)
+    mm = re.match(r"_ZN2rf\d+([a-z0-9_]+?)_kernelI", n)                             # (rocprofv3 leaves names with a _Float16 template argument -- DF16_ -- mangled)
+    if mm: return "rf_conv_gemm[f16]" if mm.group(1) == "conv_gemm" else "rf_" + mm.group(1)
     m = re.search(r"conv_gemm_kernel<(unsigned short|float), (unsigned short|float)", n)
     if m:
         if m.group(1) == "unsigned short" and m.group(2) == "float": return "rf_conv_gemm[bf16x3]"      # bf16 operands, fp32 out: the split-bf16 VAE convs (+ the UNet's 4-channel out conv)
