@@ -178,6 +178,14 @@ typedef struct rf_ffn_desc {
     double* gn_part1;
     int32_t gn_cpg1, gn_coff1, gn_slot1, gn_nchunks1;
     int32_t dtype;        /* element type of x / w1p / w2q / residual / out / wpo / res2: RF_BF16 (also 0: the descriptor as it was before the field) or RF_F16 */
+    /* attn1.to_out IN FRONT of the feed-forward (attention.py:239-243; needs wpo): wo != NULL makes `x` the attention's output [front_rows or M][ldx] and the block first forms */
+    /*   x1 = x Wo^T + bo + ctx[row / rows_per_sample0] + res0[row % front_rows]        (out-projection + the sample's cross-attention vector + the residual tok)             */
+    /* rounds it to `dtype`, stores it to x1 -- which must be the same buffer as `residual` -- and continues with it as the feed-forward's input.  front_rows > 0: x / res0  */
+    /* have that many rows and are shared by the batch halves (the CFG-shared first block); 0: M rows.  Replaces that rf_conv_gemm launch and the re-read of its output.    */
+    const void* wo; const float* bo;
+    const float* ctx; int32_t ldc, rows_per_sample0;
+    const void* res0; int32_t ldr0, front_rows;
+    void* x1; int32_t ldx1;
 } rf_ffn_desc;
 int rf_ffn_block(const rf_ffn_desc* d, void* stream);
 

@@ -60,6 +60,10 @@ class FfnDesc(C.Structure):
         ("gn_part0", C.c_void_p), ("gn_cpg0", C.c_int32), ("gn_coff0", C.c_int32), ("gn_slot0", C.c_int32), ("gn_nchunks0", C.c_int32),
         ("gn_part1", C.c_void_p), ("gn_cpg1", C.c_int32), ("gn_coff1", C.c_int32), ("gn_slot1", C.c_int32), ("gn_nchunks1", C.c_int32),
         ("dtype", C.c_int32),
+        ("wo", C.c_void_p), ("bo", C.c_void_p),
+        ("ctx", C.c_void_p), ("ldc", C.c_int32), ("rows_per_sample0", C.c_int32),
+        ("res0", C.c_void_p), ("ldr0", C.c_int32), ("front_rows", C.c_int32),
+        ("x1", C.c_void_p), ("ldx1", C.c_int32),
     ]
 
 

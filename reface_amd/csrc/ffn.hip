@@ -35,6 +35,13 @@ struct FfnParams {
     // wpo [C][C] plain rows (no column permutation: the B operand is built in natural K order, see the epilogue); NULL = no projection.
     const bf16_t* wpo; const float* bpo;
     const bf16_t* res2; int ldr2; int res2_rows;
+    // attn1.to_out IN FRONT of the feed-forward (attention.py:239-243; round 6, FRONT kernels): `x` is then the attention's output [front_rows][ldx] and the block first forms
+    //   x1 = x Wo^T + bo + ctx[row / rows_per_sample0] + res0[row % front_rows]            (out-projection + cross-attention vector + residual tok)
+    // rounds it to the storage type, stores it to `x1` (the feed-forward's residual, read back through `res`) and goes on with it as the feed-forward's input.
+    const bf16_t* wo; const float* bo;       // [C][C] plain rows, [C]
+    const float* ctx; int ldc; int rows_per_sample0;
+    const bf16_t* res0; int ldr0; int front_rows;
+    bf16_t* x1; int ldx1;
     // GroupNorm(32) partial sums of `out` for up to two consumers (the layout rf_conv_gemm's epilogue writes: one slot per 128-row block and sample)
     int gn_rows;
     double* gn_part[2];
@@ -43,9 +50,10 @@ struct FfnParams {
 
 __device__ __forceinline__ int ffn_lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
-template <int C, bool PROJ, typename T = bf16_t>
+template <int C, bool PROJ, typename T = bf16_t, bool FRONT = false>
 __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
     static_assert(sizeof(T) == 2, "16-bit operands (bf16 / fp16)");
+    static_assert(!FRONT || PROJ, "the out-projection in front exists in the whole-block kernel only");
     constexpr int CK = C / 64;               // K tiles of GEMM 1
     constexpr int NB = C / 32;               // 32-row blocks of the output (transposed)
     constexpr int F = 4 * C;                 // hidden width
@@ -73,10 +81,106 @@ __global__ __launch_bounds__(256, 1) void ffn_geglu_kernel(const FfnParams p) {
 
     // ---- X^T fragments of this wave's 32 tokens: the B operand of GEMM 1, resident in registers (20 k-steps x 16 bytes per lane)
     u32x4_t xq[CK * 4];
+    const int xrow = (FRONT && p.front_rows > 0) ? row % p.front_rows : row;          // (FRONT under CFG sharing: both batch halves read the same attention output)
 #pragma unroll
     for (int s_ = 0; s_ < CK * 4; ++s_) {
         xq[s_] = u32x4_t{0u, 0u, 0u, 0u};
-        if (row < p.M) xq[s_] = *(const u32x4_t*)(p.x + (long long)row * p.ldx + s_ * 16 + lhalf * 8);
+        if (row < p.M) xq[s_] = *(const u32x4_t*)(p.x + (long long)xrow * p.ldx + s_ * 16 + lhalf * 8);
+    }
+
+    if constexpr (FRONT) {
+        // ---- attn1.to_out in front: x1^T = Wo . att^T over five [C x 64] tiles of Wo streamed through the (still idle) W2 buffers + 40 KB of the W1 ring, exactly as the
+        // proj_out contraction at the other end of the kernel; + bo + the sample's cross-attention vector + the residual tok; rounded, stored (the feed-forward's residual),
+        // re-laid-out by v_permlane32_swap into the X^T fragments the rest of the kernel expects.  The kernel's own prologue starts behind it.
+        const __amdgpu_buffer_rsrc_t rsWo = __builtin_amdgcn_make_buffer_rsrc((void*)p.wo, 0, (unsigned)(C * C * 2), 0x00020000);
+        const int prow_ = lane >> 3;
+        auto fbuf = [&](int kt) -> char* { return kt % 3 == 2 ? smem + W1B : smem + OFF_W2 + (kt % 3) * W2B; };
+        auto issue_wo = [&](int kt, int q0, int q1) {
+            char* base = fbuf(kt);
+#pragma unroll
+            for (int q = 0; q < NPW2; ++q) {
+                if (q >= q0 && q < q1) {
+                    const int rg = wave + 4 * q, r = rg * 8 + prow_;
+                    const int off = r * C * 2 + (((lane & 7) ^ ((r >> 1) & 7)) * 16);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsWo, (__attribute__((address_space(3))) void*)(base + rg * 1024), 16, off, kt * 128, 0, 0);
+                }
+            }
+        };
+        issue_wo(0, 0, NPW2);
+        issue_wo(1, 0, NPW2);
+        float* const cl = (float*)smem;                          // [C] bo + ctx of this block's sample (the first bytes of the idle W1 ring)
+        {
+            const float* const cv = p.ctx ? p.ctx + (long long)(m0 / p.rows_per_sample0) * p.ldc : nullptr;
+            for (int i = tid; i < C; i += 256) cl[i] = p.bo[i] + (cv ? cv[i] : 0.f);
+        }
+        const int brow0 = 16 * ((lrow >> 2) & 1) + 4 * (lrow >> 3) + (lrow & 3), bsw0 = (brow0 >> 1) & 7;
+        f32x16_t a0[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a0[nb][r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < CK; ++kt) {
+            if (kt + 1 < CK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW2) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const char* const wb = fbuf(kt) + brow0 * 128;
+            u32x4_t af[2];
+            af[0] = *(const u32x4_t*)(wb + (((0 + lhalf) ^ bsw0) << 4));
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int it = kk * NB + nb, cur = it & 1;
+                    if (it + 1 < 4 * NB) {
+                        const int nkk = (it + 1) / NB, nnb = (it + 1) % NB;
+                        af[cur ^ 1] = *(const u32x4_t*)(wb + nnb * 4096 + (((nkk * 2 + lhalf) ^ bsw0) << 4));
+                    }
+                    mma16<T>(a0[nb], af[cur], xq[kt * 4 + kk]);
+                }
+                if (kt + 2 < CK) issue_wo(kt + 2, kk * 3, kk * 3 + 3 < NPW2 ? kk * 3 + 3 : NPW2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // + column constants + residual, rounded as the unfused out-projection stores it; the row goes out (x1) and stays (xq)
+        constexpr int PF0 = 4;
+        u32x4_t r0[PF0][2];
+        auto load_r0 = [&](int nb, u32x4_t* r) {
+            if (p.res0 && row < p.M) {
+                const u32x4_t* rp = (const u32x4_t*)(p.res0 + (long long)xrow * p.ldr0 + nb * 32 + lhalf * 16);
+                r[0] = rp[0];
+                r[1] = rp[1];
+            }
+        };
+#pragma unroll
+        for (int nb = 0; nb < PF0; ++nb) load_r0(nb, r0[nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = nb * 32 + lhalf * 16;
+            u32x4_t pk[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float f[8], v[8];
+                const f32x4_t c0 = *(const f32x4_t*)(cl + col + 8 * h), c1 = *(const f32x4_t*)(cl + col + 8 * h + 4);
+                if (p.res0) unpack16<T>(r0[nb % PF0][h], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (row < p.M) ? a0[nb][8 * h + e] + (e < 4 ? c0[e] : c1[e - 4]) + (p.res0 ? f[e] : 0.f) : 0.f;
+                pk[h] = pack16<T>(v);
+                if (row < p.M) ((u32x4_t*)(p.x1 + (long long)row * p.ldx1 + col))[h] = pk[h];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(pk[0][e], pk[1][e], false, false);
+                xq[2 * nb][e] = sw[0];
+                xq[2 * nb + 1][e] = sw[1];
+            }
+            if (nb + PF0 < NB) load_r0(nb + PF0, r0[nb % PF0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // every wave is done with the Wo buffers and the column constants: the kernel's own prologue (W1 ring, W2 chunk 0, bias) may overwrite them
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 
     // LayerNorm of the token's row in registers (attention.py:231-233 `norm3` in front of the feed-forward): the lane pair (tok, half 0 / 1)
@@ -557,14 +661,17 @@ static int ffn_launch(const rf::FfnParams& p, int C, void* stream, int dtype = R
                      "rf_ffn_block: GroupNorm consumer %d: cpg=%d slot=%d needs %d slots of %d", c, p.gn_cpg[c], p.gn_slot[c], p.gn_rows / 128, p.gn_nch[c]);
     }
     constexpr int smem = 4 * 16384 + 2 * 320 * 128 + 2 * 4 * 512;
-#define RF_FFN_LAUNCH(PROJ_, T_)                                                                       \
+    RF_CHECK(!p.wo || (p.wpo && p.bo && p.x1 && p.res == p.x1 && p.rows_per_sample0 > 0 && p.rows_per_sample0 % 128 == 0 && p.ldx1 % 8 == 0 && (!p.res0 || p.ldr0 % 8 == 0) &&
+                       ((uintptr_t)p.wo | (uintptr_t)p.x1 | (uintptr_t)p.res0 | (uintptr_t)p.bo | (uintptr_t)p.ctx) % 16 == 0 && p.ldc % 4 == 0 && (p.front_rows == 0 || p.front_rows % 128 == 0)),
+             "rf_ffn_block: the out-projection in front needs the fused tail (wpo), bo, x1 == residual, rows_per_sample0 / front_rows multiples of the 128-token block, aligned operands");
+#define RF_FFN_LAUNCH(PROJ_, T_, FRONT_)                                                               \
     {                                                                                                  \
-        auto k = ffn_geglu_kernel<320, PROJ_, T_>;                                                     \
+        auto k = ffn_geglu_kernel<320, PROJ_, T_, FRONT_>;                                             \
         RF_RAISE_LDS(k, smem, "rf_ffn_geglu");                                                         \
         hipLaunchKernelGGL(k, dim3((p.M + 127) / 128), dim3(256), smem, (hipStream_t)stream, p);       \
     }
-    if (dtype == RF_F16) { if (p.wpo) RF_FFN_LAUNCH(true, f16_t) else RF_FFN_LAUNCH(false, f16_t) }
-    else { if (p.wpo) RF_FFN_LAUNCH(true, bf16_t) else RF_FFN_LAUNCH(false, bf16_t) }
+    if (dtype == RF_F16) { if (p.wo) RF_FFN_LAUNCH(true, f16_t, true) else if (p.wpo) RF_FFN_LAUNCH(true, f16_t, false) else RF_FFN_LAUNCH(false, f16_t, false) }
+    else { if (p.wo) RF_FFN_LAUNCH(true, bf16_t, true) else if (p.wpo) RF_FFN_LAUNCH(true, bf16_t, false) else RF_FFN_LAUNCH(false, bf16_t, false) }
 #undef RF_FFN_LAUNCH
     RF_LAUNCH_CHECK("rf_ffn_geglu");
     return 0;
@@ -591,5 +698,7 @@ extern "C" int rf_ffn_block(const rf_ffn_desc* d, void* stream) {
     p.gn_rows = (d->gn_part0 || d->gn_part1) ? d->gn_rows : 0;
     p.gn_part[0] = d->gn_part0; p.gn_cpg[0] = d->gn_cpg0; p.gn_coff[0] = d->gn_coff0; p.gn_slot[0] = d->gn_slot0; p.gn_nch[0] = d->gn_nchunks0;
     p.gn_part[1] = d->gn_part1; p.gn_cpg[1] = d->gn_cpg1; p.gn_coff[1] = d->gn_coff1; p.gn_slot[1] = d->gn_slot1; p.gn_nch[1] = d->gn_nchunks1;
+    p.wo = (const bf16_t*)d->wo; p.bo = d->bo; p.ctx = d->ctx; p.ldc = d->ldc; p.rows_per_sample0 = d->rows_per_sample0;
+    p.res0 = (const bf16_t*)d->res0; p.ldr0 = d->ldr0; p.front_rows = d->front_rows; p.x1 = (bf16_t*)d->x1; p.ldx1 = d->ldx1;
     return ffn_launch(p, d->C, stream, d->dtype == 0 ? RF_BF16 : d->dtype);
 }

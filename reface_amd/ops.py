@@ -152,13 +152,14 @@ def ffn_geglu(x, w1p, b1p, w2q, b2, out, *, residual=None, ln_eps=0.0, name="ffn
                   (x, w1p, b1p, w2q, b2, out, residual), name)
 
 
-def ffn_block(x, w1p, b1p, w2q, b2, out, *, residual, wpo, bpo, res2, res2_rows=0, ln_eps=0.0, name="ffn_block"):
+def ffn_block(x, w1p, b1p, w2q, b2, out, *, residual, wpo, bpo, res2, res2_rows=0, ln_eps=0.0, front=None, name="ffn_block"):
     """The token-resident tail of a SpatialTransformer block at C = 320 (rf_ffn_block): out[M, C] = ((GEGLU(LN?(x) W1^T + b1)) W2^T + b2 + residual)
     Wpo^T + bpo + res2[row % res2_rows] in one kernel.  x / residual / res2 / out: bf16 row-strided 2-D views; wpo [C, C] bf16 contiguous (plain rows).
     The launch can emit the GroupNorm statistics of `out` (fuse_groupnorm_stats accepts it as a producer: 128-row blocks, all C columns)."""
     lib = _lib.load()
     _require_gpu(x, w1p, b1p, w2q, b2, out, residual, wpo, bpo, res2)
-    M, Cc = x.shape
+    M, Cc = out.shape          # (with `front` and CFG sharing, x -- the attention's output -- has front_rows rows)
+    assert x.shape == ((int(front.get("front_rows", 0)) or M) if front is not None else M, Cc)
     assert x.dtype == w1p.dtype == w2q.dtype == out.dtype and x.dtype in H16 and b1p.dtype == b2.dtype == torch.float32
     assert wpo is None or (wpo.dtype == x.dtype and bpo.dtype == torch.float32 and wpo.shape == (Cc, Cc) and wpo.is_contiguous())
     assert w1p.shape == (8 * Cc, Cc) and w2q.shape == (Cc, 4 * Cc) and w1p.is_contiguous() and w2q.is_contiguous()
@@ -172,7 +173,21 @@ def ffn_block(x, w1p, b1p, w2q, b2, out, *, residual, wpo, bpo, res2, res2_rows=
     d.wpo, d.bpo = _p(wpo), _p(bpo)
     d.res2, d.ldr2, d.res2_rows = _p(res2), (res2.stride(0) if res2 is not None else 0), int(res2_rows)
     d.dtype = code(x.dtype)
-    return Launch(lib.rf_ffn_block, (C.byref(d),), (d, x, w1p, b1p, w2q, b2, out, residual, wpo, bpo, res2), name)
+    keep = (d, x, w1p, b1p, w2q, b2, out, residual, wpo, bpo, res2)
+    if front is not None:
+        # attn1.to_out in front (rf_ffn_desc.wo ...): x is the attention's output; front = dict(wo [C, C], bo [C], ctx [samples, C] fp32 or None, rows_per_sample,
+        # res0 = tok [front_rows or M, C], front_rows (0: M), x1 = the buffer `residual` points at)
+        wo, bo, ctx, res0, x1 = front["wo"], front["bo"], front.get("ctx"), front.get("res0"), front["x1"]
+        _require_gpu(wo, bo, ctx, res0, x1)
+        assert wpo is not None and wo.dtype == x.dtype and wo.shape == (Cc, Cc) and wo.is_contiguous() and bo.dtype == torch.float32 and bo.numel() == Cc
+        assert x1.data_ptr() == residual.data_ptr() and x1.shape == (M, Cc) and x1.stride(1) == 1 and x1.dtype == x.dtype
+        fr = int(front.get("front_rows", 0))
+        assert res0 is None or (res0.dtype == x.dtype and res0.stride(1) == 1 and res0.shape == ((fr or M), Cc))
+        assert ctx is None or (ctx.dtype == torch.float32 and ctx.stride(1) == 1 and ctx.shape[1] == Cc and ctx.shape[0] * front["rows_per_sample"] == M)
+        d.wo, d.bo, d.ctx, d.ldc, d.rows_per_sample0 = _p(wo), _p(bo), _p(ctx), (ctx.stride(0) if ctx is not None else 0), int(front["rows_per_sample"])
+        d.res0, d.ldr0, d.front_rows, d.x1, d.ldx1 = _p(res0), (res0.stride(0) if res0 is not None else 0), fr, _p(x1), x1.stride(0)
+        keep = keep + (wo, bo, ctx, res0, x1)
+    return Launch(lib.rf_ffn_block, (C.byref(d),), keep, name)
 
 
 def attn_in(x, wps, rv, tok, wqkv, bqkv, qkv, *, rows_per_sample, ln_eps=1e-5, name="attn_in"):

@@ -43,7 +43,7 @@ def ffn_flops(l):
     """rf_ffn_geglu: 2*M*C*8C (GEGLU projection) + 2*M*4C*C (ff.net.2)."""
     if l.fn.__name__ == "rf_ffn_block":          # + proj_out (2*M*C*C) when fused behind the feed-forward
         d = l.keep[0]
-        return 2.0 * d.M * d.C * 8 * d.C + 2.0 * d.M * 4 * d.C * d.C + (2.0 * d.M * d.C * d.C if d.wpo else 0.0)
+        return 2.0 * d.M * d.C * 8 * d.C + 2.0 * d.M * 4 * d.C * d.C + (2.0 * d.M * d.C * d.C if d.wpo else 0.0) + (2.0 * d.M * d.C * d.C if d.wo else 0.0)
     if l.fn.__name__ != "rf_ffn_geglu":
         return 0.0
     M, C_ = l.args[10], l.args[11]

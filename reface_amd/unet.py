@@ -126,6 +126,9 @@ class UNetEngine:
         # two K = 320 GEMM launches
         self.front_fuse = os.environ.get("REFACE_FRONT_FUSE", "1") == "1"
         self.n_front_fused = 0
+        # attn1.to_out (+ residual + cross-attention vector) in FRONT of the token-resident tail kernel (rf_ffn_desc.wo): REFACE_MID_FUSE=0 keeps its rf_conv_gemm launch(es)
+        self.mid_fuse = os.environ.get("REFACE_MID_FUSE", "1") == "1"
+        self.n_mid_fused = 0
         self.out_fuse = os.environ.get("REFACE_OUT_FUSE", "1") == "1"          # `out` head (GroupNorm + SiLU + 3x3 conv to 4 channels) as one pass (csrc/smallconv.hip)
         # the stem (3x3 conv from the 9 stored-in-16 input channels) as a pixels-on-lanes kernel that computes the CFG-duplicated half once and emits
         # the statistics of both its GroupNorm consumers (csrc/smallconv.hip): REFACE_STEM_FUSE=0 keeps the implicit GEMM + the statistics pass
@@ -541,12 +544,35 @@ class UNetEngine:
         # attn1 out-projection + residual + the (token-independent) cross-attention output; with pair=True one launch per CFG
         # half: same A and residual, that half's context vectors
         w_out, b_out, cv = self.gw(self.sd[f"{t}.attn1.to_out.0.weight"]), self.f32(f"{t}.attn1.to_out.0.bias"), self.ctx_vec(p)
+        # the whole rest of the block in ONE kernel where the token-resident tail applies: the out-projection runs in front of the feed-forward inside rf_ffn_block (x1 is
+        # written once, as the feed-forward's residual, and not re-read as its input; the launch(es) of attn1.to_out are gone)
+        tail_ok = fused_ffn and self.ln_fold and self.tail_fuse and x.stride(3) == 1 and x.stride(1) == W * x.stride(2) and (B == 1 or x.stride(0) == H * x.stride(1))
+        mid = self.mid_fuse and tail_ok and (H * W) % 128 == 0
         l_out = []
-        for hf in range(nb):
-            l_out.append(ops.linear(att, w_out, x1[hf * M:(hf + 1) * M], b_out, residual=tok, rowvec=cv[hf * B:(hf + 1) * B],
-                                    rows_per_sample=H * W, name=f"{t}.attn1.to_out"))
-        self.main += l_out
+        if not mid:
+            for hf in range(nb):
+                l_out.append(ops.linear(att, w_out, x1[hf * M:(hf + 1) * M], b_out, residual=tok, rowvec=cv[hf * B:(hf + 1) * B],
+                                        rows_per_sample=H * W, name=f"{t}.attn1.to_out"))
+            self.main += l_out
         self.pool.put(qkv)
+        if mid:
+            w1f, b1f = ops.fold_layernorm_geglu(self.sd[f"{t}.ff.net.0.proj.weight"], self.sd[f"{t}.ff.net.0.proj.bias"], self.sd[f"{t}.norm3.weight"], self.sd[f"{t}.norm3.bias"])
+            wgm, bgm = ops.pack_geglu(w1f, b1f, F32)
+            y = dst if dst is not None else self.pool.get((nb * B, H, W, c), self.dt)
+            y2 = y.as_strided((nb * M, c), (y.stride(2), 1))
+            assert y.stride(3) == 1 and y.stride(1) == W * y.stride(2) and y.stride(0) == H * y.stride(1)
+            x_rows = x.as_strided((M, c), (x.stride(2), 1))
+            self._add(ops.ffn_block(att, wgm.to(self.dt).contiguous(), bgm, ops.pack_ffn_w2(self.sd[f"{t}.ff.net.2.weight"], self.dt), self.f32(f"{t}.ff.net.2.bias"), y2,
+                                    residual=x1, wpo=self.sd[f"{p}.proj_out.weight"].reshape(c, c).to(self.dt).contiguous(), bpo=self.f32(f"{p}.proj_out.bias"),
+                                    res2=x_rows, res2_rows=M if nb > 1 else 0, ln_eps=1e-5,
+                                    front=dict(wo=w_out, bo=b_out, ctx=cv, rows_per_sample=H * W, res0=tok, front_rows=M if nb > 1 else 0, x1=x1),
+                                    name=f"{t}.to_out+ff+proj_out"), y)
+            for buf in (tok, ln, x1):          # (only now: the launch reads tok and the attention output, and owns x1)
+                self.pool.put(buf)
+            self.n_ln_folded += 1
+            self.n_tail_fused += 1
+            self.n_mid_fused += 1
+            return y
         self.pool.put(tok)
         if pair or a8:
             self.pool.put(ln)

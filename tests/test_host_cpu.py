@@ -235,7 +235,7 @@ def test_fp16_mode_surface():
     from reface_amd.unet import UNetModel
     hdr = open(os.path.join(ROOT, "include", "reface_hip.h")).read()
     assert re.search(r"RF_F16\s*=\s*4", hdr) and _lib.RF_F16 == 4 and ops.code(torch.float16) == 4
-    assert [f for f, _ in _lib.FfnDesc._fields_][-1] == "dtype" and [f for f, _ in _lib.StemDesc._fields_][-1] == "dtype"
+    assert "dtype" in [f for f, _ in _lib.FfnDesc._fields_] and [f for f, _ in _lib.StemDesc._fields_][-1] == "dtype"
     if os.path.exists(_lib.LIB_PATH):
         lib = _lib.load()
         assert lib.rf_version() >= 101

@@ -799,6 +799,51 @@ def test_ffn_block_fused_tail(B, hw, pair, concat, dt):
     check(yn, refn, dt)
 
 
+@pytest.mark.parametrize("dt", H16)
+@pytest.mark.parametrize("B,hw,pair", [(2, 32, False), (16, 64, False), (4, 32, True), (3, 16, False)])
+def test_ffn_block_with_out_projection_in_front(B, hw, pair, dt):
+    """rf_ffn_block with attn1.to_out in FRONT (rf_ffn_desc.wo; attention.py:239-243): x1 = att Wo^T + bo + ctx[sample] + tok inside the kernel, then the token-resident
+    tail on it.  Against the chain it replaces on the GPU -- the out-projection as rf_conv_gemm (one launch per CFG half under `pair`: both halves read the same attention
+    output and tok, each its own cross-attention vectors), then rf_ffn_block on its output: the same roundings of x1, so a few storage steps at most -- and the stored x1."""
+    Cc = 320
+    HW = hw * hw
+    nb = 2 if pair else 1
+    Mt, M = B * HW, nb * B * HW
+    att, _ = q(rnd((Mt, Cc), 1300) * 0.8, dt)
+    tok, _ = q(rnd((Mt, Cc), 1301), dt)
+    xin, _ = q(rnd((Mt, Cc), 1302), dt)
+    wo, bo = rnd((Cc, Cc), 1303) / math.sqrt(Cc), rnd((Cc,), 1304) * 0.3
+    ctx = (rnd((nb * B, Cc), 1305) * 0.5).to(DEV)
+    gamma, beta = rnd((Cc,), 1306) * 0.3 + 1.0, rnd((Cc,), 1307) * 0.2
+    w1, b1 = rnd((8 * Cc, Cc), 1308) / math.sqrt(Cc), rnd((8 * Cc,), 1309) * 0.5
+    w2, b2 = rnd((Cc, 4 * Cc), 1310) / math.sqrt(4 * Cc), rnd((Cc,), 1311)
+    wpo, bpo = rnd((Cc, Cc), 1312) / math.sqrt(Cc), rnd((Cc,), 1313)
+    w1f, b1f = ops.fold_layernorm_geglu(w1, b1, gamma, beta)
+    w1p, b1p = ops.pack_geglu(w1f, b1f, dt)
+    w2q = ops.pack_ffn_w2(w2.to(DEV), dt)
+    wod = wo.to(dt).to(DEV)
+    common = dict(wpo=wpo.to(dt).to(DEV), bpo=bpo.to(DEV), res2=xin, res2_rows=Mt if pair else 0, ln_eps=1e-5)
+    # fused: out-projection in front
+    x1f = torch.zeros((M, Cc), dtype=dt, device=DEV)
+    yf = torch.empty((M, Cc), dtype=dt, device=DEV)
+    ops.ffn_block(att, w1p.to(DEV), b1p.to(DEV), w2q, b2.to(DEV), yf, residual=x1f,
+                  front=dict(wo=wod, bo=bo.to(DEV), ctx=ctx, rows_per_sample=HW, res0=tok, front_rows=Mt if pair else 0, x1=x1f), **common)()
+    # the chain
+    x1c = torch.empty((M, Cc), dtype=dt, device=DEV)
+    for hf in range(nb):
+        ops.linear(att, wod, x1c[hf * Mt:(hf + 1) * Mt], bo.to(DEV), residual=tok, rowvec=ctx[hf * B:(hf + 1) * B], rows_per_sample=HW)()
+    yc = torch.empty((M, Cc), dtype=dt, device=DEV)
+    ops.ffn_block(x1c, w1p.to(DEV), b1p.to(DEV), w2q, b2.to(DEV), yc, residual=x1c, **common)()
+    torch.cuda.synchronize()
+    d1 = (x1f.float() - x1c.float()).abs().max().item()
+    dy = (yf.float() - yc.float()).abs().max().item()
+    s1, sy = x1c.float().abs().max().item(), yc.float().abs().max().item()
+    print(f"to_out in front (B {B}, {hw}x{hw}, pair {pair}, {dt}): x1 vs chain max |d| {d1:.2e} at {s1:.1f}, block output {dy:.2e} at {sy:.1f}")
+    assert torch.isfinite(yf.float()).all()
+    assert d1 <= 2 * STEP[dt] * max(1.0, s1)          # same products, another order of the fp32 additions: a rounding boundary now and then
+    assert dy <= 16 * STEP[dt] * max(1.0, sy)
+
+
 @pytest.mark.parametrize("M,K0,Cc,N,geglu,res", [(4096, 320, 320, 960, False, False), (65536, 320, 320, 960, False, True), (16384, 640, 640, 5120, True, True),
                                                   (4096, 1280, 1280, 3840, False, True), (1000, 320, 320, 640, True, False),
                                                   (4096, 1280, 1280, 10240, True, True)])          # (the consumer is split along N: 2.5 rounds of 256 x 256 tiles)
