@@ -1,7 +1,7 @@
 #!/bin/bash
-# r06zz (final library, with rf_attn_in): the round's final evidence on ONE box for the final library -- GPU suite, smoke, rocprofv3 kernel stats + PMC traffic + matrix-pipe occupancy for configs[1] in bf16
+# r06final (final library: rf_attn_in + the out-projection in front of the tail kernel): the round's final evidence on ONE box for the final library -- GPU suite, smoke, rocprofv3 kernel stats + PMC traffic + matrix-pipe occupancy for configs[1] in bf16
 # and fp16, the per-launch profile table -> ceiling budget, the default bench line (with the PMC pass of this library matched by digest).
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; T=r06zz
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; T=r06final
 timeout 2400 python -m pytest tests/ -q -m gpu > gpurun_out/${T}_pytest_gpu.log 2>&1; tail -4 gpurun_out/${T}_pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${T}_smoke.log 2>&1; tail -1 gpurun_out/${T}_smoke.log
 EXTRA="" bash tools/profile_round.sh $T c1 2>&1 | tail -6
