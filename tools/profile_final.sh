@@ -1,7 +1,7 @@
 #!/bin/bash
-# r06final (final library: rf_attn_in + the out-projection in front of the tail kernel): the round's final evidence on ONE box for the final library -- GPU suite, smoke, rocprofv3 kernel stats + PMC traffic + matrix-pipe occupancy for configs[1] in bf16
+# tools/profile_final.sh <tag>: the round's final evidence on ONE box for the final library -- GPU suite, smoke, rocprofv3 kernel stats + PMC traffic + matrix-pipe occupancy for configs[1] in bf16
 # and fp16, the per-launch profile table -> ceiling budget, the default bench line (with the PMC pass of this library matched by digest).
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; T=r06final
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; T=${1:-rNNfinal}
 timeout 2400 python -m pytest tests/ -q -m gpu > gpurun_out/${T}_pytest_gpu.log 2>&1; tail -4 gpurun_out/${T}_pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${T}_smoke.log 2>&1; tail -1 gpurun_out/${T}_smoke.log
 EXTRA="" bash tools/profile_round.sh $T c1 2>&1 | tail -6

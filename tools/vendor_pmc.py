@@ -3,7 +3,7 @@
 DDIM step, under rocprofv3: the same plain bf16 GEMM  out[M, N] = x[M, K] W[N, K]^T + b  through both, `--reps` launches each, warm operands.
 
   rocprofv3 --kernel-trace --stats ...      -> durations, grid / workgroup / LDS / register footprint of both kernels
-  rocprofv3 --pmc <set> ...                 -> instruction and wait counters per launch (one pass per counter set: tools/run_r06b.sh)
+  rocprofv3 --pmc <set> ...                 -> instruction and wait counters per launch (one pass per counter set: tools/archive/run_r06b.sh)
   python tools/vendor_pmc.py --join DIR...  -> one table: counters per launch and per 1024 MFMA-FLOP-equivalents, ours vs the vendor's
 
 Run with --which ours|vendor|both so that a PMC pass can be attributed by kernel name (hipBLASLt's kernels are named Cijk_*)."""
