@@ -44,7 +44,7 @@ def make_tree(root, n, natural=False):
         Image.fromarray(lab).save(os.path.join(root, "CelebA-HQ-mask", "Overall_mask", f"{i}.png"))
 
 
-def worker(tree, outdir, batches, device_ms, B=8, legacy=False, world=1, png_level=None, gpu_prep=False, natural=False, aux_level=None):
+def worker(tree, outdir, batches, device_ms, B=8, legacy=False, world=1, png_level=None, gpu_prep=False, natural=False, aux_level=None, stage="both", loader_workers=4):
     import numpy as np
     import torch
     from reface_amd import output as O
@@ -54,7 +54,15 @@ def worker(tree, outdir, batches, device_ms, B=8, legacy=False, world=1, png_lev
     # the products run on the GPU, reface_amd/prep.py) -- the host half the CLI has with --gpu_prep
     from reface_amd.data import raw_collate
     ds = CelebAdataset(dataset_dir=tree, n_targets=batches * B, raw="full" if gpu_prep else False)
-    loader = torch.utils.data.DataLoader(ds, batch_size=B, num_workers=4, shuffle=False, collate_fn=raw_collate if gpu_prep else None)
+    loader = torch.utils.data.DataLoader(ds, batch_size=B, num_workers=loader_workers, shuffle=False, collate_fn=raw_collate if gpu_prep else None)
+    if stage == "writer":          # (--stage writer: the PNG half alone -- the same records submitted `batches` times, no reader)
+        class _NoReader:
+            def __iter__(self_):
+                ids = [f"{i:012d}" for i in range(B)]
+                tgt = torch.zeros((B, 3, 8, 8))
+                for _ in range(batches):
+                    yield (tgt, None, None, None, ids) if gpu_prep else (tgt, None, None, ids)
+        loader = _NoReader()
     [os.makedirs(os.path.join(outdir, d), exist_ok=True) for d in ("results", "grid", "samples")]
     # round 4: the panels / grid are composed on the GPU and arrive as ONE packed uint8 record per image; the writer's worker count is the
     # process's share of the host.  --legacy: the round-3 host half (fp32 panels composed on the host, 8 workers per process)
@@ -79,7 +87,9 @@ def worker(tree, outdir, batches, device_ms, B=8, legacy=False, world=1, png_lev
             target, prior, kw, ids = item
         t_host = time.perf_counter()
         time.sleep(device_ms / 1e3)                      # the device's share of the batch (sampling + decode are queued, the host is free)
-        if legacy and not gpu_prep:
+        if stage == "reader":          # (--stage reader: the decode / resize half alone)
+            pass
+        elif legacy and not gpu_prep:
             writer.submit(list(ids), pool_f[0][:target.shape[0]], target.float().numpy(), kw["inpaint_image"].float().numpy(),
                           kw["inpaint_mask"].float().numpy(), pool_f[1][:target.shape[0]])
         else:
@@ -106,11 +116,13 @@ def main():
     ap.add_argument("--natural", action="store_true", help="photo-like images in and out (smooth content + sensor noise) instead of uniform noise, the codecs' worst case")
     ap.add_argument("--gpu-prep", action="store_true", help="readers hand over uint8 arrays only (the CLI's --gpu_prep)")
     ap.add_argument("--png-level", type=int, default=None, help="zlib level of the PNG files (default: PIL's 6, the reference's files)")
+    ap.add_argument("--stage", default="both", choices=["both", "reader", "writer"], help="attribute the host half: the DataLoader readers alone, the PNG writer alone (run with --device-ms 0)")
+    ap.add_argument("--loader-workers", type=int, default=4, help="DataLoader worker processes per rank (reference: 4)")
     ap.add_argument("--aux-png-level", type=int, default=None, help="zlib level of the samples/ and grid/ files only (the CLI's --fast_aux_png = 1); results/ keeps --png-level")
     a = ap.parse_args()
     if a.worker:
         worker(a.worker[0], a.worker[1], a.batches, a.device_ms, legacy=a.legacy, world=a.world, png_level=a.png_level, gpu_prep=a.gpu_prep, natural=a.natural,
-               aux_level=a.aux_png_level)
+               aux_level=a.aux_png_level, stage=a.stage, loader_workers=a.loader_workers)
         return
     with tempfile.TemporaryDirectory() as tmp:
         tree = os.path.join(tmp, "CelebAMask-HQ")
@@ -118,7 +130,7 @@ def main():
         out = {}
         for n in (1, a.procs):
             extra = (["--legacy"] if a.legacy else []) + (["--png-level", str(a.png_level)] if a.png_level is not None else []) + (["--gpu-prep"] if a.gpu_prep else []) + (["--natural"] if a.natural else []) + \
-                    (["--aux-png-level", str(a.aux_png_level)] if a.aux_png_level is not None else [])
+                    (["--aux-png-level", str(a.aux_png_level)] if a.aux_png_level is not None else []) + ["--stage", a.stage, "--loader-workers", str(a.loader_workers)]
             ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", tree, os.path.join(tmp, f"out_{n}_{r}"), "--batches", str(a.batches),
                                     "--device-ms", str(a.device_ms), "--world", str(n)] + extra, stdout=subprocess.PIPE, text=True) for r in range(n)]
             rs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in ps]
@@ -131,6 +143,8 @@ def main():
             (", readers decode / resize only: --gpu_prep)" if a.gpu_prep else ")")
         out["content"] = "photo-like (smooth + sensor noise)" if a.natural else "uniform noise (worst case of JPEG decode and zlib)"
         out["device_ms_assumed"] = a.device_ms
+        out["stage"] = a.stage
+        out["loader_workers"] = a.loader_workers
         out["verdict"] = ("host half hides under the device time in all %d processes" % a.procs
                           if out[a.procs]["ms_per_batch_max"] < 1.05 * max(a.device_ms, out[1]["ms_per_batch_max"]) else
                           "host half EXCEEDS the device time with %d processes: scaling would be host-bound on this machine" % a.procs)
