@@ -24,9 +24,18 @@ template <> struct AttnMma<bf16_t> {
     __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
     }
+    // D = A B + C with C in registers of its own (C stays live: no copy in front of the MFMA)
+    __device__ static __forceinline__ f32x16_t mma_c(const u32x4_t& a, const u32x4_t& b, const f32x16_t& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
 };
 template <> struct AttnMma<f16_t> {
     __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) { mma16<f16_t>(acc, a, b); }
+    __device__ static __forceinline__ f32x16_t mma_c(const u32x4_t& a, const u32x4_t& b, const f32x16_t& c) {
+        f32x16_t r = c;
+        mma16<f16_t>(r, a, b);
+        return r;
+    }
 };
 template <> struct AttnMma<float> {
     __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
@@ -691,11 +700,19 @@ template <int OFF> __device__ __forceinline__ u32x2_t ds_read_tr16(const char* p
 // rows of O^T beyond the head dim multiply whatever follows the row and are never stored -- except rows 48..63, whose lanes read a
 // run of ones, so the MFMA also delivers the softmax denominator.  Every wave issues two or three of a tile's ten one-KiB pieces.
 // The running max moves only when a score exceeds it by 2^8 in the exp2 domain (P <= 256; the O rescale becomes rare).
+// d = 80 (round 6): the same stream with five whole k-steps and three O^T row blocks.  Nothing is padded in the head dim, so the softmax
+// reference point enters as the C operand of the first QK^T MFMA of a unit (a 16-register splat of -m_run per query block, rewritten only when
+// the reference moves) instead of riding in a padded k-slot; rows 80..95 of O^T read the run of ones (the denominator).  S twice + O + Q + the
+// splats are ~300 registers: ONE wave per SIMD (a 142 KB ring, one block per CU) -- the in-wave pipeline is what overlaps the two pipes here.
 template <typename T, int D, int KT>
-__global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, (D < 48 ? 2 : 1)) void attention_dma_kernel(const AttnParams p) {
     static_assert(sizeof(T) == 2, "16-bit operands (bf16 / fp16)");
-    static_assert(D > 32 && D < 48 && D % 8 == 0, "three 16-wide k-steps");
-    // KT keys per stage and barrier: 64 (ring of 7) or 128 (ring of 3; half the barriers) -- both ~70 KB, two blocks per CU
+    static_assert((D > 32 && D < 48 && D % 8 == 0) || D == 80, "three 16-wide k-steps with a padded slot, or five whole ones");
+    static_assert(D % 32 == 8 || D % 32 == 16, "the upper 16 rows of the last O^T row block are free for the denominator");
+    constexpr int QSTEPS = (D + 15) / 16;               // 16-wide k-steps of QK^T
+    constexpr bool PADK = D % 16 != 0;                  // the last k-step has a zero-padded lane half: -m_run rides there
+    constexpr int DVB = (D + 31) / 32;                  // 32-row blocks of O^T
+    // KT keys per stage and barrier: 64 (ring of 7) or 128 (ring of 3; half the barriers) -- both ~70 KB at d = 40, two blocks per CU
     constexpr int QB = 2, NU = KT / 32, NSTG = KT == 64 ? 7 : 3;
     constexpr int VPR = D / 8, KROW = D * 2;
     constexpr int K_BYTES = KT * KROW, STAGE = 2 * K_BYTES;
@@ -722,12 +739,12 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
     const T* V = (const T*)p.v + b * p.sv + h * D;
     T* O = (T*)p.out + b * p.so + h * D;
 
-    u32x4_t qf[QB][3];
+    u32x4_t qf[QB][QSTEPS];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const int qi = q0 + qb * 32 + lq;
 #pragma unroll
-        for (int st = 0; st < 3; ++st) {
+        for (int st = 0; st < QSTEPS; ++st) {
             const int c = st * 16 + lh * 8;
             u32x4_t v = {0u, 0u, 0u, 0u};
             if (qi < p.Nq && c < D) v = *(const u32x4_t*)(Q + (long long)qi * p.ldq + c);
@@ -772,9 +789,9 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
     };
 
     // ---- per-lane LDS offsets of the fragments (unit 0 of a stage)
-    int kfo[3];
+    int kfo[QSTEPS];
 #pragma unroll
-    for (int st = 0; st < 3; ++st) {
+    for (int st = 0; st < QSTEPS; ++st) {
         const int slot = st * 2 + lh;
         kfo[st] = lq * KROW + (slot < VPR ? slot : VPR - 1) * 16;
     }
@@ -784,14 +801,14 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
     // Rows 48..63 of O^T (lanes 16..31 of the second row block) have no V column: their reads go to the run of ones instead, so that
     // those rows of the MFMA accumulate sum_k P[k, q] -- the softmax denominator, at no VALU cost.
     const bool ones_lane = ((lane >> 4) & 1) != 0;
-    const char* const ones_ptr = smem + ONES_OFF - 64;
+    const char* const ones_ptr = smem + ONES_OFF - (DVB - 1) * 64;
     const char* const ones_k = smem + ONES_OFF;          // 16 bytes of ones: the K fragment of the padded k-slot (see m_run)
 
-    f32x16_t o[QB][2];
+    f32x16_t o[QB][DVB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < DVB; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[qb][i][r] = 0.f;
     // Softmax reference point m_run (exp2 domain; set from the first unit, afterwards only raised, and only when a score exceeds it
@@ -801,10 +818,15 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
     float m_run[QB] = {0.f, 0.f};
     constexpr float thr = 8.0f;
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16_t negm[PADK ? 1 : QB];                       // !PADK: -m_run of every query block as the C operand of a unit's first QK^T MFMA
+    negm[0] = zero16;
+    if constexpr (!PADK) negm[QB - 1] = zero16;
     const int ntiles = p.Nk / KT;                       // >= NSTG (dispatch)
 #pragma unroll
     for (int x = 0; x < NSTG - 1; ++x) dma_tile(x, x);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (d = 80: one block per CU, nobody else covers the fill -- start as soon as tile 0 is there; the loop's own wait covers tile 1)
+    if constexpr (!PADK && NSTG == 3 && NP % 4 == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP / 4) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     f32x16_t S[2][QB];
@@ -813,34 +835,50 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
     for (int qb = 0; qb < QB; ++qb) pf[qb][0] = pf[qb][1] = u32x4_t{0u, 0u, 0u, 0u};
     typedef short s16x4_t __attribute__((ext_vector_type(4)));
     // Fragments are read one region ahead of the MFMAs that use them (the LDS latency would otherwise sit in front of every group).
-    u32x4_t kf[3], vf[2][2];
+    u32x4_t kf[QSTEPS], vf[2][DVB];
 #define RF_LOAD_KF(sb, un)                                                                                      \
     {                                                                                                           \
-        _Pragma("unroll") for (int st = 0; st < 2; ++st) kf[st] = *(const u32x4_t*)((sb) + (un) * (32 * KROW) + kfo[st]);             \
-        kf[2] = *(const u32x4_t*)(lh ? ones_k : (sb) + (un) * (32 * KROW) + kfo[2]);                            \
+        _Pragma("unroll") for (int st = 0; st < QSTEPS - (PADK ? 1 : 0); ++st) kf[st] = *(const u32x4_t*)((sb) + (un) * (32 * KROW) + kfo[st]);             \
+        if constexpr (PADK) kf[QSTEPS - 1] = *(const u32x4_t*)(lh ? ones_k : (sb) + (un) * (32 * KROW) + kfo[QSTEPS - 1]);                            \
     }
 #define RF_LOAD_VF1(sb, un, g, i)                                                                               \
     {                                                                                                           \
-        const char* const vb = ((i) == 1 && ones_lane) ? ones_ptr : (sb) + vfo;                                 \
+        const char* const vb = ((i) == DVB - 1 && ones_lane) ? ones_ptr : (sb) + vfo;                           \
         const u32x2_t l2 = ds_read_tr16<((un) * 32 + (g) * 16) * KROW + (i) * 64>(vb);                          \
         const u32x2_t h2 = ds_read_tr16<((un) * 32 + (g) * 16 + 8) * KROW + (i) * 64>(vb);                      \
         vf[g][i] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};                                                         \
     }
-#define RF_LOAD_VF(sb, un) RF_LOAD_VF1(sb, un, 0, 0) RF_LOAD_VF1(sb, un, 0, 1) RF_LOAD_VF1(sb, un, 1, 0) RF_LOAD_VF1(sb, un, 1, 1)
-#define RF_WAIT_VF() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[1][0]), "+v"(vf[1][1]));
-#define RF_WAIT_KF() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]));
+#define RF_LOAD_VF(sb, un)                                                                                      \
+    {                                                                                                           \
+        RF_LOAD_VF1(sb, un, 0, 0) RF_LOAD_VF1(sb, un, 0, 1) RF_LOAD_VF1(sb, un, 1, 0) RF_LOAD_VF1(sb, un, 1, 1)   \
+        if constexpr (DVB == 3) { RF_LOAD_VF1(sb, un, 0, DVB - 1) RF_LOAD_VF1(sb, un, 1, DVB - 1) }             \
+    }
+#define RF_WAIT_VF()                                                                                            \
+    {                                                                                                           \
+        if constexpr (DVB == 3)                                                                                 \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[1][0]), "+v"(vf[1][1]), "+v"(vf[0][DVB - 1]), "+v"(vf[1][DVB - 1]));   \
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[1][0]), "+v"(vf[1][1]));                    \
+    }
+#define RF_WAIT_KF()                                                                                            \
+    {                                                                                                           \
+        if constexpr (QSTEPS == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[QSTEPS - 2]), "+v"(kf[QSTEPS - 1]));   \
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]));                      \
+    }
 #define RF_QK(dst)                                                                                              \
     {                                                                                                           \
-        _Pragma("unroll") for (int st = 0; st < 3; ++st)                                                        \
+        _Pragma("unroll") for (int st = 0; st < QSTEPS; ++st)                                                   \
             _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) {                                                 \
-                if (st == 0) dst[qb] = zero16;                                                                  \
-                AttnMma<T>::mma(dst[qb], kf[st], qf[qb][st]);                                                   \
+                if (st == 0 && !PADK) dst[qb] = AttnMma<T>::mma_c(kf[st], qf[qb][st], negm[PADK ? 0 : qb]);      \
+                else {                                                                                          \
+                    if (st == 0) dst[qb] = zero16;                                                              \
+                    AttnMma<T>::mma(dst[qb], kf[st], qf[qb][st]);                                               \
+                }                                                                                               \
             }                                                                                                   \
     }
 #define RF_PV()                                                                                                 \
     {                                                                                                           \
         _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                           \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                       \
+            _Pragma("unroll") for (int i = 0; i < DVB; ++i)                                                     \
                 _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) AttnMma<T>::mma(o[qb][i], vf[g][i], pf[qb][g]);                    \
     }
     RF_LOAD_KF(smem, 0)
@@ -886,17 +924,22 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
                 for (int qb = 0; qb < QB; ++qb) {
                     // new reference: this unit's max (the first unit may also lower it), rounded UP to a value of the operand type
                     const float target = m_run[qb] + ((t == 0 && uu == 0) ? mx[qb] : fmaxf(mx[qb], 0.f));
-                    const float m_new = ceil16<T>(target);
+                    const float m_new = PADK ? ceil16<T>(target) : target;
                     const float delta = m_new - m_run[qb];
                     const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < DVB; ++i)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) o[qb][i][r] *= alpha;
                     m_run[qb] = m_new;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) cur[qb][r] -= delta;          // this unit's scores were taken against the old reference
-                    if (lh) qf[qb][2][0] = bits16<T>(-m_new);                     // lane half 1 of k-step 2: [-m_run, 0, ...] (exact: a value of T)
+                    if constexpr (PADK) {
+                        if (lh) qf[qb][QSTEPS - 1][0] = bits16<T>(-m_new);       // lane half 1 of the last k-step: [-m_run, 0, ...] (exact: a value of T)
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) negm[PADK ? 0 : qb][r] = -m_new;
+                    }
                 }
             }
             // ---- region 2: QK^T of the next unit beside exp2 / pack of this one
@@ -935,12 +978,12 @@ __global__ __launch_bounds__(256, 2) void attention_dma_kernel(const AttnParams 
 #undef RF_PV
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const float l_tot = __shfl(o[qb][1][8], lq, 64);          // row 48 of O^T: lane half 0, register 8
+        const float l_tot = __shfl(o[qb][DVB - 1][8], lq, 64);          // row 48 (d = 80: 80) of O^T: lane half 0, register 8 of the last row block
         const float inv = 1.0f / l_tot;
         const int qi = q0 + qb * 32 + lq;
         if (qi < p.Nq) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < DVB; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int dv = i * 32 + 8 * g + 4 * lh;
@@ -1012,6 +1055,9 @@ static int launch_attn(const AttnParams& p, int B, hipStream_t st) {
     // 73 us against 85 at N = 1024 (tools/archive/run_r04x.sh: 64-key stages with 8 waves 85, 128-key stages with 4 waves 105, two query blocks per wave 81-99).
     // d = 160 keeps the 4-wave / 64-key form (N = 256: four stages of 64 keys already cover the sequence).
     if constexpr (sizeof(T) == 2 && D == 80) {
+        // whole 128-key tiles: the in-wave software-pipelined kernel, one wave per SIMD (RF_ATTN_PIPE80=0 in experiment builds: the generic one)
+        static const int pipe80 = tune_env("RF_ATTN_PIPE80", 1);
+        if (pipe80 && p.Nk % 128 == 0 && p.Nk >= 384) return launch_attn_dma<T, D, 128>(p, B, st);
         if (p.Nk >= 512 && (long long)((p.Nq + 255) / 256) * B * p.heads >= 256) return launch_attn_qb<T, D, 1, 128, 8>(p, B, st);
     }
     return launch_attn_qb<T, D, 1>(p, B, st);

@@ -90,15 +90,32 @@ def record_layout(H, W, with_grid=True):
     return nbytes, lay
 
 
-def default_writer_threads(world=1):
-    """PNG-encode workers per process: the encodes of one batch must finish inside a batch time, but N processes x 8 workers x 4 loader
-    processes on one node is what the 8-process probe measured as contention (tools/host_scaling_probe.py) -- bound the workers by the
-    process's share of the host: cpus / (world * 6), between 2 and 8."""
+def available_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the container's CFS quota (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us`).  The GPU
+    boxes of the test pool show 256 CPUs in the mask under a quota of 16 (`profiles/r06i_host_half_stages.txt`): sizing pools by the mask alone
+    oversubscribes the quota and every thread is throttled."""
     try:
         cpus = len(os.sched_getaffinity(0))
     except AttributeError:
         cpus = os.cpu_count() or 8
-    return max(2, min(8, cpus // (max(1, world) * 6)))
+    try:
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        else:
+            quota = open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read().strip()
+            period = open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+        if quota != "max" and int(quota) > 0:
+            cpus = min(cpus, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return cpus
+
+
+def default_writer_threads(world=1):
+    """PNG-encode workers per process.  One job is ONE file (48 per batch of 8), so idle workers cost nothing and what bounds the count is the
+    process's share of the host next to its 4 loader processes: available_cpus() / (world * 2), between 2 and 8 (16 CPUs per rank, what a GPU slot
+    of the test pool gets: 8 workers; with 5 workers and one job per IMAGE a batch of 8 took two rounds of the slowest image)."""
+    return max(2, min(8, available_cpus() // (max(1, world) * 2)))
 
 
 def paths(outdir, sid):
@@ -108,11 +125,16 @@ def paths(outdir, sid):
             "inpaint": os.path.join(s, sid + "_inpaint.png"), "ref": os.path.join(s, sid + "_ref.png")}
 
 
+# files of one image, most expensive encode first (results/ at the reference's zlib level, then the 4-panel grid, then the panels): the jobs of a
+# batch are queued in this order ACROSS its images, so the long encodes start first and the short ones fill the workers' tails
+ENCODE_ORDER = ("result", "grid", "GT", "inpaint", "ref", "mask")
+
+
 class OutputWriter:
     """PNG encoding off the launch thread: ``submit`` takes host arrays of one batch and returns at once; ``close`` drains."""
 
     def __init__(self, outdir, skip_grid=False, depth=4, threads=8, compress_level=None, aux_compress_level=None):
-        # One job per IMAGE, `threads` workers: the six PNG encodes of an image are ~0.3 s of zlib on incompressible content (zlib runs
+        # One job per FILE, `threads` workers: the six PNG encodes of an image are ~0.3 s of zlib on incompressible content (zlib runs
         # outside the GIL), so a single worker caps the CLI at ~3 images/s -- below one MI355X (tools/host_scaling_probe.py: 2.86 s per
         # batch of 8 with one worker against 0.9 s of device time)
         self.outdir, self.skip_grid = outdir, skip_grid
@@ -122,9 +144,10 @@ class OutputWriter:
         # compares with the reference's -- keeps `compress_level`
         self.save_kw = {} if compress_level is None else {"compress_level": int(compress_level)}
         self.aux_kw = self.save_kw if aux_compress_level is None else {"compress_level": int(aux_compress_level)}
-        self.q = queue.Queue(maxsize=depth * 8)
+        self.q = queue.Queue(maxsize=depth * 8 * len(ENCODE_ORDER))
         self.err = None
-        self.n = 0
+        self.n = 0                 # images whose files are all on disk
+        self.left = {}             # image id -> files still to write
         self.lock = threading.Lock()
         self.ts = [threading.Thread(target=self._run, daemon=True) for _ in range(max(1, threads))]
         for t in self.ts:
@@ -137,23 +160,48 @@ class OutputWriter:
             if job is None:
                 return
             try:
-                if len(job) == 3:          # a packed uint8 record composed on the device: only slicing and PNG encoding are left
-                    sid, rec, lay = job
-                    arrs = {k: rec[o:o + int(np.prod(shp))].reshape(shp) for k, (o, shp) in lay.items()}
-                else:
-                    sid, res, tgt, inp, msk, ref = job
-                    arrs = compose(res, tgt, inp, msk, ref, skip_grid=self.skip_grid)
-                p = paths(self.outdir, sid)
-                for k, a in arrs.items():
-                    Image.fromarray(a).save(p[k], **(self.save_kw if k == "result" else self.aux_kw))
-                with self.lock:
-                    self.n += 1
+                if len(job) == 6:          # float panels of one image (the host-composed path): compose here, off the launch thread, then
+                    sid = job[0]           # hand the files to whoever is free -- or encode them here when the queue is full (never block a worker)
+                    arrs = compose(*job[1:], skip_grid=self.skip_grid)
+                    todo = [(sid, k, arrs[k], paths(self.outdir, sid)[k]) for k in ENCODE_ORDER if k in arrs]
+                    with self.lock:
+                        self.left[sid] = self.left.get(sid, 0) + len(todo) - 1
+                    for j in todo[1:]:
+                        try:
+                            self.q.put_nowait(j)
+                        except queue.Full:
+                            self._encode(Image, *j)
+                    job = todo[0]
+                self._encode(Image, *job)
             except Exception as e:          # surfaced on the next submit / close
                 self.err = e
+            finally:
+                self.q.task_done()
+
+    def _encode(self, Image, sid, key, arr, path):
+        Image.fromarray(arr).save(path, **(self.save_kw if key == "result" else self.aux_kw))
+        with self.lock:
+            self.left[sid] -= 1
+            if self.left[sid] == 0:
+                del self.left[sid]
+                self.n += 1
+
+    def _enqueue(self, per_image):
+        """per_image: [(sid, {name: uint8 HWC array})] of one batch -> one job per file, long encodes first."""
+        with self.lock:
+            for sid, arrs in per_image:
+                self.left[sid] = self.left.get(sid, 0) + len(arrs)
+        for key in ENCODE_ORDER:
+            for sid, arrs in per_image:
+                if key in arrs:
+                    self.q.put((sid, key, arrs[key], paths(self.outdir, sid)[key]))
 
     def submit(self, ids, result01, target, inpaint_image, inpaint_mask, ref512):
         if self.err is not None:
             raise self.err
+        with self.lock:
+            for sid in ids:
+                self.left[sid] = self.left.get(sid, 0) + 1          # the compose job itself; the worker adds the image's files
         for i, sid in enumerate(ids):
             self.q.put((sid, result01[i], target[i], inpaint_image[i], inpaint_mask[i], ref512[i]))
 
@@ -163,10 +211,14 @@ class OutputWriter:
         if self.err is not None:
             raise self.err
         _, lay = record_layout(H, W, with_grid=not self.skip_grid)
+        per_image = []
         for i, sid in enumerate(ids):
-            self.q.put((sid, np.array(records[i], copy=True), lay))
+            rec = np.array(records[i], copy=True)
+            per_image.append((sid, {k: rec[o:o + int(np.prod(shp))].reshape(shp) for k, (o, shp) in lay.items()}))
+        self._enqueue(per_image)
 
     def close(self):
+        self.q.join()              # (a compose job queues its files before it is done: nothing is behind the sentinels)
         for _ in self.ts:
             self.q.put(None)
         for t in self.ts:

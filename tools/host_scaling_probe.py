@@ -137,6 +137,8 @@ def main():
             out[n] = {"ms_per_batch_max": max(r["ms_per_batch"] for r in rs), "ms_per_batch_mean": sum(r["ms_per_batch"] for r in rs) / n,
                       "host_ms_on_launch_thread_max": max(r["host_ms_on_launch_thread"] for r in rs)}
         out["cpus"] = len(os.sched_getaffinity(0))
+        from reface_amd.output import available_cpus
+        out["cpus_under_cgroup_quota"] = available_cpus()          # what the container may really use (the mask alone says 256 on the test pool's boxes, the quota 16)
         out["host_half"] = "round 3 (fp32 panels composed on the host, 8 PNG workers)" if a.legacy else \
             f"round 4 (packed uint8 records from the device, PNG workers = share of the host, zlib level {a.png_level if a.png_level is not None else 6}" + \
             (f" for results/, {a.aux_png_level} for samples/ + grid/" if a.aux_png_level is not None else "") + \
