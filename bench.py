@@ -108,18 +108,21 @@ def cpu_baseline(cpu_sd, cores):
     from oracle import unet as ounet, vae as ovae
     from reface_amd import params as P
     # pick the thread count that is actually fastest on this host (all logical CPUs oversubscribe badly)
+    from reface_amd.output import available_cpus
+    quota = available_cpus()          # the container's CFS quota (the test pool: 16 under a 256-CPU affinity mask): sustained work gets this many CPUs
     best, best_t, probe = cores, float("inf"), {}
     xs, ws = torch.randn(2, 320, 64, 64), torch.randn(320, 320, 3, 3)
-    for n in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8), 32, 16, 8}):
+    for n in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8), 32, 16, 8, quota}):
         if n > cores:
             continue
         torch.set_num_threads(n)
         torch.nn.functional.conv2d(xs, ws, padding=1)
-        t0 = time.time()
-        for _ in range(3):
+        t0, k = time.time(), 0
+        while k < 3 or time.time() - t0 < 0.4:          # >= 4 quota periods per candidate: a burst of a few ms is not throttled, the baseline's seconds are
             torch.nn.functional.conv2d(xs, ws, padding=1)
-        dt = time.time() - t0
-        probe[str(n)] = round(dt / 3 * 1e3, 2)
+            k += 1
+        dt = (time.time() - t0) / k
+        probe[str(n)] = round(dt * 1e3, 2)
         if dt < best_t:
             best, best_t = n, dt
     cores = best
@@ -142,8 +145,8 @@ def cpu_baseline(cpu_sd, cores):
         ovae.decode_first_stage(vsd, vcfg, z)
         t_dec = time.time() - t0
     ips = 1.0 / (50 * t_step + t_dec)
-    return {"value": ips, "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-            "thread_probe_ms": probe, "thread_probe_note": "ms per 3x3 conv (2 x 320 x 64 x 64 -> 320) by torch thread count; the fastest count is the one used",
+    return {"value": ips, "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(), "cpus_under_cgroup_quota": quota,
+            "thread_probe_ms": probe, "thread_probe_note": "ms per 3x3 conv (2 x 320 x 64 x 64 -> 320) by torch thread count, each count sustained for >= 0.4 s; the fastest count is the one used",
             "sample": f"B=1: 2 CFG DDIM steps (UNet batch 2, latent 64x64) = {ts[0]:.2f}s / {ts[1]:.2f}s, the faster scaled x50, + 1 fp32 VAE decode 512x512 = {t_dec:.2f}s"}
 
 

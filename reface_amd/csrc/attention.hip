@@ -734,12 +734,17 @@ __global__ __launch_bounds__(256, (D < 48 ? 2 : 1)) void attention_dma_kernel(co
     const int bh = bid / p.nqb, qblk = bid - bh * p.nqb;
     const int b = bh / p.heads, h = bh % p.heads;
     const int q0 = qblk * (4 * 32 * QB) + wave * (32 * QB);
+#ifdef RF_ATTN_STAMP          // (experiment builds: cycle stamps of the kernel's phases, written over the first output row of every wave -- tools/archive/attn_stamp.py)
+    long long stamp_[5];
+    stamp_[0] = __builtin_readcyclecounter();
+#endif
     const T* Q = (const T*)p.q + b * p.sq + h * D;
     const T* K = (const T*)p.k + b * p.sk + h * D;
     const T* V = (const T*)p.v + b * p.sv + h * D;
     T* O = (T*)p.out + b * p.so + h * D;
 
     u32x4_t qf[QB][QSTEPS];
+    auto load_q = [&]() {
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const int qi = q0 + qb * 32 + lq;
@@ -761,8 +766,16 @@ __global__ __launch_bounds__(256, (D < 48 ? 2 : 1)) void attention_dma_kernel(co
             qf[qb][st] = v;
         }
     }
+    };
+    if constexpr (PADK) load_q();
 
-    for (int i = tid; i < ONES_BYTES / 4; i += 256) ((uint32_t*)(smem + ONES_OFF))[i] = (uint32_t)one16<T>() * 0x10001u;
+    if constexpr (PADK) {
+        for (int i = tid; i < ONES_BYTES / 4; i += 256) ((uint32_t*)(smem + ONES_OFF))[i] = (uint32_t)one16<T>() * 0x10001u;
+    } else {
+        static_assert(ONES_BYTES % 16 == 0, "whole 16-byte writes");
+        const uint32_t o2 = (uint32_t)one16<T>() * 0x10001u;
+        for (int i = tid; i < ONES_BYTES / 16; i += 256) ((u32x4_t*)(smem + ONES_OFF))[i] = u32x4_t{o2, o2, o2, o2};
+    }
     // ---- staging: tile X is issued by wave X % 4
     const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, (unsigned)((((long long)p.Nk - 1) * p.ldk + D) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, (unsigned)((((long long)p.Nk - 1) * p.ldv + D) * 2), 0x00020000);
@@ -822,11 +835,19 @@ __global__ __launch_bounds__(256, (D < 48 ? 2 : 1)) void attention_dma_kernel(co
     negm[0] = zero16;
     if constexpr (!PADK) negm[QB - 1] = zero16;
     const int ntiles = p.Nk / KT;                       // >= NSTG (dispatch)
+    if constexpr (PADK) {
 #pragma unroll
-    for (int x = 0; x < NSTG - 1; ++x) dma_tile(x, x);
-    // (d = 80: one block per CU, nobody else covers the fill -- start as soon as tile 0 is there; the loop's own wait covers tile 1)
-    if constexpr (!PADK && NSTG == 3 && NP % 4 == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP / 4) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int x = 0; x < NSTG - 1; ++x) dma_tile(x, x);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        // d = 80: one block per CU, nobody else covers the fill.  Tile 0 goes out first, the Q rows behind it, tile 1 last: "at most tile 1's pieces
+        // outstanding" then says tile 0 AND Q have arrived (whether or not this wave had Q rows to load); the loop's own wait covers tile 1.
+        static_assert(NSTG == 3 && NP % 4 == 0, "two tiles in the prologue, whole pieces per wave");
+        dma_tile(0, 0);
+        load_q();
+        dma_tile(1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP / 4) : "memory");
+    }
     __syncthreads();
 
     f32x16_t S[2][QB];
@@ -881,6 +902,9 @@ __global__ __launch_bounds__(256, (D < 48 ? 2 : 1)) void attention_dma_kernel(co
             _Pragma("unroll") for (int i = 0; i < DVB; ++i)                                                     \
                 _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) AttnMma<T>::mma(o[qb][i], vf[g][i], pf[qb][g]);                    \
     }
+#ifdef RF_ATTN_STAMP
+    stamp_[1] = __builtin_readcyclecounter();
+#endif
     RF_LOAD_KF(smem, 0)
     RF_WAIT_KF()
     RF_QK(S[0])
@@ -926,7 +950,8 @@ __global__ __launch_bounds__(256, (D < 48 ? 2 : 1)) void attention_dma_kernel(co
                     const float target = m_run[qb] + ((t == 0 && uu == 0) ? mx[qb] : fmaxf(mx[qb], 0.f));
                     const float m_new = PADK ? ceil16<T>(target) : target;
                     const float delta = m_new - m_run[qb];
-                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    // (delta < 0 only when the first unit lowers the reference: O is still zero there, and 2^-delta overflows for scores below -128)
+                    const float alpha = __builtin_amdgcn_exp2f(fminf(-delta, 0.f));
 #pragma unroll
                     for (int i = 0; i < DVB; ++i)
 #pragma unroll
@@ -966,7 +991,13 @@ __global__ __launch_bounds__(256, (D < 48 ? 2 : 1)) void attention_dma_kernel(co
             unit(std::integral_constant<int, 3>{});
         }
         sc = sn;
+#ifdef RF_ATTN_STAMP
+        if (t == 0) stamp_[2] = __builtin_readcyclecounter();
+#endif
     }
+#ifdef RF_ATTN_STAMP
+    stamp_[3] = __builtin_readcyclecounter();
+#endif
     RF_WAIT_VF()
     RF_PV()
 #undef RF_WAIT_VF
@@ -981,7 +1012,25 @@ __global__ __launch_bounds__(256, (D < 48 ? 2 : 1)) void attention_dma_kernel(co
         const float l_tot = __shfl(o[qb][DVB - 1][8], lq, 64);          // row 48 (d = 80: 80) of O^T: lane half 0, register 8 of the last row block
         const float inv = 1.0f / l_tot;
         const int qi = q0 + qb * 32 + lq;
-        if (qi < p.Nq) {
+        if constexpr (!PADK) {
+            // 16-byte stores: the two lane halves of a query hold columns 8 g + {0..3} and 8 g + {4..7}; one v_permlane32_swap per dword hands lane half 0
+            // the whole group g (even), lane half 1 the whole group g + 1 -- half the store instructions, 32 contiguous bytes per row and instruction
+#pragma unroll
+            for (int i = 0; i < DVB; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    uint32_t w[2][2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        w[k][0] = pack2<T>(o[qb][i][4 * (g + k)] * inv, o[qb][i][4 * (g + k) + 1] * inv);
+                        w[k][1] = pack2<T>(o[qb][i][4 * (g + k) + 2] * inv, o[qb][i][4 * (g + k) + 3] * inv);
+                    }
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);          // [0]: group g (lh 0) / g + 1's low half from below (lh 1)
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+                    const int dv = i * 32 + 8 * (g + lh);
+                    if (qi < p.Nq && dv < D) *(u32x4_t*)(O + (long long)qi * p.ldo + dv) = u32x4_t{s0[0], s1[0], s0[1], s1[1]};
+                }
+        } else if (qi < p.Nq) {
 #pragma unroll
             for (int i = 0; i < DVB; ++i)
 #pragma unroll
@@ -996,6 +1045,16 @@ __global__ __launch_bounds__(256, (D < 48 ? 2 : 1)) void attention_dma_kernel(co
                 }
         }
     }
+#ifdef RF_ATTN_STAMP
+    stamp_[4] = __builtin_readcyclecounter();
+    if (lane == 0 && q0 < p.Nq) {
+        int* const dst = (int*)(O + (long long)q0 * p.ldo);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = (int)(stamp_[i + 1] - stamp_[i]);
+        dst[4] = (int)(stamp_[0] & 0x7fffffff);
+    }
+#endif
 }
 
 template <typename T, int D, int KT>

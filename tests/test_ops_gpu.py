@@ -296,13 +296,16 @@ def _attn_ref(qr, kr, vr, heads, d, scale):
     return (att @ sp(vr, Nk)).transpose(1, 2).reshape(B, Nq, heads * d).float()
 
 
-@pytest.mark.parametrize("Nq,Nk,mode", [(4096, 4096, "plain"), (4000, 1088, "plain"), (3900, 1024, "hot"), (4096, 1152, "cold"), (4096, 1024, "late")])
+@pytest.mark.parametrize("d,Nq,Nk,mode", [(40, 4096, 4096, "plain"), (40, 4000, 1088, "plain"), (40, 3900, 1024, "hot"), (40, 4096, 1152, "cold"), (40, 4096, 1024, "late"),
+                                          (80, 1024, 1024, "plain"), (80, 1000, 1152, "plain"), (80, 900, 1024, "hot"), (80, 1024, 384, "cold"), (80, 1024, 1024, "late"),
+                                          (80, 2304, 2304, "plain"), (80, 70, 512, "hot"), (40, 4096, 1024, "frozen"), (80, 1024, 1024, "frozen")])
 @pytest.mark.parametrize("dt", H16)
-def test_attention_d40_pipelined_kernel(Nq, Nk, mode, dt):
-    """attention_dma_kernel (bf16, d = 40, Nk a multiple of 64 >= 1024, grid >= 512 blocks): ragged query count, a key count that is not
-    a multiple of 128, scores far above 2^8 in the exp2 domain (the thresholded running max must move, more than once), scores that
-    are all very negative (the first unit has to LOWER the reference point from 0) and a dominant key in the last tile."""
-    B, heads, d = 4, 8, 40
+def test_attention_pipelined_kernels(d, Nq, Nk, mode, dt):
+    """attention_dma_kernel (16-bit; d = 40 with Nk a multiple of 64 >= 1024 and a grid >= 512 blocks, d = 80 with Nk a multiple of 128 >= 384): ragged
+    query counts, a key count that is not a multiple of 128, the shortest ring (3 tiles), scores far above 2^8 in the exp2 domain (the thresholded running
+    max must move, more than once), scores that are all very negative (the first unit has to LOWER the reference point from 0) and a dominant key in the
+    last tile.  d = 40 carries the reference point in a padded k-slot of Q, d = 80 as the C operand of a unit's first QK^T MFMA."""
+    B, heads = 4, 8
     Cc = heads * d
     qx, kx, vx = rnd((B, Nq, Cc), 41), rnd((B, Nk, Cc), 42), rnd((B, Nk, Cc), 43)
     scale = d ** -0.5
@@ -312,9 +315,10 @@ def test_attention_d40_pipelined_kernel(Nq, Nk, mode, dt):
         # perturbation of the logits that peaked softmaxes turn into percent-level differences (covered by "plain" at unit variance)
         qx *= 2.5 * 2.5 * scale * ops.LOG2E
         scale = ops.LN2
-    elif mode == "cold":
-        kx = -qx[:, :1].repeat(1, Nk, 1) * 3.0 + 0.1 * kx     # every key anti-aligned with query 0 ...
-        qx = qx[:, :1].repeat(1, Nq, 1) * 3.0 + 0.1 * qx      # ... and every query close to it: all scores << 0
+    elif mode in ("cold", "frozen"):
+        f = 3.0 if mode == "cold" else 5.0                   # "frozen": every score below -128 in the exp2 domain (2^-delta of the first unit's move overflows fp32)
+        kx = -qx[:, :1].repeat(1, Nk, 1) * f + 0.1 * kx       # every key anti-aligned with query 0 ...
+        qx = qx[:, :1].repeat(1, Nq, 1) * f + 0.1 * qx        # ... and every query close to it: all scores << 0
     elif mode == "late":
         kx[:, Nk - 3] = qx[:, 7] * 4.0                       # one key of the last tile dominates query 7
     qd, qr = q(qx, dt)

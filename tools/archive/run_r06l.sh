@@ -1,0 +1,7 @@
+#!/bin/bash
+# r06l: d = 80 self-attention on the in-wave pipelined kernel (one wave per SIMD) against the generic 8-wave kernel: tests, isolated launch time, whole bench A/B
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r06l; O=gpurun_out/r06l
+timeout 900 python -m pytest tests/test_ops_gpu.py -q -x -k "attention" > $O/pytest_attention.log 2>&1; tail -3 $O/pytest_attention.log
+export REFACE_HIP_LIB=$PWD/reface_amd/lib/alt/a80.so
+for v in 0 1 0 1; do echo "RF_ATTN_PIPE80=$v"; RF_ATTN_PIPE80=$v python tools/bench_gemm.py --only "attn d80" --cold 1 --reps 30 2>/dev/null | tail -1; RF_ATTN_PIPE80=$v python tools/bench_gemm.py --only "attn d80" --reps 50 2>/dev/null | tail -1; done | tee $O/attn_d80_isolated.txt
+bash tools/abenv.sh "RF_ATTN_PIPE80=0" "RF_ATTN_PIPE80=1" "RF_ATTN_PIPE80=0" "RF_ATTN_PIPE80=1" | tee $O/ab_c1.txt
