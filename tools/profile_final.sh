@@ -12,4 +12,7 @@ timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-conditio
 python tools/ceiling_budget.py gpurun_out/${T}_c1_profile.json > gpurun_out/${T}_c1_ceiling_budget.txt; tail -14 gpurun_out/${T}_c1_ceiling_budget.txt
 # the committed PMC pass must carry this library's digest for bench.py to report it: copy it where bench.py looks BEFORE the default line is taken
 cp gpurun_out/${T}_c1_traffic.json profiles/${T}_c1_pmc_hbm_traffic.json
+cp gpurun_out/${T}_c1h_traffic.json profiles/${T}_c1h_pmc_hbm_traffic.json
+# ... and the traffic passes of the other configurations the default line reports (configs[3], configs[4] in both fp8 forms)
+for c in c3 c4 c4c; do bash tools/pmc_traffic.sh ${T}_$c $c 2>&1 | tail -2; cp gpurun_out/${T}_${c}_traffic.json profiles/${T}_${c}_pmc_hbm_traffic.json; rm -rf gpurun_out/${T}_${c}_pmc_FETCH_SIZE gpurun_out/${T}_${c}_pmc_WRITE_SIZE; done
 timeout 1800 python3 bench.py --steps 5 --warmup 2 > gpurun_out/${T}_default_bench.json 2> gpurun_out/${T}_default_bench.log; tail -8 gpurun_out/${T}_default_bench.log
