@@ -278,7 +278,9 @@ def pmc_traffic(family, workload):
                 d = json.load(f)
             meta = d.get("_meta", {})
             fam = d.get(family)
-            if meta.get("workload") != workload or fam is None:
+            # (a pass collected with `tools/pmc_traffic.sh <tag> c1h|c4c` before round 6's last call stamped the CONFIG KEY where the bench line's id names the BASELINE config)
+            wl = re.sub(r"^c1h:", "c1:", re.sub(r"^c4c:", "c4:", meta.get("workload") or ""))
+            if wl != workload or fam is None:
                 continue
             val = fam["hbm_read_bytes_per_launch"] + fam["hbm_write_bytes_per_launch_uncalibrated"]
             if family.startswith("rf_conv_gemm"):

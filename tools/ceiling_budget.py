@@ -6,8 +6,8 @@
                                                                                    hipBLASLt on 16384 x 640 x 5760, profiles/r04k_vs_vendor_libraries.txt)
                                                                           BW     = 6.5 TB/s      (what L2 misses are served at, tools/fill_probe.py)
                                                                           T_launch = 3 us        (launch + prologue + epilogue drain of a one-round grid)
-                                                                          R_exp  = 9.8e12 / s    (attention only: one v_exp_f32 per score, 16 lanes per SIMD
-                                                                                   and clock at the transcendental unit's quarter rate -- the d = 40 kernel's bound)
+                                                                          R_exp  = 1.97e13 / s   (attention only: one v_exp_f32 per score at 8 cycles per wave instruction --
+                                                                                   tools/exp_probe.py: 40 cycles per 4; never the larger term: the attention floors are FLOP floors)
 
 against the measured time, and the sum of the floors = the whole-step time THIS DESIGN (this launch list, these algebraic reductions) could reach if every
 kernel ran at the best rate seen on the chip -- and the MFMA utilisation that would be, priced like bench.py prices `unet_mfma_util_*` (reference FLOP count
@@ -23,7 +23,7 @@ ap.add_argument("--bw", type=float, default=6.5e12)
 ap.add_argument("--tlaunch", type=float, default=3e-6)
 ap.add_argument("--alg-flop", type=float, default=2 * 8 * 796.94e9, help="reference FLOP of one UNet evaluation on the CFG batch (bench.py F_UNET x 2B)")
 ap.add_argument("--peak", type=float, default=2.5e15)
-ap.add_argument("--exp-rate", type=float, default=1024 * 4 * 2.4e9, help="v_exp_f32 per second of the chip: 1024 SIMDs x 16 lanes per clock at quarter rate x 2.4 GHz")
+ap.add_argument("--exp-rate", type=float, default=1024 * 8 * 2.4e9, help="v_exp_f32 per second of the chip: 1024 SIMDs x 64 lanes / 8 cycles per instruction x 2.4 GHz")
 a = ap.parse_args()
 rows = json.load(open(a.profile))["step_launches"]
 cls = collections.OrderedDict()

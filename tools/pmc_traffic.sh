@@ -39,7 +39,7 @@ sys.path.insert(0, ".")
 import bench
 c = bench.CONFIGS["$cfg"]
 import time
-out["_meta"] = {"collected_unix": time.time(), "lib_digest": bench.lib_digest(), "workload": "$cfg:%dx%d:S50:B%d:%s" % (8 * c["latent"], 8 * c["latent"], c["batch"], ("$EXTRA".split("--dtype ")[1].split()[0] if "--dtype " in "$EXTRA" else c["dtype"])),
+out["_meta"] = {"collected_unix": time.time(), "lib_digest": bench.lib_digest(), "workload": "%s:%dx%d:S50:B%d:%s" % ({"c4c": "c4", "c1h": "c1"}.get("$cfg", "$cfg"), 8 * c["latent"], 8 * c["latent"], c["batch"], ("$EXTRA".split("--dtype ")[1].split()[0] if "--dtype " in "$EXTRA" else c["dtype"])),
                 "command": "tools/pmc_traffic.sh ${tag} $cfg (REFACE_NO_GRAPH=1, --steps 1 --warmup 0: one batch of eager launches per PMC pass)"}
 json.dump(out, open("gpurun_out/${tag}_traffic.json", "w"), indent=1)
 for k, v in sorted(((k, v) for k, v in out.items() if k != "_meta"), key=lambda kv: -kv[1].get("FETCH_SIZE_KB_raw_total", 0)):
