@@ -688,3 +688,27 @@ def test_e4m3_numpy_reference_is_self_consistent():
     # and it agrees with torch's own float8_e4m3fn cast on 100 k random values over 7 decades (finite range)
     x = (torch.randn(100000, generator=torch.Generator().manual_seed(5)) * torch.logspace(-4, 2.6, 100000)).clamp(-448, 448)
     assert np.array_equal(e4m3fn_encode_rne_sat_np(x.numpy()), x.to(torch.float8_e4m3fn).view(torch.uint8).numpy())
+
+
+def test_worker_pools_are_sized_by_the_cgroup_quota(tmp_path, monkeypatch):
+    """reface_amd/output.available_cpus: the affinity mask capped by the container's CFS quota (the GPU boxes of the test pool: 256 CPUs in the mask, a quota of 16 --
+    profiles/r06i_host_half_stages.txt); default_writer_threads is that share / (2 x world), between 2 and 8."""
+    import builtins
+    import os
+    from reface_amd import output as O
+    n = O.available_cpus()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    real_open, real_exists = builtins.open, os.path.exists
+    f = tmp_path / "cpu.max"
+
+    def fake_open(path, *a, **k):
+        return real_open(str(f), *a, **k) if path == "/sys/fs/cgroup/cpu.max" else real_open(path, *a, **k)
+    monkeypatch.setattr(os.path, "exists", lambda p: True if p == "/sys/fs/cgroup/cpu.max" else real_exists(p))
+    monkeypatch.setattr(builtins, "open", fake_open)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)))
+    f.write_text("1600000 100000\n")
+    assert O.available_cpus() == 16 and O.default_writer_threads(1) == 8 and O.default_writer_threads(8) == 2
+    f.write_text("max 100000\n")
+    assert O.available_cpus() == 256 and O.default_writer_threads(8) == 8
+    f.write_text("50000 100000\n")          # half a CPU: never below one
+    assert O.available_cpus() == 1 and O.default_writer_threads(1) == 2
